@@ -1,0 +1,49 @@
+"""Builds libepos_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m epos_amd.build            # or epos_amd.build.build()
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so travels to the
+GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libepos_hip.so')
+
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
+         '-fPIC', '-shared']
+
+
+def sources():
+  return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def _stale():
+  if not os.path.exists(LIB_PATH):
+    return True
+  t = os.path.getmtime(LIB_PATH)
+  deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(
+      os.path.join(HERE, '..', 'include', '*.h'))
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+  """Compiles every HIP source into epos_amd/lib/libepos_hip.so."""
+  if not force and not _stale():
+    return LIB_PATH
+  os.makedirs(LIB_DIR, exist_ok=True)
+  cmd = [HIPCC] + FLAGS + ['-o', LIB_PATH] + sources()
+  if verbose:
+    print(' '.join(cmd))
+  subprocess.check_call(cmd)
+  return LIB_PATH
+
+
+if __name__ == '__main__':
+  print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,220 @@
+// Many-to-many 2D-3D correspondence extraction on gfx950 -- replaces
+// epos_lib/corresp.py:9-101 (establish_many_to_many) and misc.py:14-26.
+//
+// The reference masks pixels by object confidence, keeps for every masked pixel
+// the fragments with conf > max_conf * tau_b and emits one correspondence per
+// (pixel, kept fragment) in raster order, then ascending fragment id
+// (np.nonzero order, corresp.py:52,67). Here that is a stable stream compaction
+// in three launches, all integer-exact:
+//   1. corr_mask:  one wave per 64 pixels; lane = pixel for the object-confidence
+//                  test (ballot), then lane = fragment (F <= 64) for each masked
+//                  pixel: wave max, threshold, ballot -> 64-bit kept-fragment mask.
+//   2. corr_scan:  per slot exclusive scans (masked-pixel index, first row).
+//   3. corr_fill:  lane = fragment; row = slot base + pixel base + rank of the
+//                  fragment inside the mask (popcount of lower bits).
+// One "slot" = one (image, object) pair; all slots of a batch go in one launch.
+// HBM-bound byte/compare work: no MFMA here.
+#include "common.h"
+
+namespace epos {
+namespace {
+
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void corr_mask_kernel(
+    const float* __restrict__ obj_confs, const float* __restrict__ frag_confs,
+    const EposCorrSlot* __restrict__ slots, int P, int O, int F, float tau_a,
+    float tau_b, int32_t* px_flag, int32_t* corr_cnt, uint64_t* frag_mask) {
+  const int s = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (p0 >= P) return;                       // wave-uniform
+  const int img = slots[s].image, obj = slots[s].obj_id;
+  const int p = p0 + lane;
+  const int64_t pix0 = static_cast<int64_t>(img) * P;
+  bool masked = false;
+  if (p < P) masked = obj_confs[(pix0 + p) * (O + 1) + obj] > tau_a;  // corresp.py:46-47
+  uint64_t todo = __ballot(masked);
+  uint64_t mybits = 0;
+  while (todo) {                             // wave-uniform loop over masked pixels
+    const int j = __ffsll(static_cast<long long>(todo)) - 1;
+    todo &= todo - 1;
+    const float* fc = frag_confs + ((pix0 + p0 + j) * O + (obj - 1)) * F;
+    const float v = lane < F ? fc[lane] : -INFINITY;
+    const float m = wave_max64(v);           // corresp.py:63
+    const float thr = m * tau_b;             // f32 * f32 (numpy weak-scalar rule)
+    const uint64_t bits = __ballot(lane < F && v > thr);   // corresp.py:64, strict >
+    if (lane == j) mybits = bits;
+  }
+  if (p < P) {
+    const int64_t o = static_cast<int64_t>(s) * P + p;
+    px_flag[o] = masked ? 1 : 0;
+    corr_cnt[o] = __popcll(mybits);
+    frag_mask[o] = mybits;
+  }
+}
+
+// In-place exclusive scan of two int arrays of length P per slot.
+__global__ __launch_bounds__(1024) void corr_scan_kernel(int32_t* px, int32_t* cnt,
+                                                         int P, int32_t* totals) {
+  __shared__ int32_t sa[1024], sb[1024];
+  const int s = blockIdx.x, t = threadIdx.x;
+  int32_t* a = px + static_cast<int64_t>(s) * P;
+  int32_t* b = cnt + static_cast<int64_t>(s) * P;
+  const int chunk = (P + 1023) / 1024;
+  const int lo = min(t * chunk, P), hi = min(lo + chunk, P);
+  int32_t suma = 0, sumb = 0;
+  for (int i = lo; i < hi; ++i) { suma += a[i]; sumb += b[i]; }
+  sa[t] = suma; sb[t] = sumb;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+    int32_t va = 0, vb = 0;
+    if (t >= off) { va = sa[t - off]; vb = sb[t - off]; }
+    __syncthreads();
+    sa[t] += va; sb[t] += vb;
+    __syncthreads();
+  }
+  int32_t ra = sa[t] - suma, rb = sb[t] - sumb;   // exclusive prefix of the chunk
+  for (int i = lo; i < hi; ++i) {
+    const int32_t va = a[i], vb = b[i];
+    a[i] = ra; b[i] = rb;
+    ra += va; rb += vb;
+  }
+  if (t == 1023) { totals[2 * s] = sa[t]; totals[2 * s + 1] = sb[t]; }
+}
+
+__global__ void corr_slot_bases_kernel(const int32_t* totals, int S,
+                                       int64_t* slot_base) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t acc = 0;
+    for (int s = 0; s < S; ++s) { slot_base[s] = acc; acc += totals[2 * s + 1]; }
+    slot_base[S] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void corr_fill_kernel(
+    const float* __restrict__ obj_confs, const float* __restrict__ frag_confs,
+    const float* __restrict__ frag_coords, const double* __restrict__ centers,
+    const double* __restrict__ sizes, const EposCorrSlot* __restrict__ slots,
+    int P, int W, int O, int F, double inv_scale, const int32_t* px_off,
+    const int32_t* corr_off, const uint64_t* frag_mask, const int64_t* slot_base,
+    int64_t capacity, EposCorrOut out, int32_t* overflow) {
+  const int s = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (p0 >= P) return;
+  const int img = slots[s].image, obj = slots[s].obj_id;
+  const int p = p0 + lane;
+  const int64_t pix0 = static_cast<int64_t>(img) * P;
+  uint64_t mbits = 0;
+  int32_t pxo = 0, co = 0;
+  if (p < P) {
+    const int64_t o = static_cast<int64_t>(s) * P + p;
+    mbits = frag_mask[o]; pxo = px_off[o]; co = corr_off[o];
+  }
+  uint64_t todo = __ballot(mbits != 0);
+  const int64_t base_s = slot_base[s];
+  const double* cen = centers + static_cast<int64_t>(obj - 1) * F * 3;
+  const double* siz = sizes + static_cast<int64_t>(obj - 1) * F;
+  while (todo) {
+    const int j = __ffsll(static_cast<long long>(todo)) - 1;
+    todo &= todo - 1;
+    const uint64_t bits = __shfl(mbits, j, 64);
+    const int32_t px_id = __shfl(pxo, j, 64);
+    const int32_t row0 = __shfl(co, j, 64);
+    if ((bits >> lane) & 1ull) {
+      const int rank = __popcll(bits & ((1ull << lane) - 1ull));
+      const int64_t row = base_s + row0 + rank;
+      if (row >= capacity) {
+        *overflow = 1;
+      } else {
+      const int pj = p0 + j;
+      const int y = pj / W, x = pj - y * W;
+      const int64_t fidx = ((pix0 + pj) * O + (obj - 1)) * F + lane;
+      const float conf_obj = obj_confs[(pix0 + pj) * (O + 1) + obj];
+      const float conf_frag = frag_confs[fidx];
+      out.px_id[row] = px_id;
+      out.frag_id[row] = lane;
+      // misc.py:26: scale * (idx + 0.5), x first (corresp.py:55-57).
+      out.coord_2d[2 * row + 0] = inv_scale * (static_cast<double>(x) + 0.5);
+      out.coord_2d[2 * row + 1] = inv_scale * (static_cast<double>(y) + 0.5);
+      const double sz = siz[lane];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        // corresp.py:76-78: the in-place f32 `*=` rounds the f64 product to f32
+        // before the f64 add.
+        const float local = static_cast<float>(
+            static_cast<double>(frag_coords[fidx * 3 + d]) * sz);
+        out.coord_3d[3 * row + d] = cen[lane * 3 + d] + static_cast<double>(local);
+      }
+      out.conf_obj[row] = conf_obj;
+      out.conf_frag[row] = conf_frag;
+      out.conf[row] = conf_obj * conf_frag;                  // corresp.py:82-84
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace epos
+
+using namespace epos;
+
+extern "C" int epos_corr_count(const float* obj_confs, const float* frag_confs,
+                               const EposCorrSlot* slots, int S, int B, int P,
+                               int O, int F, float min_obj_conf,
+                               float min_frag_rel_conf, int32_t* px_off,
+                               int32_t* corr_off, uint64_t* frag_mask,
+                               int32_t* totals, void* stream) {
+  EPOS_REQUIRE(obj_confs && frag_confs && slots && px_off && corr_off &&
+               frag_mask && totals, "null pointer");
+  EPOS_REQUIRE(F >= 1 && F <= 64, "num_frags must be in [1, 64]");
+  EPOS_REQUIRE(B > 0 && P > 0 && O > 0, "empty problem");
+  if (S == 0) return EPOS_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(static_cast<unsigned>(ceil_div(P, 256)), S);
+  hipLaunchKernelGGL(corr_mask_kernel, grid, dim3(256), 0, st, obj_confs,
+                     frag_confs, slots, P, O, F, min_obj_conf, min_frag_rel_conf,
+                     px_off, corr_off, frag_mask);
+  int rc = launch_status("corr_mask_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(corr_scan_kernel, dim3(S), dim3(1024), 0, st, px_off,
+                     corr_off, P, totals);
+  return launch_status("corr_scan_kernel");
+}
+
+extern "C" int epos_corr_slot_bases(const int32_t* totals, int S,
+                                    int64_t* slot_base, void* stream) {
+  EPOS_REQUIRE(totals && slot_base, "null pointer");
+  hipLaunchKernelGGL(corr_slot_bases_kernel, dim3(1), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), totals, S, slot_base);
+  return launch_status("corr_slot_bases_kernel");
+}
+
+extern "C" int epos_corr_fill(const float* obj_confs, const float* frag_confs,
+                              const float* frag_coords, const double* frag_centers,
+                              const double* frag_sizes, const EposCorrSlot* slots,
+                              int S, int B, int P, int W, int O, int F,
+                              double inv_scale, const int32_t* px_off,
+                              const int32_t* corr_off, const uint64_t* frag_mask,
+                              const int64_t* slot_base, int64_t capacity,
+                              const EposCorrOut* out, int32_t* overflow,
+                              void* stream) {
+  EPOS_REQUIRE(obj_confs && frag_confs && frag_coords && frag_centers &&
+               frag_sizes && slots && px_off && corr_off && frag_mask &&
+               slot_base && out && overflow, "null pointer");
+  EPOS_REQUIRE(F >= 1 && F <= 64, "num_frags must be in [1, 64]");
+  EPOS_REQUIRE(W > 0 && P % W == 0, "P must be a multiple of W");
+  if (S == 0) return EPOS_OK;
+  dim3 grid(static_cast<unsigned>(ceil_div(P, 256)), S);
+  hipLaunchKernelGGL(corr_fill_kernel, grid, dim3(256), 0,
+                     static_cast<hipStream_t>(stream), obj_confs, frag_confs,
+                     frag_coords, frag_centers, frag_sizes, slots, P, W, O, F,
+                     inv_scale, px_off, corr_off, frag_mask, slot_base, capacity,
+                     *out, overflow);
+  return launch_status("corr_fill_kernel");
+}

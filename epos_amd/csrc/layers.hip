@@ -1,0 +1,274 @@
+// HBM-bound layer kernels of the EPOS network for gfx950 (NHWC fp32):
+// depthwise 3x3 (+folded BN, ReLU before/after), im2col for the two dense 3x3
+// stem convs, global average pool, bilinear resize (align_corners), grouped
+// softmax and argmax. All accesses are float4 along the channel axis (the
+// contiguous axis of NHWC), 16 B per lane, so a wave moves 1 KiB per instruction.
+#include "common.h"
+
+namespace epos {
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) {
+  *reinterpret_cast<float4*>(p) = v;
+}
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f),
+                     fmaxf(v.w, 0.f));
+}
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y),
+                     fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+
+// --------------------------------------------------------------------------
+// Depthwise 3x3. One thread = one output pixel x 4 channels; consecutive threads
+// walk the channel axis first (coalesced), then pixels.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
+                                                           int c4n,
+                                                           int64_t total) {
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int c = static_cast<int>(id % c4n) * 4;
+  int64_t pix = id / c4n;
+  const int xo = static_cast<int>(pix % p.Wo);
+  pix /= p.Wo;
+  const int yo = static_cast<int>(pix % p.Ho);
+  const int b = static_cast<int>(pix / p.Ho);
+  const int pad = p.rate;  // SAME (stride 1) and fixed_padding (stride 2) agree
+  float4 acc = ld4(p.bias + c);
+  const float* xb = p.X + static_cast<int64_t>(b) * p.Hi * p.Wi * p.ldx + c;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yi = yo * p.stride - pad + ky * p.rate;
+    if (yi < 0 || yi >= p.Hi) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xi = xo * p.stride - pad + kx * p.rate;
+      if (xi < 0 || xi >= p.Wi) continue;
+      float4 v = ld4(xb + (static_cast<int64_t>(yi) * p.Wi + xi) * p.ldx);
+      if (p.relu_in) v = relu4(v);
+      acc = fma4(v, ld4(p.w9c + (ky * 3 + kx) * p.C + c), acc);
+    }
+  }
+  if (p.relu_out) acc = relu4(acc);
+  st4(p.Y + ((static_cast<int64_t>(b) * p.Ho + yo) * p.Wo + xo) * p.ldy + c, acc);
+}
+
+// --------------------------------------------------------------------------
+// im2col for dense 3x3 convs (scalar: C may be 3).
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_kernel(EposIm2colArgs p,
+                                                        int64_t total) {
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int col = static_cast<int>(id % p.ldcol);
+  int64_t pix = id / p.ldcol;
+  float v = 0.f;
+  if (col < 9 * p.C) {
+    const int tap = col / p.C, c = col - tap * p.C;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int xo = static_cast<int>(pix % p.Wo);
+    const int64_t t = pix / p.Wo;
+    const int yo = static_cast<int>(t % p.Ho);
+    const int b = static_cast<int>(t / p.Ho);
+    const int yi = yo * p.stride - p.pad + ky * p.rate;
+    const int xi = xo * p.stride - p.pad + kx * p.rate;
+    if (yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi) {
+      v = p.X[((static_cast<int64_t>(b) * p.Hi + yi) * p.Wi + xi) * p.ldx + c];
+      if (p.preprocess) v = (2.0f / 255.0f) * v - 1.0f;   // feature.py:171-174
+    }
+  }
+  p.col[pix * p.ldcol + col] = v;
+}
+
+// --------------------------------------------------------------------------
+// Global average pool: block = (image, 64-channel group); 16 float4 lanes x 64
+// row phases; fixed-order LDS reduction (deterministic).
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void global_avg_pool_kernel(
+    const float* X, int64_t ldx, float* Y, int HW, int C) {
+  __shared__ float4 part[64][16];
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 15) * 4;
+  const int phase = threadIdx.x >> 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    const float* xb = X + static_cast<int64_t>(b) * HW * ldx + c;
+    for (int r = phase; r < HW; r += 64) {
+      const float4 v = ld4(xb + static_cast<int64_t>(r) * ldx);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[phase][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (phase == 0 && c < C) {
+    float4 t = part[0][threadIdx.x];
+    for (int i = 1; i < 64; ++i) {
+      const float4 v = part[i][threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    const float n = static_cast<float>(HW);
+    st4(Y + static_cast<int64_t>(b) * C + c,
+        make_float4(t.x / n, t.y / n, t.z / n, t.w / n));
+  }
+}
+
+// --------------------------------------------------------------------------
+// Bilinear resize, align_corners=True (TF resize_bilinear arithmetic order).
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(
+    const float* X, int64_t ldx, float* Y, int64_t ldy, int Hi, int Wi, int Ho,
+    int Wo, int c4n, float sy, float sx, int64_t total) {
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int c = static_cast<int>(id % c4n) * 4;
+  int64_t pix = id / c4n;
+  const int xo = static_cast<int>(pix % Wo);
+  pix /= Wo;
+  const int yo = static_cast<int>(pix % Ho);
+  const int b = static_cast<int>(pix / Ho);
+  const float fy = yo * sy, fx = xo * sx;
+  const int y0 = static_cast<int>(floorf(fy)), x0 = static_cast<int>(floorf(fx));
+  const int y1 = min(static_cast<int>(ceilf(fy)), Hi - 1);
+  const int x1 = min(static_cast<int>(ceilf(fx)), Wi - 1);
+  const float ly = fy - y0, lx = fx - x0;
+  const float* xb = X + static_cast<int64_t>(b) * Hi * Wi * ldx + c;
+  const float4 tl = ld4(xb + (static_cast<int64_t>(y0) * Wi + x0) * ldx);
+  const float4 tr = ld4(xb + (static_cast<int64_t>(y0) * Wi + x1) * ldx);
+  const float4 bl = ld4(xb + (static_cast<int64_t>(y1) * Wi + x0) * ldx);
+  const float4 br = ld4(xb + (static_cast<int64_t>(y1) * Wi + x1) * ldx);
+  auto lerp = [](float a, float bb, float w) { return a + (bb - a) * w; };
+  float4 o;
+  o.x = lerp(lerp(tl.x, tr.x, lx), lerp(bl.x, br.x, lx), ly);
+  o.y = lerp(lerp(tl.y, tr.y, lx), lerp(bl.y, br.y, lx), ly);
+  o.z = lerp(lerp(tl.z, tr.z, lx), lerp(bl.z, br.z, lx), ly);
+  o.w = lerp(lerp(tl.w, tr.w, lx), lerp(bl.w, br.w, lx), ly);
+  st4(Y + ((static_cast<int64_t>(b) * Ho + yo) * Wo + xo) * ldy + c, o);
+}
+
+// --------------------------------------------------------------------------
+// Softmax over groups of G <= 64 consecutive floats; one wave per group.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void softmax_groups_kernel(float* X,
+                                                             int64_t n_groups,
+                                                             int G) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (g >= n_groups) return;
+  float* x = X + g * G;
+  const bool on = lane < G;
+  const float v = on ? x[lane] : -INFINITY;
+  const float m = wave_max(v);
+  const float e = on ? expf(v - m) : 0.f;
+  const float s = wave_sum(e);
+  if (on) x[lane] = e / s;
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float* X, int64_t ldx,
+                                                     int64_t* labels, int64_t P,
+                                                     int C) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float* x = X + i * ldx;
+  float best = x[0];
+  int arg = 0;
+  for (int c = 1; c < C; ++c) {
+    const float v = x[c];
+    if (v > best) { best = v; arg = c; }
+  }
+  labels[i] = arg;
+}
+
+inline unsigned blocks_for(int64_t total, int threads) {
+  return static_cast<unsigned>(ceil_div(total, threads));
+}
+
+}  // namespace
+}  // namespace epos
+
+using namespace epos;
+
+extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
+  EPOS_REQUIRE(a && a->X && a->w9c && a->bias && a->Y, "null pointer");
+  EPOS_REQUIRE(a->C % 4 == 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0,
+               "C, ldx, ldy must be multiples of 4");
+  EPOS_REQUIRE(a->stride == 1 || (a->stride == 2 && a->rate == 1),
+               "stride 2 requires rate 1");
+  const int c4n = a->C / 4;
+  const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * c4n;
+  if (total == 0) return EPOS_OK;
+  hipLaunchKernelGGL(depthwise3x3_kernel, dim3(blocks_for(total, 256)), dim3(256),
+                     0, static_cast<hipStream_t>(stream), *a, c4n, total);
+  return launch_status("depthwise3x3_kernel");
+}
+
+extern "C" int epos_im2col3x3_f32(const EposIm2colArgs* a, void* stream) {
+  EPOS_REQUIRE(a && a->X && a->col, "null pointer");
+  EPOS_REQUIRE(a->ldcol >= 9 * a->C, "ldcol too small");
+  const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * a->ldcol;
+  if (total == 0) return EPOS_OK;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), *a, total);
+  return launch_status("im2col3x3_kernel");
+}
+
+extern "C" int epos_global_avg_pool_f32(const float* X, int64_t ldx, float* Y,
+                                        int B, int HW, int C, void* stream) {
+  EPOS_REQUIRE(X && Y, "null pointer");
+  EPOS_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && HW > 0, "C, ldx multiples of 4");
+  hipLaunchKernelGGL(global_avg_pool_kernel,
+                     dim3(static_cast<unsigned>(ceil_div(C, 64)), B), dim3(1024),
+                     0, static_cast<hipStream_t>(stream), X, ldx, Y, HW, C);
+  return launch_status("global_avg_pool_kernel");
+}
+
+extern "C" int epos_resize_bilinear_f32(const float* X, int64_t ldx, float* Y,
+                                        int64_t ldy, int B, int Hi, int Wi,
+                                        int Ho, int Wo, int C, void* stream) {
+  EPOS_REQUIRE(X && Y, "null pointer");
+  EPOS_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "multiples of 4");
+  const float sy = Ho > 1 ? static_cast<float>(Hi - 1) / (Ho - 1) : 0.f;
+  const float sx = Wo > 1 ? static_cast<float>(Wi - 1) / (Wo - 1) : 0.f;
+  const int c4n = C / 4;
+  const int64_t total = static_cast<int64_t>(B) * Ho * Wo * c4n;
+  if (total == 0) return EPOS_OK;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks_for(total, 256)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, Y,
+                     ldy, Hi, Wi, Ho, Wo, c4n, sy, sx, total);
+  return launch_status("resize_bilinear_kernel");
+}
+
+extern "C" int epos_softmax_groups_f32(float* X, int64_t n_groups, int G,
+                                       void* stream) {
+  EPOS_REQUIRE(X, "null pointer");
+  EPOS_REQUIRE(G >= 1 && G <= 64, "G must be in [1, 64]");
+  if (n_groups == 0) return EPOS_OK;
+  hipLaunchKernelGGL(softmax_groups_kernel, dim3(blocks_for(n_groups, 4)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), X, n_groups,
+                     G);
+  return launch_status("softmax_groups_kernel");
+}
+
+extern "C" int epos_argmax_i64(const float* X, int64_t ldx, int64_t* labels,
+                               int64_t P, int C, void* stream) {
+  EPOS_REQUIRE(X && labels, "null pointer");
+  if (P == 0) return EPOS_OK;
+  hipLaunchKernelGGL(argmax_kernel, dim3(blocks_for(P, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), X, ldx, labels, P, C);
+  return launch_status("argmax_kernel");
+}

@@ -1,0 +1,420 @@
+"""EPOS network (DeepLabv3+/Xception-65) executor for MI355X.
+
+Builds, once per (batch, height, width, num_objs, num_frags), a static plan of
+fused HIP launches for the forward pass that the reference builds as a TF graph
+in ``model.predict`` (model.py:629-687 -> multi_scale_logits :517 -> get_logits
+:461 -> feature.extract_features -> net_xception.xception_65), allocates every
+activation buffer in HBM up front (NHWC fp32, the reference's layout and dtype)
+and replays the plan on the current HIP stream -- eagerly or as a captured
+hipGraph (no tracing compiler: the plan is explicit).
+
+Fusion groups:
+  * BatchNorm is folded into the preceding conv at weight-load time;
+  * depthwise 3x3 (+BN, ReLU before/after) is one launch;
+  * pointwise 1x1 (+BN, +residual add, +ReLU) is one fp32-MFMA GEMM launch that
+    can read/write channel slices of the ASPP / decoder concat buffers, so no
+    concat copy exists;
+  * the two dense 3x3 stem convs are im2col + the same GEMM.
+torch is used for device memory and streams only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from epos_amd import _lib
+from epos_amd import weights as W
+
+XCEPTION_BN_EPS = 1e-3   # feature.py:300-307
+HEAD_BN_EPS = 1e-5       # model.py:194-199, 307-312
+
+
+def _ptr(t, offset_elems=0):
+  return ctypes.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
+def scale_dimension(dim, scale):
+  """model.py:100-114."""
+  return int((float(dim) - 1.0) * scale + 1.0)
+
+
+class EposNet(object):
+  """Static-shape forward plan. ``forward(images)`` returns the logits buffers;
+  ``predict(images)`` the reference's prediction dict (model.py:629-687)."""
+
+  def __init__(self, checkpoint, batch, height, width, num_objs, num_frags=64,
+               model_variant='xception_65', encoder_output_stride=8,
+               decoder_output_stride=4, atrous_rates=(12, 24, 36),
+               multi_grid=None, device='cuda:0'):
+    if model_variant != 'xception_65':
+      raise ValueError('Unsupported model variant: %s' % model_variant)
+    if encoder_output_stride != 8 or decoder_output_stride != 4:
+      raise ValueError('Only encoder OS 8 / decoder OS 4 (common.py:127-135).')
+    if not torch.cuda.is_available():
+      raise _lib.EposError('EposNet needs a HIP device (no CPU fallback).')
+    self.lib = _lib.load()
+    self.dev = torch.device(device)
+    self.B, self.H, self.W = batch, height, width
+    self.num_objs, self.num_frags = num_objs, num_frags
+    self.atrous_rates = tuple(atrous_rates)
+    self.multi_grid = list(multi_grid) if multi_grid else [1, 1, 1]
+    self.ckpt = checkpoint
+    self._keep = []          # device tensors owned by the plan
+    self.ops = []            # (name, callable(stream))
+    self.flops = 0           # multiply-add * 2 of the whole plan
+    self.op_flops = {}
+    self._graph = None
+    self._build_plan()
+
+  # ------------------------------------------------------------ buffers ---
+  def _empty(self, *shape, dtype=torch.float32):
+    t = torch.empty(*shape, dtype=dtype, device=self.dev)
+    self._keep.append(t)
+    return t
+
+  def _dev(self, arr):
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
+    self._keep.append(t)
+    return t
+
+  # ------------------------------------------------------ weight packing ---
+  def _pack_pointwise(self, w_kn, scale, bias):
+    """w_kn [K, N] (TF HWIO with H=W=1), BN scale folded, packed for the GEMM."""
+    k, n = w_kn.shape
+    w = np.ascontiguousarray(w_kn.astype(np.float32) * scale[None, :].astype(
+        np.float32))
+    kpad = (k + 3) // 4 * 4
+    if kpad != k:
+      w = np.concatenate([w, np.zeros((kpad - k, n), np.float32)], 0)
+    total = self.lib.epos_pack_pointwise_weights(None, kpad, n, None)
+    dst = np.empty(total, np.float32)
+    self.lib.epos_pack_pointwise_weights(
+        w.ctypes.data_as(ctypes.c_void_p), kpad, n,
+        dst.ctypes.data_as(ctypes.c_void_p))
+    npad = (n + 127) // 128 * 128
+    b = np.zeros(npad, np.float32)
+    b[:n] = bias
+    return self._dev(dst), self._dev(b), kpad
+
+  def _conv_params(self, scope, eps):
+    """1x1 / dense conv followed by BN -> (w [K,N], scale, bias)."""
+    w = self.ckpt[scope + '/weights']
+    kh, kw, cin, cout = w.shape
+    scale, bias = W.fold_bn(self.ckpt, scope, eps, 'conv')
+    return w.reshape(kh * kw * cin, cout), scale, bias
+
+  def _dw_params(self, scope, eps):
+    w = self.ckpt[scope + '/depthwise_weights']          # [3,3,C,1]
+    scale, bias = W.fold_bn(self.ckpt, scope, eps, 'dw')
+    w9c = (w[:, :, :, 0].reshape(9, -1) * scale[None, :]).astype(np.float32)
+    return self._dev(w9c), self._dev(bias)
+
+  # --------------------------------------------------------------- ops ---
+  def _add(self, name, fn, flops=0):
+    self.ops.append((name, fn))
+    self.flops += flops
+    self.op_flops[name] = flops
+
+  def _pointwise(self, name, a, a_off, lda, m, k, w_kn, scale, bias, c, c_off,
+                 ldc, relu, relu_in=False, res=None, res_off=0, ldr=0, sub=1,
+                 ho=0, wo=0, hi=0, wi=0):
+    wp, bp, kpad = self._pack_pointwise(w_kn, scale, bias)
+    n = w_kn.shape[1]
+    assert kpad == k or (kpad > k and lda >= kpad), (name, k, kpad, lda)
+    args = _lib.PointwiseArgs(
+        A=_ptr(a, a_off), lda=lda, Wp=_ptr(wp), bias=_ptr(bp),
+        R=_ptr(res, res_off) if res is not None else None, ldr=ldr,
+        C=_ptr(c, c_off), ldc=ldc, M=m, N=n, K=kpad, relu=int(relu),
+        relu_in=int(relu_in), sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi)
+    lib = self.lib
+
+    def run(stream, args=args):
+      _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), stream), name)
+    self._add(name, run, 2 * m * n * k)
+
+  def _depthwise(self, name, x, ldx, hi, wi, c, stride, rate, scope, eps,
+                 relu_in, relu_out):
+    ho = hi if stride == 1 else (hi - 1) // 2 + 1
+    wo = wi if stride == 1 else (wi - 1) // 2 + 1
+    w9c, bias = self._dw_params(scope, eps)
+    y = self._empty(self.B, ho, wo, c)
+    args = _lib.DepthwiseArgs(
+        X=_ptr(x), ldx=ldx, w9c=_ptr(w9c), bias=_ptr(bias), Y=_ptr(y), ldy=c,
+        B=self.B, Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c, stride=stride, rate=rate,
+        relu_in=int(relu_in), relu_out=int(relu_out))
+    lib = self.lib
+
+    def run(stream, args=args):
+      _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(args), stream), name)
+    self._add(name, run, 2 * 9 * self.B * ho * wo * c)
+    return y, ho, wo
+
+  def _stem_conv(self, name, x, hi, wi, cin, scope, stride, preprocess):
+    """resnet_utils.conv2d_same 3x3 (+BN+ReLU) = im2col + GEMM
+    (net_xception.py:460-463)."""
+    ho = hi if stride == 1 else (hi - 1) // 2 + 1
+    wo = wi if stride == 1 else (wi - 1) // 2 + 1
+    k = 9 * cin
+    ldcol = (k + 3) // 4 * 4
+    m = self.B * ho * wo
+    col = self._empty(m, ldcol)
+    args = _lib.Im2colArgs(
+        X=_ptr(x), ldx=cin, col=_ptr(col), ldcol=ldcol, B=self.B, Hi=hi, Wi=wi,
+        Ho=ho, Wo=wo, C=cin, stride=stride, rate=1, pad=1,
+        preprocess=int(preprocess))
+    lib = self.lib
+
+    def run(stream, args=args):
+      _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(args), stream), name)
+    self._add(name + '/im2col', run)
+    w_kn, scale, bias = self._conv_params(scope, XCEPTION_BN_EPS)
+    cout = w_kn.shape[1]
+    y = self._empty(self.B, ho, wo, cout)
+    self._pointwise(name, col, 0, ldcol, m, k, w_kn, scale, bias, y, 0, cout,
+                    relu=True)
+    return y, ho, wo, cout
+
+  def _xception_module(self, scope, x, hi, wi, cin, depths, skip, act_in_sep,
+                       stride, rate, unit_rates):
+    """net_xception.py:197-323 as 3 x (depthwise launch + GEMM launch); the skip
+    connection is the residual input of the third GEMM's epilogue."""
+    eps = XCEPTION_BN_EPS
+    ho = hi if stride == 1 else (hi - 1) // 2 + 1
+    wo = wi if stride == 1 else (wi - 1) // 2 + 1
+    shortcut = None
+    if skip == 'conv':
+      w_kn, sc, bi = self._conv_params(scope + '/shortcut', eps)
+      shortcut = self._empty(self.B, ho, wo, depths[2])
+      self._pointwise(scope + '/shortcut', x, 0, cin, self.B * ho * wo, cin,
+                      w_kn, sc, bi, shortcut, 0, depths[2], relu=False,
+                      sub=stride, ho=ho, wo=wo, hi=hi, wi=wi)
+    r, rh, rw, rc = x, hi, wi, cin
+    taps = {}
+    for i in range(3):
+      sc = '%s/separable_conv%d' % (scope, i + 1)
+      s_i = stride if i == 2 else 1
+      d, dh, dw_ = self._depthwise(
+          sc + '_depthwise', r, rc, rh, rw, rc, s_i, rate * unit_rates[i],
+          sc + '_depthwise', eps, relu_in=not act_in_sep, relu_out=act_in_sep)
+      w_kn, scl, bi = self._conv_params(sc + '_pointwise', eps)
+      y = self._empty(self.B, dh, dw_, depths[i])
+      res, ldr = None, 0
+      if i == 2 and skip == 'conv':
+        res, ldr = shortcut, depths[2]
+      elif i == 2 and skip == 'sum':
+        res, ldr = x, cin
+      self._pointwise(sc + '_pointwise', d, 0, rc, self.B * dh * dw_, rc, w_kn,
+                      scl, bi, y, 0, depths[i], relu=act_in_sep, res=res,
+                      ldr=ldr)
+      taps[i] = y
+      r, rh, rw, rc = y, dh, dw_, depths[i]
+    return r, rh, rw, rc, taps
+
+  # -------------------------------------------------------------- plan ---
+  def _build_plan(self):
+    B, H, Wd = self.B, self.H, self.W
+    net = 'xception_65'
+    self.images = self._empty(B, H, Wd, 3)
+    x, h, w, c = self._stem_conv(net + '/entry_flow/conv1_1', self.images, H, Wd,
+                                 3, net + '/entry_flow/conv1_1', 2, True)
+    x, h, w, c = self._stem_conv(net + '/entry_flow/conv1_2', x, h, w, c,
+                                 net + '/entry_flow/conv1_2', 1, False)
+    # stack_blocks_dense (net_xception.py:326-393) with output_stride 8/2 = 4.
+    target, current_stride, rate = 4, 1, 1
+    low_level = None
+    blocks = [
+        ('entry_flow/block1', [128, 128, 128], 'conv', False, 1, 2, [1, 1, 1]),
+        ('entry_flow/block2', [256, 256, 256], 'conv', False, 1, 2, [1, 1, 1]),
+        ('entry_flow/block3', [728, 728, 728], 'conv', False, 1, 2, [1, 1, 1]),
+        ('middle_flow/block1', [728, 728, 728], 'sum', False, 16, 1, [1, 1, 1]),
+        ('exit_flow/block1', [728, 1024, 1024], 'conv', False, 1, 2, [1, 1, 1]),
+        ('exit_flow/block2', [1536, 1536, 2048], 'none', True, 1, 1,
+         self.multi_grid),
+    ]
+    for bscope, depths, skip, act, units, stride, url in blocks:
+      for u in range(units):
+        scope = '%s/%s/unit_%d/xception_module' % (net, bscope, u + 1)
+        if current_stride == target:
+          x, h, w, c, taps = self._xception_module(
+              scope, x, h, w, c, depths, skip, act, 1, rate, url)
+          rate *= stride
+        else:
+          x, h, w, c, taps = self._xception_module(
+              scope, x, h, w, c, depths, skip, act, stride, 1, url)
+          current_stride *= stride
+        if bscope == 'entry_flow/block2':
+          low_level = (taps[1], taps[1].shape[1], taps[1].shape[2], depths[1])
+    self.encoder = x
+    eh, ew, ec = h, w, c
+    lib = self.lib
+
+    # ---- ASPP (model.py:213-265): branches write slices of one 1280-wide buffer.
+    nb = 2 + len(self.atrous_rates)
+    cat = self._empty(B, eh, ew, 256 * nb)
+    ldcat = 256 * nb
+    m_enc = B * eh * ew
+    pooled = self._empty(B, ec)
+
+    def run_pool(stream, x=x, pooled=pooled):
+      _lib.check(lib.epos_global_avg_pool_f32(_ptr(x), ec, _ptr(pooled), B,
+                                              eh * ew, ec, stream), 'avg_pool')
+    self._add('image_pooling/mean', run_pool)
+    w_kn, sc, bi = self._conv_params('image_pooling', HEAD_BN_EPS)
+    pool_feat = self._empty(B, 256)
+    self._pointwise('image_pooling', pooled, 0, ec, B, ec, w_kn, sc, bi,
+                    pool_feat, 0, 256, relu=True)
+
+    def run_bcast(stream, pool_feat=pool_feat, cat=cat):
+      _lib.check(lib.epos_resize_bilinear_f32(
+          _ptr(pool_feat), 256, _ptr(cat), ldcat, B, 1, 1, eh, ew, 256, stream),
+                 'image_pooling/resize')
+    self._add('image_pooling/resize', run_bcast)
+    w_kn, sc, bi = self._conv_params('aspp0', HEAD_BN_EPS)
+    self._pointwise('aspp0', x, 0, ec, m_enc, ec, w_kn, sc, bi, cat, 256, ldcat,
+                    relu=True)
+    for i, r in enumerate(self.atrous_rates, 1):
+      d, _, _ = self._depthwise('aspp%d_depthwise' % i, x, ec, eh, ew, ec, 1, r,
+                                'aspp%d_depthwise' % i, HEAD_BN_EPS, False, True)
+      w_kn, sc, bi = self._conv_params('aspp%d_pointwise' % i, HEAD_BN_EPS)
+      self._pointwise('aspp%d_pointwise' % i, d, 0, ec, m_enc, ec, w_kn, sc, bi,
+                      cat, 256 * (i + 1), ldcat, relu=True)
+    w_kn, sc, bi = self._conv_params('concat_projection', HEAD_BN_EPS)
+    proj = self._empty(B, eh, ew, 256)
+    self._pointwise('concat_projection', cat, 0, ldcat, m_enc, ldcat, w_kn, sc,
+                    bi, proj, 0, 256, relu=True)
+    self.aspp_concat, self.concat_projection = cat, proj
+
+    # ---- decoder (model.py:268-393).
+    ll, lh, lw, lc = low_level
+    dh = scale_dimension(H, 1.0 / 4)
+    dw_ = scale_dimension(Wd, 1.0 / 4)
+    assert (lh, lw) == (dh, dw_), ((lh, lw), (dh, dw_))
+    dcat = self._empty(B, dh, dw_, 304)
+
+    def run_up(stream, proj=proj, dcat=dcat):
+      _lib.check(lib.epos_resize_bilinear_f32(
+          _ptr(proj), 256, _ptr(dcat), 304, B, eh, ew, dh, dw_, 256, stream),
+                 'decoder/resize')
+    self._add('decoder/resize', run_up)
+    m_dec = B * dh * dw_
+    w_kn, sc, bi = self._conv_params('decoder/feature_projection0', HEAD_BN_EPS)
+    self._pointwise('decoder/feature_projection0', ll, 0, lc, m_dec, lc, w_kn,
+                    sc, bi, dcat, 256, 304, relu=True)
+    self.decoder_concat = dcat
+    x, c = dcat, 304
+    for j in range(2):
+      scope = 'decoder/decoder_conv%d' % j
+      d, _, _ = self._depthwise(scope + '_depthwise', x, c, dh, dw_, c, 1, 1,
+                                scope + '_depthwise', HEAD_BN_EPS, False, True)
+      w_kn, sc, bi = self._conv_params(scope + '_pointwise', HEAD_BN_EPS)
+      y = self._empty(B, dh, dw_, 256)
+      self._pointwise(scope + '_pointwise', d, 0, c, m_dec, c, w_kn, sc, bi, y,
+                      0, 256, relu=True)
+      x, c = y, 256
+    self.decoder_out = x
+    self.out_h, self.out_w = dh, dw_
+
+    # ---- logits (model.py:396-458), sorted(name) order (model.py:503).
+    self.logits = {}
+    for name, ch in sorted(W.outputs_to_num_channels(
+        self.num_objs, self.num_frags).items()):
+      wt = self.ckpt['logits/%s/weights' % name].reshape(256, ch)
+      bs = self.ckpt['logits/%s/biases' % name]
+      buf = self._empty(B, dh, dw_, ch)
+      self._pointwise('logits/' + name, x, 0, 256, m_dec, 256, wt,
+                      np.ones(ch, np.float32), bs, buf, 0, ch, relu=False)
+      self.logits[name] = buf
+
+    # ---- predict post-ops (model.py:677-683): softmax in place, argmax.
+    self.post_ops = []
+    obj = self.logits[W.PRED_OBJ_CONF]
+    frag = self.logits[W.PRED_FRAG_CONF]
+    self.obj_label = self._empty(B, dh, dw_, dtype=torch.int64)
+    O, F = self.num_objs, self.num_frags
+    if F > 64:
+      raise ValueError('num_frags > 64 is not supported by the HIP softmax.')
+
+    def run_softmax_obj(stream):
+      _lib.check(lib.epos_softmax_groups_f32(_ptr(obj), m_dec, O + 1, stream),
+                 'softmax_obj')
+
+    def run_softmax_frag(stream):
+      _lib.check(lib.epos_softmax_groups_f32(_ptr(frag), m_dec * O, F, stream),
+                 'softmax_frag')
+
+    def run_argmax(stream):
+      _lib.check(lib.epos_argmax_i64(_ptr(obj), O + 1, _ptr(self.obj_label),
+                                     m_dec, O + 1, stream), 'argmax')
+    self.post_ops = [('softmax_obj', run_softmax_obj),
+                     ('softmax_frag', run_softmax_frag),
+                     ('argmax', run_argmax)]
+
+  # ----------------------------------------------------------- running ---
+  def _stream(self):
+    return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+  def run_plan(self, with_post=True):
+    s = self._stream()
+    for _, fn in self.ops:
+      fn(s)
+    if with_post:
+      for _, fn in self.post_ops:
+        fn(s)
+
+  def set_images(self, images):
+    """images: float32 [B,H,W,3] in [0,255] (host numpy or device tensor)."""
+    t = torch.as_tensor(images)
+    if t.dtype != torch.float32:
+      t = t.float()
+    self.images.copy_(t.reshape(self.B, self.H, self.W, 3), non_blocking=True)
+
+  def capture_graph(self):
+    """Captures the whole plan into one hipGraph (stream capture)."""
+    torch.cuda.synchronize(self.dev)
+    side = torch.cuda.Stream(self.dev)
+    with torch.cuda.stream(side):
+      self.run_plan()                      # warm-up outside capture
+    torch.cuda.synchronize(self.dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+      self.run_plan()
+    self._graph = g
+    return g
+
+  def forward(self, images=None, use_graph=False):
+    """Runs the plan (logits + softmax/argmax post-ops) on the current stream and
+    returns the prediction dict of ``model.predict`` (model.py:629-687) as views
+    of the plan's HBM buffers (valid until the next forward)."""
+    if images is not None:
+      self.set_images(images)
+    if use_graph:
+      if self._graph is None:
+        self.capture_graph()
+      self._graph.replay()
+    else:
+      self.run_plan()
+    B, h, w = self.B, self.out_h, self.out_w
+    O, F = self.num_objs, self.num_frags
+    return {
+        W.PRED_OBJ_CONF: self.logits[W.PRED_OBJ_CONF],
+        W.PRED_OBJ_LABEL: self.obj_label,
+        W.PRED_FRAG_CONF: self.logits[W.PRED_FRAG_CONF].view(B, h, w, O, F),
+        W.PRED_FRAG_LOC: self.logits[W.PRED_FRAG_LOC].view(B, h, w, O, F, 3),
+    }
+
+  def time_ops(self, iters=3):
+    """Per-launch HIP-event timing of the plan (diagnostics)."""
+    out = []
+    s = self._stream()
+    for name, fn in self.ops:
+      fn(s)
+      torch.cuda.synchronize(self.dev)
+      e0 = torch.cuda.Event(enable_timing=True)
+      e1 = torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(iters):
+        fn(s)
+      e1.record()
+      torch.cuda.synchronize(self.dev)
+      out.append((name, e0.elapsed_time(e1) / iters, self.op_flops.get(name, 0)))
+    return out

@@ -1,0 +1,234 @@
+/*
+ * epos_hip.h -- C ABI of libepos_hip.so, the MI355X (gfx950) implementation of
+ * the EPOS inference hot path (thodan/epos): DeepLabv3+/Xception-65 forward,
+ * many-to-many 2D-3D correspondence extraction, per-object PnP-RANSAC.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every `d_*` / `const float* x` marked
+ *     [device] is a DEVICE pointer (HBM), everything else is host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     device entry points only enqueue work on it and never synchronise, so
+ *     they can be captured into a hipGraph;
+ *   - return value: 0 = OK, < 0 = error (EPOS_E_*); -1000 - hipError_t for HIP
+ *     runtime failures. epos_last_error() gives a message for the last failure
+ *     on the calling thread;
+ *   - activations are NHWC fp32 (the reference's layout and dtype,
+ *     SURVEY.md section 8); `ld*` are row strides in ELEMENTS so that a kernel
+ *     can read or write a channel slice of a wider (concat) buffer.
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef EPOS_HIP_H_
+#define EPOS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPOS_OK 0
+#define EPOS_E_INVALID (-1)   /* bad argument (NULL, non-multiple-of-4 channels, ...) */
+#define EPOS_E_CAPACITY (-2)  /* caller-provided output capacity too small */
+#define EPOS_E_NODEVICE (-3)  /* no HIP device available */
+#define EPOS_E_HIP_BASE (-1000)
+
+#define EPOS_ABI_VERSION 1
+
+int epos_abi_version(void);
+const char* epos_last_error(void);
+/* Number of visible HIP devices (>= 0) or a negative error. */
+int epos_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * Network layers (replace the TF1.12 ops that model.py / net_xception.py lower
+ * to; call sites: SURVEY.md section 2.2).
+ * ------------------------------------------------------------------------- */
+
+/* Packs a 1x1-conv weight matrix W[K][N] (TF HWIO with H=W=1, i.e. [Cin][Cout])
+ * into the tile order the MFMA kernel streams: [ceil(K/32)*8][Npad][4] floats,
+ * Npad = round_up(N, 128), zero padded. Host-side helper (host pointers).
+ * Returns the number of floats written (or required, if dst == NULL). */
+int64_t epos_pack_pointwise_weights(const float* w_kn, int K, int N, float* dst);
+
+/* out[m, n] = act( sum_k A[row(m), k] * W[k, n] + bias[n] (+ R[m, n]) )
+ * = slim.conv2d(kernel 1x1, stride `sub`) + folded BatchNorm (+ residual add)
+ * (+ ReLU): net_xception.py:167-182 (pointwise half of separable_conv2d_same),
+ * :296-302 (shortcut), model.py:223-224,237,257-258,349-352 (ASPP/decoder 1x1),
+ * model.py:449-456 (logits, bias, no BN).
+ * A [device]: rows of `lda` floats; with sub > 1 the row of output pixel
+ * (b, y, x) is input pixel (b, y*sub, x*sub) of a [B, Hi, Wi] map (TF 'SAME'
+ * 1x1 stride-2 conv samples even indices); M = B*Ho*Wo output pixels.
+ * Wp [device]: packed by epos_pack_pointwise_weights; bias [device]: Npad floats
+ * (or NULL); R [device]: optional residual rows of ldr floats; C [device]: output
+ * rows of ldc floats. K % 4 == 0, lda % 4 == 0 required. */
+typedef struct EposPointwiseArgs {
+  const float* A; int64_t lda;
+  const float* Wp; const float* bias;
+  const float* R; int64_t ldr;
+  float* C; int64_t ldc;
+  int32_t M, N, K;
+  int32_t relu;       /* apply ReLU last */
+  int32_t relu_in;    /* apply ReLU to A on load (pre-activation) */
+  int32_t sub;        /* spatial subsampling of A rows (1 or 2) */
+  int32_t Ho, Wo, Hi, Wi;   /* only read when sub > 1 */
+} EposPointwiseArgs;
+int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
+
+/* Depthwise 3x3 conv + folded BatchNorm (+ optional ReLU before and after):
+ * the depthwise half of net_xception.py:167-182 / model.py:80-88. stride 1 ->
+ * TF 'SAME' (zero pad `rate`); stride 2 -> fixed_padding (net_xception.py:74-93)
+ * + VALID, i.e. zero pad 1 before / 1 after with rate 1. w9c [device]: [9][C]
+ * tap-major, BN scale folded in; bias [device]: [C]. C % 4 == 0. */
+typedef struct EposDepthwiseArgs {
+  const float* X; int64_t ldx;     /* [B, Hi, Wi] pixels, rows of ldx floats */
+  const float* w9c; const float* bias;
+  float* Y; int64_t ldy;           /* [B, Ho, Wo] pixels */
+  int32_t B, Hi, Wi, Ho, Wo, C;
+  int32_t stride, rate;
+  int32_t relu_in, relu_out;
+} EposDepthwiseArgs;
+int epos_depthwise3x3_f32(const EposDepthwiseArgs* args, void* stream);
+
+/* im2col for a dense 3x3 conv (slim resnet_utils.conv2d_same,
+ * external/slim/nets/resnet_utils.py:77-122, used at net_xception.py:460-463):
+ * col[m, (ky*3+kx)*C + c] = X[b, y*stride - pad + ky*rate, x*stride - pad + kx*rate, c]
+ * (zero outside), columns zero-padded to ldcol. With preprocess != 0 the input
+ * is first mapped x -> x*(2/255) - 1 (feature.py:171-174) for in-bounds taps. */
+typedef struct EposIm2colArgs {
+  const float* X; int64_t ldx;
+  float* col; int64_t ldcol;
+  int32_t B, Hi, Wi, Ho, Wo, C;
+  int32_t stride, rate, pad;
+  int32_t preprocess;
+} EposIm2colArgs;
+int epos_im2col3x3_f32(const EposIm2colArgs* args, void* stream);
+
+/* Global mean over H*W (model.py:220): X [B, HW, C] (ldx) -> Y [B, C]. */
+int epos_global_avg_pool_f32(const float* X, int64_t ldx, float* Y, int B,
+                             int HW, int C, void* stream);
+
+/* Bilinear resize, align_corners=True (misc.py:94-107 -> tf.image.resize_bilinear):
+ * X [B, Hi, Wi, C] (ldx) -> Y [B, Ho, Wo, C] (ldy). Hi = Wi = 1 broadcasts
+ * (image-pooling branch, model.py:225-226). C % 4 == 0. */
+int epos_resize_bilinear_f32(const float* X, int64_t ldx, float* Y, int64_t ldy,
+                             int B, int Hi, int Wi, int Ho, int Wo, int C,
+                             void* stream);
+
+/* In-place softmax over groups of `G` consecutive floats (model.py:677-678):
+ * X holds n_groups * G floats, group g at X + g*G (G <= 64). */
+int epos_softmax_groups_f32(float* X, int64_t n_groups, int G, void* stream);
+
+/* Per-pixel argmax over C channels -> int64 label (model.py:683); first maximum
+ * wins (tf.argmax / np.argmax tie rule). */
+int epos_argmax_i64(const float* X, int64_t ldx, int64_t* labels, int64_t P,
+                    int C, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Correspondence extraction (replaces epos_lib/corresp.py:9-101,
+ * establish_many_to_many, and misc.py:14-26).
+ * One "slot" = one (image, object) pair to extract.
+ * ------------------------------------------------------------------------- */
+typedef struct EposCorrSlot {
+  int32_t image;     /* image index in the batch */
+  int32_t obj_id;    /* 1-based object id: channel obj_id of obj_confs,
+                        channel obj_id-1 of the fragment heads (corresp.py:46,60) */
+} EposCorrSlot;
+
+/* Pass 1+2: per slot, count masked pixels and correspondences and compute the
+ * raster-order exclusive offsets. All buffers [device].
+ *   obj_confs  f32 [B, P, O+1]      (P = h*w pixels of the head map)
+ *   frag_confs f32 [B, P, O, F]     (F == 64)
+ *   px_off, corr_off  i32 [S, P]    scratch/outputs (exclusive scans)
+ *   frag_mask  u64 [S, P]           kept-fragment bitmask per pixel (0 = not masked)
+ *   totals     i32 [S, 2]           {masked pixels, correspondences} per slot
+ */
+int epos_corr_count(const float* obj_confs, const float* frag_confs,
+                    const EposCorrSlot* slots /*[device]*/, int S, int B, int P,
+                    int O, int F, float min_obj_conf, float min_frag_rel_conf,
+                    int32_t* px_off, int32_t* corr_off, uint64_t* frag_mask,
+                    int32_t* totals, void* stream);
+
+/* Pass 3: fills the correspondence arrays. slot_base i64[S] [device] gives each
+ * slot's first row in the pooled output arrays (exclusive scan of totals[:,1],
+ * computed by epos_corr_slot_bases or by the host); `capacity` rows are
+ * available; rows beyond it are not written and *overflow is set to 1.
+ *   frag_coords f32 [B, P, O, F, 3]
+ *   frag_centers f64 [O, F, 3], frag_sizes f64 [O, F]  (model store, obj_id-1 major)
+ * Outputs [device]: px_id i64[N], frag_id i64[N], coord_2d f64[N,2],
+ * coord_3d f64[N,3], conf/conf_obj/conf_frag f32[N] with the exact arithmetic of
+ * corresp.py:55-57,71-78,82-84 (see oracle/corresp_ref.py). W = head map width,
+ * inv_scale = 1 / output_scale. */
+typedef struct EposCorrOut {
+  int64_t* px_id; int64_t* frag_id;
+  double* coord_2d; double* coord_3d;
+  float* conf; float* conf_obj; float* conf_frag;
+} EposCorrOut;
+int epos_corr_fill(const float* obj_confs, const float* frag_confs,
+                   const float* frag_coords, const double* frag_centers,
+                   const double* frag_sizes, const EposCorrSlot* slots, int S,
+                   int B, int P, int W, int O, int F, double inv_scale,
+                   const int32_t* px_off, const int32_t* corr_off,
+                   const uint64_t* frag_mask, const int64_t* slot_base,
+                   int64_t capacity, const EposCorrOut* out, int32_t* overflow,
+                   void* stream);
+
+/* slot_base[s] = sum_{t<s} totals[t][1]; slot_base[S] = grand total. [device] */
+int epos_corr_slot_bases(const int32_t* totals, int S, int64_t* slot_base,
+                         void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Pose fitting (replaces pyprogressivex.find6DPoses, scripts/infer.py:470-488;
+ * the un-vendored danini/progressive-x pybind11 module).
+ * ------------------------------------------------------------------------- */
+typedef struct EposFitParams {
+  double threshold;                 /* inlier_thresh, tau_r [px]   (infer.py:76-79)  */
+  double neighborhood_ball_radius;  /* tau_d (accepted, unused in round 1)           */
+  double spatial_coherence_weight;  /* (accepted, unused in round 1)                 */
+  double scaling_from_millimeters;  /* (accepted, unused in round 1)                 */
+  double max_tanimoto_similarity;   /* infer.py:112-114                              */
+  double conf;                      /* required_progx_confidence (unused: the        */
+  double proposal_engine_conf;      /*  defaults 0.5 / 1.0 always run max_iters)     */
+  double min_coverage;              /* min_hypothesis_quality, tau_q                 */
+  double min_triangle_area;         /* tau_t                                         */
+  int32_t max_iters;                /* max_fitting_iterations (400)                  */
+  int32_t min_point_number;         /* 6 (infer.py:483)                              */
+  int32_t max_model_number;         /* num_instances; -1 = as many as found          */
+  int32_t max_model_number_for_optimization;  /* accepted, unused in round 1         */
+  int32_t use_prosac;               /* sample from a growing confidence-sorted prefix */
+  int32_t lo_iters;                 /* Gauss-Newton refits of the best model (def 8) */
+} EposFitParams;
+void epos_fit_params_default(EposFitParams* p);
+
+/* Host-pointer drop-in for pyprogressivex.find6DPoses: xy f64[n,2] (pixels),
+ * xyz f64[n,3] (mm), K f64[9] row-major. Outputs (caller-owned): poses
+ * f64[max_k*12] = k blocks of row-major [R|t] 3x4 (the reference stacks them as
+ * [3k,4], infer.py:490-495), labels i32[n] (instance index or -1), scores
+ * f64[max_k]. Returns k >= 0 (0 <=> the reference's `pose_ests is None`) or < 0. */
+int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
+                      const double* K, const EposFitParams* p, uint64_t seed,
+                      double* poses_out, int32_t* labels_out, double* scores_out,
+                      int32_t max_k);
+
+/* Batched device entry: S independent fitting problems (slots) in one call, all
+ * buffers [device], nothing synchronises.
+ *   xy f64[N,2], xyz f64[N,3] pooled; slot s owns rows [slot_base[s], slot_base[s+1])
+ *   Ks f64[S,9]; max_models i32[S] (per-slot num_instances, <= max_k)
+ *   seeds u64[S]
+ *   work: scratch of epos_fit_workspace_bytes(S, N_capacity, p) bytes
+ * Outputs: poses f64[S,max_k,12], scores f64[S,max_k], num_models i32[S],
+ *          labels i32[N] (instance index within the slot or -1). */
+int64_t epos_fit_workspace_bytes(int S, int64_t n_capacity, const EposFitParams* p,
+                                 int32_t max_k);
+int epos_find6d_poses_device(const double* xy, const double* xyz,
+                             const int64_t* slot_base, int S, int64_t n_capacity,
+                             const double* Ks, const int32_t* max_models,
+                             const uint64_t* seeds, const EposFitParams* p,
+                             int32_t max_k, void* work, double* poses,
+                             double* scores, int32_t* num_models, int32_t* labels,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* EPOS_HIP_H_ */

@@ -1,0 +1,594 @@
+/*
+ * ORACLE (test infrastructure, not product): plain-C, single-thread restatement of
+ * the EPOS pose-fitting stage, i.e. of the call
+ *     pyprogressivex.find6DPoses(...)                 scripts/infer.py:470-488
+ * and of how its result is unpacked (infer.py:490-503).
+ *
+ * PARITY UNPINNED. The arithmetic lives in the un-vendored submodule
+ * danini/progressive-x (branch version-epos, .gitmodules:7-10; the commit is not
+ * recorded in the tree, the directory is empty) and the reference holds no test
+ * or golden pose for it. What is fixed by the reference is the call contract
+ * only: f64 2D/3D correspondences, K, the parameter set, ">= 6 correspondences",
+ * "up to num_instances poses, each [R|t] + a quality, or None". This file
+ * restates the PUBLISHED algorithm family (Barath & Matas, GC-RANSAC CVPR'18 /
+ * Progressive-X ICCV'19; EPOS CVPR'20 sec. 3.4) in the form the build defines
+ * (DESIGN.md "Pose fitting"):
+ *
+ *   per instance round:
+ *     for it in [0, max_iters):                       (proposal_engine_conf = 1.0
+ *        draw 3 distinct active correspondences         => the cap always runs)
+ *        P3P minimal solver -> <= 4 poses
+ *        MSAC quality  q = sum_inliers (1 - e^2 / tau_r^2),  e = reprojection error
+ *     best hypothesis (max q, ties -> lowest index) -> local optimisation:
+ *        Gauss-Newton refits of the 6-dof pose on its inliers, kept while q grows
+ *     accept iff  #inliers >= min_point_number,
+ *                 Tanimoto(inliers, inliers of each accepted instance) < max_tanimoto,
+ *                 coverage = |inliers not yet explained| / |inliers| >= min_coverage
+ *     label + remove its inliers; stop at max_model_number instances.
+ *
+ * The graph-cut spatial-coherence labelling of GC-RANSAC and PEARL's joint
+ * relabelling are NOT restated (their parameters are accepted and ignored).
+ *
+ * All sums over correspondences use one canonical order so that the wavefront-
+ * parallel HIP kernel can reproduce them bit for bit: 64 strided partial sums
+ * (partial l takes items l, l+64, ...) combined by a 6-level xor butterfly.
+ * Only + - * / sqrt are used (correctly rounded on both sides); build with
+ * -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct PnpRefParams {
+  double threshold;
+  double neighborhood_ball_radius;
+  double spatial_coherence_weight;
+  double scaling_from_millimeters;
+  double max_tanimoto_similarity;
+  double conf;
+  double proposal_engine_conf;
+  double min_coverage;
+  double min_triangle_area;
+  int32_t max_iters;
+  int32_t min_point_number;
+  int32_t max_model_number;
+  int32_t max_model_number_for_optimization;
+  int32_t use_prosac;
+  int32_t lo_iters;
+} PnpRefParams;
+
+/* ------------------------------------------------------------------ RNG -- */
+static uint64_t mix64(uint64_t z) {          /* splitmix64 finaliser */
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static uint64_t draw(uint64_t seed, uint32_t round, uint32_t it, uint32_t k,
+                     uint64_t n) {           /* uniform in [0, n) */
+  uint64_t u = mix64(mix64(seed ^ mix64(((uint64_t)round << 32) | it)) + k);
+  return (uint64_t)(((unsigned __int128)u * n) >> 64);
+}
+/* three distinct indices in [0, m) */
+static void sample3(uint64_t seed, uint32_t round, uint32_t it, int64_t m,
+                    int64_t s[3]) {
+  int64_t a = (int64_t)draw(seed, round, it, 0, (uint64_t)m);
+  int64_t b = (int64_t)draw(seed, round, it, 1, (uint64_t)(m - 1));
+  int64_t c = (int64_t)draw(seed, round, it, 2, (uint64_t)(m - 2));
+  if (b >= a) b += 1;
+  int64_t lo = a < b ? a : b, hi = a < b ? b : a;
+  if (c >= lo) c += 1;
+  if (c >= hi) c += 1;
+  s[0] = a; s[1] = b; s[2] = c;
+}
+
+/* ------------------------------------------------------- small algebra -- */
+static double dot3(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+static void cross3(const double* a, const double* b, double* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* symmetric 3x3 stored as s[6] = {00, 01, 02, 11, 12, 22} */
+static void sym_adj(const double* s, double* b) {
+  b[0] = s[3] * s[5] - s[4] * s[4];
+  b[1] = s[2] * s[4] - s[1] * s[5];
+  b[2] = s[1] * s[4] - s[2] * s[3];
+  b[3] = s[0] * s[5] - s[2] * s[2];
+  b[4] = s[1] * s[2] - s[0] * s[4];
+  b[5] = s[0] * s[3] - s[1] * s[1];
+}
+static double sym_det(const double* s, const double* adj) {
+  return s[0] * adj[0] + s[1] * adj[1] + s[2] * adj[2];
+}
+static double sym_inner(const double* a, const double* b) { /* sum_ij a_ij b_ij */
+  return a[0] * b[0] + a[3] * b[3] + a[5] * b[5] +
+         2.0 * (a[1] * b[1] + a[2] * b[2] + a[4] * b[4]);
+}
+static double sym_quad(const double* s, const double* v) { /* v^T S v */
+  return s[0] * v[0] * v[0] + s[3] * v[1] * v[1] + s[5] * v[2] * v[2] +
+         2.0 * (s[1] * v[0] * v[1] + s[2] * v[0] * v[2] + s[4] * v[1] * v[2]);
+}
+static double sym_at(const double* s, int i, int j) {
+  static const int idx[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  return s[idx[i][j]];
+}
+
+/* One real root of x^3 + b x^2 + c x + d (Newton from a start beyond the outer
+ * turning point, so the iteration is monotone). */
+static double cubic_root(double b, double c, double d) {
+  double x;
+  const double disc = b * b - 3.0 * c;
+  if (disc > 0.0) {
+    const double v = sqrt(disc);
+    const double t1 = (-b - v) / 3.0;            /* local maximum */
+    const double f1 = ((t1 + b) * t1 + c) * t1 + d;
+    if (f1 > 0.0) {                              /* root left of the maximum */
+      double step = v / 3.0 + 1e-3;
+      x = t1 - step;
+      for (int i = 0; i < 200 && (((x + b) * x + c) * x + d) > 0.0; ++i) { step *= 2.0; x = t1 - step; }
+    } else {
+      const double t2 = (-b + v) / 3.0;          /* local minimum */
+      double step = v / 3.0 + 1e-3;
+      x = t2 + step;
+      for (int i = 0; i < 200 && (((x + b) * x + c) * x + d) < 0.0; ++i) { step *= 2.0; x = t2 + step; }
+    }
+  } else {
+    /* monotone cubic: bracket from the inflection point outward */
+    const double t0 = -b / 3.0;
+    const double f0 = ((t0 + b) * t0 + c) * t0 + d;
+    double step = 1.0 + fabs(t0);
+    x = t0;
+    if (f0 > 0.0) {
+      x = t0 - step;
+      for (int i = 0; i < 200 && (((x + b) * x + c) * x + d) > 0.0; ++i) { step *= 2.0; x = t0 - step; }
+    } else if (f0 < 0.0) {
+      x = t0 + step;
+      for (int i = 0; i < 200 && (((x + b) * x + c) * x + d) < 0.0; ++i) { step *= 2.0; x = t0 + step; }
+    }
+  }
+  for (int i = 0; i < 60; ++i) {
+    const double f = ((x + b) * x + c) * x + d;
+    const double fp = (3.0 * x + 2.0 * b) * x + c;
+    if (fp == 0.0) break;
+    const double dx = f / fp;
+    x -= dx;
+    if (fabs(dx) <= 1e-15 * fabs(x)) break;
+  }
+  return x;
+}
+
+/* ------------------------------------------------------------------ P3P -- */
+/* f[3][3]: unit bearings, X[3][3]: world points. Out: up to 4 poses as R (row
+ * major 9) + t (3) in pose[k*12..]. Returns the number of poses. */
+static int p3p(const double f[3][3], const double X[3][3], double* pose) {
+  const double c12 = dot3(f[0], f[1]), c13 = dot3(f[0], f[2]),
+               c23 = dot3(f[1], f[2]);
+  double d12[3], d13[3], d23[3];
+  for (int i = 0; i < 3; ++i) {
+    d12[i] = X[0][i] - X[1][i];
+    d13[i] = X[0][i] - X[2][i];
+    d23[i] = X[1][i] - X[2][i];
+  }
+  const double a12 = dot3(d12, d12), a13 = dot3(d13, d13), a23 = dot3(d23, d23);
+  /* world-triangle frame and its inverse */
+  double nx[3];
+  cross3(d12, d13, nx);
+  const double detx = dot3(nx, nx);
+  if (!(detx > 1e-18 * (a12 * a13 + 1e-300))) return 0;   /* collinear sample */
+  /* Xm = [d12 d13 nx] (columns); inverse rows: (d13 x nx, nx x d12, nx) / detx */
+  double r0[3], r1[3];
+  cross3(d13, nx, r0);
+  cross3(nx, d12, r1);
+  double Xinv[3][3];
+  for (int i = 0; i < 3; ++i) {
+    Xinv[0][i] = r0[i] / detx;
+    Xinv[1][i] = r1[i] / detx;
+    Xinv[2][i] = nx[i] / detx;
+  }
+  /* quadrics: M12, M13, M23 in packed symmetric form */
+  const double M12[6] = {1, -c12, 0, 1, 0, 0};
+  const double M13[6] = {1, 0, -c13, 0, 0, 1};
+  const double M23[6] = {0, 0, 0, 1, -c23, 1};
+  double D1[6], D2[6];
+  for (int i = 0; i < 6; ++i) {
+    D1[i] = a23 * M12[i] - a12 * M23[i];
+    D2[i] = a23 * M13[i] - a13 * M23[i];
+  }
+  double A1[6], A2[6];
+  sym_adj(D1, A1);
+  sym_adj(D2, A2);
+  const double k0 = sym_det(D1, A1), k3 = sym_det(D2, A2);
+  const double k1 = sym_inner(A1, D2), k2 = sym_inner(A2, D1);
+  /* det(D1 + g D2) = k0 + k1 g + k2 g^2 + k3 g^3 */
+  double D0[6];
+  const double* E;                 /* the conic the line pair is intersected with */
+  if (fabs(k3) >= fabs(k0)) {
+    if (k3 == 0.0) return 0;
+    const double g = cubic_root(k2 / k3, k1 / k3, k0 / k3);
+    for (int i = 0; i < 6; ++i) D0[i] = D1[i] + g * D2[i];
+    E = fabs(g) <= 1.0 ? D2 : D1;
+  } else {
+    const double g = cubic_root(k1 / k0, k2 / k0, k3 / k0);   /* D0 = g D1 + D2 */
+    for (int i = 0; i < 6; ++i) D0[i] = g * D1[i] + D2[i];
+    E = fabs(g) <= 1.0 ? D1 : D2;
+  }
+  /* split the degenerate conic D0 into two planes l, m */
+  double B[6];
+  sym_adj(D0, B);
+  int bi = 0;
+  double bmax = -B[0];
+  if (-B[3] > bmax) { bmax = -B[3]; bi = 1; }
+  if (-B[5] > bmax) { bmax = -B[5]; bi = 2; }
+  if (!(bmax > 0.0)) return 0;                   /* complex line pair */
+  const double sq = sqrt(bmax);
+  double pt[3];
+  for (int i = 0; i < 3; ++i) pt[i] = -sym_at(B, i, bi) / sq;
+  double N[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) N[i][j] = sym_at(D0, i, j);
+  N[0][1] -= pt[2]; N[0][2] += pt[1];
+  N[1][0] += pt[2]; N[1][2] -= pt[0];
+  N[2][0] -= pt[1]; N[2][1] += pt[0];
+  /* rank one: N = 2 m l^T; strongest row ~ l, strongest column ~ m */
+  int ri = 0, ci = 0;
+  double rbest = -1.0, cbest = -1.0;
+  for (int i = 0; i < 3; ++i) {
+    const double rn = N[i][0] * N[i][0] + N[i][1] * N[i][1] + N[i][2] * N[i][2];
+    const double cn = N[0][i] * N[0][i] + N[1][i] * N[1][i] + N[2][i] * N[2][i];
+    if (rn > rbest) { rbest = rn; ri = i; }
+    if (cn > cbest) { cbest = cn; ci = i; }
+  }
+  double planes[2][3];
+  for (int j = 0; j < 3; ++j) { planes[0][j] = N[ri][j]; planes[1][j] = N[j][ci]; }
+
+  int nsol = 0;
+  for (int pl = 0; pl < 2; ++pl) {
+    const double* n = planes[pl];
+    int k = 0;
+    if (fabs(n[1]) > fabs(n[k])) k = 1;
+    if (fabs(n[2]) > fabs(n[k])) k = 2;
+    if (n[k] == 0.0) continue;
+    const int a = (k + 1) % 3, b = (k + 2) % 3;
+    const double ua = -n[a] / n[k], ub = -n[b] / n[k];   /* lam_k = ua la + ub lb */
+    /* q = P^T E P with P columns e_a + ua e_k, e_b + ub e_k */
+    const double Eaa = sym_at(E, a, a), Ebb = sym_at(E, b, b), Ekk = sym_at(E, k, k);
+    const double Eab = sym_at(E, a, b), Eak = sym_at(E, a, k), Ebk = sym_at(E, b, k);
+    const double q00 = Eaa + 2.0 * ua * Eak + ua * ua * Ekk;
+    const double q11 = Ebb + 2.0 * ub * Ebk + ub * ub * Ekk;
+    const double q01 = Eab + ub * Eak + ua * Ebk + ua * ub * Ekk;
+    const double disc = q01 * q01 - q00 * q11;
+    if (!(disc >= 0.0)) continue;
+    const double sd = sqrt(disc);
+    for (int sg = 0; sg < 2; ++sg) {
+      double la, lb;
+      const double num = sg == 0 ? (-q01 + sd) : (-q01 - sd);
+      if (fabs(q00) >= fabs(q11)) {
+        if (q00 == 0.0) continue;
+        la = num / q00; lb = 1.0;
+      } else {
+        la = 1.0; lb = num / q11;
+      }
+      double lam[3];
+      lam[a] = la; lam[b] = lb; lam[k] = ua * la + ub * lb;
+      const double qs = sym_quad(M12, lam) + sym_quad(M13, lam) + sym_quad(M23, lam);
+      if (!(qs > 0.0)) continue;
+      double sc = sqrt((a12 + a13 + a23) / qs);
+      if (lam[0] < 0.0) sc = -sc;
+      lam[0] *= sc; lam[1] *= sc; lam[2] *= sc;
+      if (!(lam[0] > 0.0 && lam[1] > 0.0 && lam[2] > 0.0)) continue;
+      /* camera-frame triangle */
+      double Y[3][3];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Y[i][j] = lam[i] * f[i][j];
+      double e12[3], e13[3], ny[3];
+      for (int j = 0; j < 3; ++j) { e12[j] = Y[0][j] - Y[1][j]; e13[j] = Y[0][j] - Y[2][j]; }
+      cross3(e12, e13, ny);
+      double* R = pose + nsol * 12;
+      double* t = R + 9;
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+          R[i * 3 + j] = e12[i] * Xinv[0][j] + e13[i] * Xinv[1][j] + ny[i] * Xinv[2][j];
+      for (int i = 0; i < 3; ++i)
+        t[i] = Y[0][i] - (R[i * 3] * X[0][0] + R[i * 3 + 1] * X[0][1] + R[i * 3 + 2] * X[0][2]);
+      ++nsol;
+    }
+  }
+  return nsol;
+}
+
+/* ------------------------------------------------------------- scoring -- */
+static void tree64(double* part, int stride, int nvals) {
+  /* xor butterfly over 64 partials, for nvals interleaved quantities */
+  double tmp[64];
+  for (int v = 0; v < nvals; ++v) {
+    for (int off = 32; off > 0; off >>= 1) {
+      for (int l = 0; l < 64; ++l) tmp[l] = part[l * stride + v] + part[(l ^ off) * stride + v];
+      for (int l = 0; l < 64; ++l) part[l * stride + v] = tmp[l];
+    }
+  }
+}
+
+/* squared reprojection error of point i under pose; returns 0 and sets *e2, or 1
+ * if the point is behind the camera */
+static int reproj(const double* pose, const double* K, const double* xy,
+                  const double* xyz, double* e2, double* Xc, double* r) {
+  const double* R = pose; const double* t = pose + 9;
+  Xc[0] = R[0] * xyz[0] + R[1] * xyz[1] + R[2] * xyz[2] + t[0];
+  Xc[1] = R[3] * xyz[0] + R[4] * xyz[1] + R[5] * xyz[2] + t[1];
+  Xc[2] = R[6] * xyz[0] + R[7] * xyz[1] + R[8] * xyz[2] + t[2];
+  if (!(Xc[2] > 0.0)) return 1;
+  const double px = (K[0] * Xc[0] + K[1] * Xc[1]) / Xc[2] + K[2];
+  const double py = (K[4] * Xc[1]) / Xc[2] + K[5];
+  r[0] = px - xy[0];
+  r[1] = py - xy[1];
+  *e2 = r[0] * r[0] + r[1] * r[1];
+  return 0;
+}
+
+/* MSAC score and inlier count of a pose over the index list idx[0..m) */
+static double score_pose(const double* pose, const double* K, const double* xy,
+                         const double* xyz, const int32_t* idx, int64_t m,
+                         double thr2, int32_t* count) {
+  double part[64];
+  int32_t cnt = 0;
+  for (int l = 0; l < 64; ++l) {
+    double acc = 0.0;
+    for (int64_t i = l; i < m; i += 64) {
+      const int32_t p = idx[i];
+      double e2, Xc[3], r[2];
+      if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
+      if (e2 < thr2) { acc += 1.0 - e2 / thr2; ++cnt; }
+    }
+    part[l] = acc;
+  }
+  tree64(part, 1, 1);
+  *count = cnt;
+  return part[0];
+}
+
+/* ------------------------------------------------- local optimisation -- */
+static void orthonormalize(double* R) {   /* Gram-Schmidt on rows, row2 = r0 x r1 */
+  double n0 = sqrt(dot3(R, R));
+  for (int j = 0; j < 3; ++j) R[j] /= n0;
+  const double d = dot3(R, R + 3);
+  for (int j = 0; j < 3; ++j) R[3 + j] -= d * R[j];
+  const double n1 = sqrt(dot3(R + 3, R + 3));
+  for (int j = 0; j < 3; ++j) R[3 + j] /= n1;
+  cross3(R, R + 3, R + 6);
+}
+
+/* solve H x = -g for symmetric positive (semi)definite 6x6 by Gaussian
+ * elimination with partial pivoting; returns 0 on success */
+static int solve6(double H[6][6], const double* g, double* x) {
+  double A[6][7];
+  for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) A[i][j] = H[i][j]; A[i][6] = -g[i]; }
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+    if (!(fabs(A[piv][c]) > 1e-300)) return 1;
+    if (piv != c) for (int j = 0; j < 7; ++j) { double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
+    for (int r = c + 1; r < 6; ++r) {
+      const double fct = A[r][c] / A[c][c];
+      for (int j = c; j < 7; ++j) A[r][j] -= fct * A[c][j];
+    }
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = A[i][6];
+    for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
+    x[i] = s / A[i][i];
+  }
+  return 0;
+}
+
+/* one Gauss-Newton step on the inliers (at thr2) of `pose`; writes `next` */
+static int gn_step(const double* pose, const double* K, const double* xy,
+                   const double* xyz, const int32_t* idx, int64_t m, double thr2,
+                   double* next) {
+  /* 27 accumulated quantities: 21 upper-triangular H entries + 6 of g */
+  static double part[64 * 27];
+  for (int l = 0; l < 64; ++l) {
+    double acc[27];
+    for (int v = 0; v < 27; ++v) acc[v] = 0.0;
+    for (int64_t i = l; i < m; i += 64) {
+      const int32_t p = idx[i];
+      double e2, Xc[3], r[2];
+      if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
+      if (!(e2 < thr2)) continue;
+      const double iz = 1.0 / Xc[2];
+      /* d(px,py)/dXc */
+      const double a0 = K[0] * iz, a1 = K[1] * iz,
+                   a2 = -(K[0] * Xc[0] + K[1] * Xc[1]) * iz * iz;
+      const double b1 = K[4] * iz, b2 = -(K[4] * Xc[1]) * iz * iz;
+      /* dXc/dw = -[Xc]x ; J = Jpi * [-[Xc]x | I] */
+      double J0[6], J1[6];
+      J0[0] = a1 * Xc[2] - a2 * Xc[1];     /* row0 . (-[Xc]x) col 0 */
+      J0[1] = -a0 * Xc[2] + a2 * Xc[0];
+      J0[2] = a0 * Xc[1] - a1 * Xc[0];
+      J0[3] = a0; J0[4] = a1; J0[5] = a2;
+      J1[0] = b1 * Xc[2] - b2 * Xc[1];
+      J1[1] = b2 * Xc[0];
+      J1[2] = -b1 * Xc[0];
+      J1[3] = 0.0; J1[4] = b1; J1[5] = b2;
+      int v = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) acc[v++] += J0[a] * J0[b] + J1[a] * J1[b];
+      for (int a = 0; a < 6; ++a) acc[v++] += J0[a] * r[0] + J1[a] * r[1];
+    }
+    for (int v = 0; v < 27; ++v) part[l * 27 + v] = acc[v];
+  }
+  tree64(part, 27, 27);
+  double H[6][6], g[6], x[6];
+  int v = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) { H[a][b] = part[v]; H[b][a] = part[v]; ++v; }
+  for (int a = 0; a < 6; ++a) g[a] = part[v++];
+  if (solve6(H, g, x)) return 1;
+  /* dR from the unit quaternion (1, w/2) / |.| */
+  double qw = 1.0, qx = 0.5 * x[0], qy = 0.5 * x[1], qz = 0.5 * x[2];
+  const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+  qw /= qn; qx /= qn; qy /= qn; qz /= qn;
+  double dR[9];
+  dR[0] = 1.0 - 2.0 * (qy * qy + qz * qz); dR[1] = 2.0 * (qx * qy - qz * qw); dR[2] = 2.0 * (qx * qz + qy * qw);
+  dR[3] = 2.0 * (qx * qy + qz * qw); dR[4] = 1.0 - 2.0 * (qx * qx + qz * qz); dR[5] = 2.0 * (qy * qz - qx * qw);
+  dR[6] = 2.0 * (qx * qz - qy * qw); dR[7] = 2.0 * (qy * qz + qx * qw); dR[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
+  const double* R = pose; const double* t = pose + 9;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      next[i * 3 + j] = dR[i * 3] * R[j] + dR[i * 3 + 1] * R[3 + j] + dR[i * 3 + 2] * R[6 + j];
+    next[9 + i] = dR[i * 3] * t[0] + dR[i * 3 + 1] * t[1] + dR[i * 3 + 2] * t[2] + x[3 + i];
+  }
+  for (int i = 0; i < 12; ++i) if (!(next[i] == next[i])) return 1;   /* NaN */
+  return 0;
+}
+
+/* ----------------------------------------------------------- main entry -- */
+static void bearing(const double* K, const double* xy, double* f) {
+  /* K^-1 [x y 1] for upper-triangular K, normalised */
+  const double y = (xy[1] - K[5]) / K[4];
+  const double x = (xy[0] - K[2] - K[1] * y) / K[0];
+  const double n = sqrt(x * x + y * y + 1.0);
+  f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
+}
+
+/* Returns the number of poses found (k), fills poses[k*12], labels[n], scores[k]. */
+int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
+                         const double* K, const PnpRefParams* prm, uint64_t seed,
+                         double* poses, int32_t* labels, double* scores,
+                         int32_t max_k) {
+  for (int64_t i = 0; i < n; ++i) labels[i] = -1;
+  if (n < prm->min_point_number || n < 3) return 0;      /* infer.py:420-422 */
+  int want = prm->max_model_number;
+  if (want < 0 || want > max_k) want = max_k;
+  const double thr2 = prm->threshold * prm->threshold;
+  const int64_t words = (n + 63) / 64;
+  int32_t* active = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  int32_t* all = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  uint64_t* inl = (uint64_t*)calloc((size_t)(words * (max_k + 1)), sizeof(uint64_t));
+  int64_t n_active = n;
+  for (int64_t i = 0; i < n; ++i) { active[i] = (int32_t)i; all[i] = (int32_t)i; }
+  int k = 0;
+  for (int round = 0; round < want; ++round) {
+    if (n_active < prm->min_point_number || n_active < 3) break;
+    double best_pose[12];
+    double best_score = -1.0;
+    int32_t best_count = 0;
+    for (int it = 0; it < prm->max_iters; ++it) {
+      int64_t m = n_active;
+      if (prm->use_prosac) {   /* growing prefix of the (confidence-sorted) list */
+        m = (n_active * (int64_t)(it + 1) + prm->max_iters - 1) / prm->max_iters;
+        if (m < prm->min_point_number) m = prm->min_point_number;
+        if (m < 3) m = 3;
+        if (m > n_active) m = n_active;
+      }
+      int64_t s[3];
+      sample3(seed, (uint32_t)round, (uint32_t)it, m, s);
+      double f[3][3], X[3][3], p2[3][2];
+      for (int j = 0; j < 3; ++j) {
+        const int32_t p = active[s[j]];
+        bearing(K, xy + 2 * p, f[j]);
+        for (int d = 0; d < 3; ++d) X[j][d] = xyz[3 * p + d];
+        p2[j][0] = xy[2 * p]; p2[j][1] = xy[2 * p + 1];
+      }
+      const double area = 0.5 * fabs((p2[1][0] - p2[0][0]) * (p2[2][1] - p2[0][1]) -
+                                     (p2[1][1] - p2[0][1]) * (p2[2][0] - p2[0][0]));
+      if (area < prm->min_triangle_area) continue;
+      double sols[48];
+      const int ns = p3p(f, X, sols);
+      for (int q = 0; q < ns; ++q) {
+        int32_t cnt;
+        const double sc = score_pose(sols + 12 * q, K, xy, xyz, active, n_active, thr2, &cnt);
+        if (sc > best_score) {
+          best_score = sc; best_count = cnt;
+          memcpy(best_pose, sols + 12 * q, sizeof(best_pose));
+        }
+      }
+    }
+    if (!(best_score > 0.0) || best_count < 3) break;
+    /* local optimisation */
+    orthonormalize(best_pose);
+    {
+      int32_t cnt;
+      best_score = score_pose(best_pose, K, xy, xyz, active, n_active, thr2, &cnt);
+      best_count = cnt;
+    }
+    for (int li = 0; li < prm->lo_iters; ++li) {
+      double cand[12];
+      if (gn_step(best_pose, K, xy, xyz, active, n_active, thr2, cand)) break;
+      int32_t cnt;
+      const double sc = score_pose(cand, K, xy, xyz, active, n_active, thr2, &cnt);
+      if (!(sc > best_score)) break;
+      best_score = sc; best_count = cnt;
+      memcpy(best_pose, cand, sizeof(cand));
+    }
+    if (best_count < prm->min_point_number) break;
+    /* inliers over ALL correspondences, Tanimoto / coverage tests */
+    uint64_t* cur = inl + (size_t)k * words;
+    memset(cur, 0, sizeof(uint64_t) * (size_t)words);
+    int64_t n_inl = 0, n_new = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      double e2, Xc[3], r[2];
+      if (reproj(best_pose, K, xy + 2 * i, xyz + 3 * i, &e2, Xc, r)) continue;
+      if (e2 < thr2) {
+        cur[i >> 6] |= 1ULL << (i & 63);
+        ++n_inl;
+        if (labels[i] < 0) ++n_new;
+      }
+    }
+    int ok = n_inl > 0;
+    for (int j = 0; j < k && ok; ++j) {
+      const uint64_t* pj = inl + (size_t)j * words;
+      int64_t inter = 0, uni = 0;
+      for (int64_t w = 0; w < words; ++w) {
+        inter += __builtin_popcountll(cur[w] & pj[w]);
+        uni += __builtin_popcountll(cur[w] | pj[w]);
+      }
+      if ((double)inter >= prm->max_tanimoto_similarity * (double)uni) ok = 0;
+    }
+    if (ok && (double)n_new < prm->min_coverage * (double)n_inl) ok = 0;
+    if (!ok) break;
+    memcpy(poses + 12 * k, best_pose, sizeof(best_pose));
+    scores[k] = best_score;
+    /* label and remove the inliers that were still active (stable compaction) */
+    int64_t w = 0;
+    for (int64_t i = 0; i < n_active; ++i) {
+      const int32_t p = active[i];
+      if ((cur[p >> 6] >> (p & 63)) & 1ULL) labels[p] = k;
+      else active[w++] = p;
+    }
+    n_active = w;
+    ++k;
+  }
+  free(active); free(all); free(inl);
+  return k;
+}
+
+void pnp_ref_params_default(PnpRefParams* p) {   /* scripts/infer.py:76-120,470-488 */
+  p->threshold = 4.0;
+  p->neighborhood_ball_radius = 20.0;
+  p->spatial_coherence_weight = 0.1;
+  p->scaling_from_millimeters = 0.1;
+  p->max_tanimoto_similarity = 0.9;
+  p->conf = 0.5;
+  p->proposal_engine_conf = 1.0;
+  p->min_coverage = 0.5;
+  p->min_triangle_area = 0.0;
+  p->max_iters = 400;
+  p->min_point_number = 6;
+  p->max_model_number = 1;
+  p->max_model_number_for_optimization = 5;
+  p->use_prosac = 0;
+  p->lo_iters = 8;
+}
+
+/* exposed for unit tests */
+int pnp_ref_p3p(const double* f9, const double* X9, double* pose48) {
+  double f[3][3], X[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { f[i][j] = f9[i * 3 + j]; X[i][j] = X9[i * 3 + j]; }
+  return p3p(f, X, pose48);
+}
+double pnp_ref_cubic_root(double b, double c, double d) { return cubic_root(b, c, d); }

@@ -1,0 +1,174 @@
+"""GPU parity of the correspondence kernels (bit-exact against the golden vectors
+generated from the imported reference) and of the PnP-RANSAC kernels (bit-exact
+labels / near-exact poses against the C oracle with equal seeds; known-pose
+recovery on synthetic scenes)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+KEYS = ['px_id', 'frag_id', 'coord_2d', 'coord_3d', 'conf', 'conf_obj',
+        'conf_frag']
+CASES = sorted(glob.glob(os.path.join(GOLDEN, 'corresp_*.npz')))
+
+
+class Store(object):
+  def __init__(self, centers, sizes):
+    n = centers.shape[0]
+    self.dp_model = {'obj_ids': list(range(1, n + 1))}
+    self.frag_centers = {o + 1: centers[o] for o in range(n)}
+    self.frag_sizes = {o + 1: sizes[o] for o in range(n)}
+
+
+@pytest.mark.parametrize('path', CASES, ids=[os.path.basename(p) for p in CASES])
+def test_corresp_bit_exact_vs_reference_golden(path):
+  from epos_amd import corresp
+  z = np.load(path)
+  out = corresp.establish_many_to_many(
+      z['obj_confs'], z['frag_confs'], z['frag_coords'],
+      gt_obj_ids=list(z['gt_obj_ids']),
+      model_store=Store(z['frag_centers'], z['frag_sizes']),
+      output_scale=float(z['output_scale']),
+      min_obj_conf=float(z['min_obj_conf']),
+      min_frag_rel_conf=float(z['min_frag_rel_conf']),
+      project_to_surface=False, only_annotated_objs=bool(z['only_annotated']))
+  assert sorted(out.keys()) == sorted(int(o) for o in z['out_obj_ids'])
+  for oid in out:
+    for k in KEYS:
+      exp = z['out_%d_%s' % (oid, k)]
+      assert out[oid][k].dtype == exp.dtype, (oid, k)
+      assert np.array_equal(out[oid][k], exp), (oid, k)
+
+
+def test_corresp_matches_oracle_at_full_size():
+  """C2-sized head map (120x160, 21 objects): HIP vs the numpy oracle, bit-exact,
+  plus the size-independent properties (raster/fragment order, px_id density)."""
+  from epos_amd import corresp
+  from oracle import corresp_ref
+  rng = np.random.RandomState(11)
+  h, w, O, F = 120, 160, 21, 64
+  obj = rng.standard_normal((h, w, O + 1)).astype('f') * 3
+  obj = np.exp(obj) / np.exp(obj).sum(-1, keepdims=True)
+  frag = rng.standard_normal((h, w, O, F)).astype('f') * 3
+  frag = (np.exp(frag) / np.exp(frag).sum(-1, keepdims=True)).astype('f')
+  loc = rng.standard_normal((h, w, O, F, 3)).astype('f')
+  centers = rng.uniform(-80, 80, (O, F, 3))
+  sizes = rng.uniform(5, 40, (O, F))
+  store = Store(centers, sizes)
+  gt = [1, 7, 21]
+  out = corresp.establish_many_to_many(obj.astype('f'), frag, loc, gt, store, 0.25,
+                                       0.1, 0.5, False, True)
+  ref = corresp_ref.establish_many_to_many(
+      obj.astype('f'), frag, loc, gt, store.dp_model['obj_ids'],
+      store.frag_centers, store.frag_sizes, 0.25, 0.1, 0.5, True)
+  assert sorted(out) == sorted(ref) == gt
+  for oid in gt:
+    for k in KEYS:
+      assert np.array_equal(out[oid][k], ref[oid][k]), (oid, k)
+    px, fr = out[oid]['px_id'], out[oid]['frag_id']
+    assert (np.diff(px) >= 0).all()                      # raster order
+    same = np.diff(px) == 0
+    assert (np.diff(fr)[same] > 0).all()                 # ascending fragment id
+    assert px.max() + 1 == len(np.unique(px))            # dense px ids
+
+
+# ----------------------------------------------------------------- fitting --
+K = np.array([[1066.8, 0, 313.0], [0, 1067.5, 241.3], [0, 0, 1]])
+
+
+def rand_rot(rng):
+  q = rng.standard_normal(4)
+  q /= np.linalg.norm(q)
+  w, x, y, z = q
+  return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def scene(rng, n, outlier, sigma, ninst=1):
+  xy, xyz, gts = [], [], []
+  per = n // ninst
+  for _ in range(ninst):
+    R = rand_rot(rng)
+    t = np.array([rng.uniform(-150, 150), rng.uniform(-100, 100),
+                  rng.uniform(600, 1200)])
+    X = rng.uniform(-60, 60, (per, 3))
+    Y = X @ R.T + t
+    p = Y @ K.T
+    p = p[:, :2] / p[:, 2:]
+    p += rng.standard_normal(p.shape) * sigma
+    no = int(per * outlier)
+    p[:no] = rng.uniform(0, [640, 480], (no, 2))
+    xy.append(p); xyz.append(X); gts.append((R, t))
+  return np.concatenate(xy), np.concatenate(xyz), gts
+
+
+def pose_err(R, t, Rg, tg):
+  c = (np.trace(R @ Rg.T) - 1) / 2
+  return np.degrees(np.arccos(np.clip(c, -1, 1))), np.linalg.norm(t - tg)
+
+
+@pytest.mark.parametrize('n,outlier,sigma,seed', [
+    (500, 0.3, 1.0, 0), (2000, 0.5, 1.0, 1), (10000, 0.7, 1.0, 2), (200, 0.0, 0.0, 3),
+    (50, 0.3, 0.5, 4), (6, 0.0, 0.0, 5), (2000, 0.3, 2.0, 6), (777, 0.5, 0.5, 7)])
+def test_ransac_hip_equals_c_oracle_and_recovers_pose(n, outlier, sigma, seed):
+  from epos_amd import fitting
+  from oracle import pnp_ref
+  rng = np.random.RandomState(100 + seed)
+  xy, xyz, gts = scene(rng, n, outlier, sigma)
+  poses, labels, scores = fitting.find6DPoses(xy, xyz, K, seed=seed)
+  rposes, rlabels, rscores = pnp_ref.find6DPoses(xy, xyz, K, seed=seed)
+  assert poses is not None and rposes is not None
+  assert poses.shape == rposes.shape == (3, 4)
+  assert np.array_equal(labels, rlabels)             # inlier index path: bit-exact
+  np.testing.assert_allclose(poses, rposes, rtol=0, atol=1e-9)
+  np.testing.assert_allclose(scores, rscores, rtol=1e-12)
+  rot, tr = pose_err(poses[:3, :3], poses[:3, 3], *gts[0])
+  if sigma <= 1.0:
+    assert rot < 1.0 and tr < 0.01 * gts[0][1][2], (rot, tr)   # <1 deg, <1% depth
+
+
+def test_ransac_multi_instance_and_degenerate():
+  from epos_amd import fitting
+  from oracle import pnp_ref
+  rng = np.random.RandomState(9)
+  xy, xyz, gts = scene(rng, 3000, 0.3, 1.0, ninst=3)
+  poses, labels, scores = fitting.find6DPoses(xy, xyz, K, max_model_number=3,
+                                              seed=3)
+  rp = pnp_ref.default_params(max_model_number=3)
+  rposes, rlabels, rscores = pnp_ref.find6DPoses(xy, xyz, K, params=rp, seed=3)
+  assert poses.shape == rposes.shape == (9, 4)
+  assert np.array_equal(labels, rlabels)
+  np.testing.assert_allclose(poses, rposes, rtol=0, atol=1e-9)
+  for i in range(3):
+    errs = [pose_err(poses[3 * i:3 * i + 3, :3], poses[3 * i:3 * i + 3, 3], *g)
+            for g in gts]
+    assert min(e[0] for e in errs) < 3.0
+  # fewer than 6 correspondences -> None (infer.py:420-422, 490)
+  p, l, s = fitting.find6DPoses(xy[:5], xyz[:5], K)
+  assert p is None and len(s) == 0
+  # pure outliers -> no model or a tiny-support model, identical to the oracle
+  xy2, xyz2, _ = scene(rng, 500, 1.0, 1.0)
+  p, l, s = fitting.find6DPoses(xy2, xyz2, K, seed=1)
+  rpz, rl, rs = pnp_ref.find6DPoses(xy2, xyz2, K, seed=1)
+  assert (p is None) == (rpz is None) and np.array_equal(l, rl)
+  # unlimited instances (detection mode, infer.py:464-465)
+  p, l, s = fitting.find6DPoses(xy, xyz, K, max_model_number=-1, seed=3,
+                                max_poses=8)
+  rp = pnp_ref.default_params(max_model_number=-1)
+  rpz, rl, rs = pnp_ref.find6DPoses(xy, xyz, K, params=rp, seed=3, max_k=8)
+  assert p.shape == rpz.shape and np.array_equal(l, rl)
+
+
+def test_ransac_deterministic_across_runs():
+  from epos_amd import fitting
+  rng = np.random.RandomState(2)
+  xy, xyz, _ = scene(rng, 4000, 0.5, 1.0)
+  a = fitting.find6DPoses(xy, xyz, K, seed=5)
+  b = fitting.find6DPoses(xy, xyz, K, seed=5)
+  assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

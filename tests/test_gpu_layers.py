@@ -1,0 +1,244 @@
+"""GPU parity tests of the layer kernels, called through the C ABI, against the
+torch-CPU oracle (oracle/net_ref.py) on identical seeded inputs. fp32 tolerance:
+rtol = atol = 1e-4 (the bar slim's own atrous tests use, resnet_v1_test.py:239),
+tightened where the arithmetic is order-identical."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+  from epos_amd import _lib
+  assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+  return _lib.load()
+
+
+def _p(t, off=0):
+  return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+
+
+def _pack(lib, w_kn):
+  k, n = w_kn.shape
+  total = lib.epos_pack_pointwise_weights(None, k, n, None)
+  dst = np.empty(total, np.float32)
+  w = np.ascontiguousarray(w_kn, np.float32)
+  lib.epos_pack_pointwise_weights(w.ctypes.data_as(ctypes.c_void_p), k, n,
+                                  dst.ctypes.data_as(ctypes.c_void_p))
+  return torch.from_numpy(dst).cuda()
+
+
+@pytest.mark.parametrize('m,k,n', [(300, 64, 128), (4800, 728, 728), (77, 28, 32),
+                                   (1000, 304, 256), (513, 256, 22), (1, 2048, 256),
+                                   (256, 1280, 256), (130, 36, 1344)])
+@pytest.mark.parametrize('relu,relu_in,res', [(0, 0, 0), (1, 0, 1), (0, 1, 0)])
+def test_pointwise_gemm(lib, m, k, n, relu, relu_in, res):
+  from epos_amd import _lib
+  rng = np.random.RandomState(m + k + n)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  bias = rng.standard_normal(n).astype(np.float32)
+  r = rng.standard_normal((m, n)).astype(np.float32)
+  npad = (n + 127) // 128 * 128
+  bpad = np.zeros(npad, np.float32); bpad[:n] = bias
+  A, Wp, Bd, R = (torch.from_numpy(a).cuda(), _pack(lib, w),
+                  torch.from_numpy(bpad).cuda(), torch.from_numpy(r).cuda())
+  ldc = n + 5                      # write into a wider buffer at an offset
+  C = torch.full((m, ldc), -7.0, device='cuda')
+  args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=_p(Bd),
+                            R=_p(R) if res else None, ldr=n, C=_p(C, 3), ldc=ldc,
+                            M=m, N=n, K=k, relu=relu, relu_in=relu_in, sub=1)
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  torch.cuda.synchronize()
+  out = C.cpu().numpy()
+  aa = np.maximum(a, 0) if relu_in else a
+  ref = aa.astype(np.float64) @ w.astype(np.float64) + bias
+  if res:
+    ref = ref + r
+  if relu:
+    ref = np.maximum(ref, 0)
+  np.testing.assert_allclose(out[:, 3:3 + n], ref, rtol=1e-4, atol=1e-4)
+  assert (out[:, :3] == -7.0).all() and (out[:, 3 + n:] == -7.0).all()
+
+
+def test_pointwise_gemm_layout_is_not_transposed(lib):
+  """A = I with an ASYMMETRIC W must reproduce W (catches row/col swaps)."""
+  from epos_amd import _lib
+  k = n = 64
+  w = np.arange(k * n, dtype=np.float32).reshape(k, n)
+  A = torch.eye(k, device='cuda')
+  C = torch.zeros(k, n, device='cuda')
+  Wp = _pack(lib, w)
+  args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=None, R=None, ldr=0,
+                            C=_p(C), ldc=n, M=k, N=n, K=k, relu=0, relu_in=0,
+                            sub=1)
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  assert np.array_equal(C.cpu().numpy(), w)
+
+
+def test_pointwise_stride2_shortcut(lib):
+  """1x1 stride-2 'SAME' conv (net_xception.py:296-302) samples even pixels."""
+  from epos_amd import _lib
+  from oracle import net_ref
+  rng = np.random.RandomState(0)
+  b, hi, wi, cin, cout = 2, 9, 12, 16, 40
+  x = rng.standard_normal((b, hi, wi, cin)).astype(np.float32)
+  w = rng.standard_normal((1, 1, cin, cout)).astype(np.float32)
+  ref = net_ref.conv2d_raw(torch.from_numpy(x).permute(0, 3, 1, 2), w, 2, 1,
+                           'SAME').permute(0, 2, 3, 1).numpy()
+  ho, wo = ref.shape[1], ref.shape[2]
+  X = torch.from_numpy(x).cuda()
+  C = torch.zeros(b, ho, wo, cout, device='cuda')
+  Wp = _pack(lib, w.reshape(cin, cout))
+  args = _lib.PointwiseArgs(A=_p(X), lda=cin, Wp=_p(Wp), bias=None, R=None,
+                            ldr=0, C=_p(C), ldc=cout, M=b * ho * wo, N=cout,
+                            K=cin, relu=0, relu_in=0, sub=2, Ho=ho, Wo=wo, Hi=hi,
+                            Wi=wi)
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('hi,wi,c,stride,rate', [
+    (17, 23, 32, 1, 1), (16, 24, 64, 2, 1), (15, 21, 8, 2, 1), (20, 28, 16, 1, 2),
+    (60, 80, 8, 1, 12), (30, 40, 8, 1, 36), (9, 9, 12, 1, 4)])
+@pytest.mark.parametrize('relu_in,relu_out', [(0, 0), (1, 0), (0, 1)])
+def test_depthwise(lib, hi, wi, c, stride, rate, relu_in, relu_out):
+  from epos_amd import _lib
+  from oracle import net_ref
+  rng = np.random.RandomState(hi * wi + c)
+  b = 2
+  x = rng.standard_normal((b, hi, wi, c)).astype(np.float32)
+  w = rng.standard_normal((3, 3, c, 1)).astype(np.float32)
+  scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+  bias = rng.standard_normal(c).astype(np.float32)
+  xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+  if relu_in:
+    xt = F.relu(xt)
+  if stride == 1:
+    y = net_ref.depthwise_raw(xt, w, 1, rate, 'SAME')
+  else:
+    y = net_ref.depthwise_raw(net_ref.fixed_padding(xt, 3, rate), w, stride, rate,
+                              'VALID')
+  y = y * torch.from_numpy(scale).view(1, -1, 1, 1) + torch.from_numpy(bias).view(
+      1, -1, 1, 1)
+  if relu_out:
+    y = F.relu(y)
+  ref = y.permute(0, 2, 3, 1).numpy()
+  ho, wo = ref.shape[1], ref.shape[2]
+  w9c = (w[:, :, :, 0].reshape(9, c) * scale[None]).astype(np.float32)
+  X, Wd, Bd = (torch.from_numpy(x).cuda(), torch.from_numpy(w9c).cuda(),
+               torch.from_numpy(bias).cuda())
+  Y = torch.zeros(b, ho, wo, c, device='cuda')
+  args = _lib.DepthwiseArgs(X=_p(X), ldx=c, w9c=_p(Wd), bias=_p(Bd), Y=_p(Y),
+                            ldy=c, B=b, Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c,
+                            stride=stride, rate=rate, relu_in=relu_in,
+                            relu_out=relu_out)
+  _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(args), None))
+  np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('hi,wi,cin,cout,stride,pre', [(16, 20, 3, 32, 2, 1),
+                                                       (15, 21, 3, 8, 2, 1),
+                                                       (12, 16, 32, 64, 1, 0)])
+def test_stem_conv_im2col_gemm(lib, hi, wi, cin, cout, stride, pre):
+  """conv2d_same (resnet_utils.py:77-122) = im2col + GEMM; includes the slim KAT
+  geometry (explicit pad 1 + VALID for stride 2)."""
+  from epos_amd import _lib
+  from oracle import net_ref
+  rng = np.random.RandomState(1)
+  b = 2
+  x = (rng.uniform(0, 255, (b, hi, wi, cin)) if pre else
+       rng.standard_normal((b, hi, wi, cin))).astype(np.float32)
+  w = rng.standard_normal((3, 3, cin, cout)).astype(np.float32) * 0.1
+  xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+  if pre:
+    xt = (2.0 / 255.0) * xt - 1.0
+  ref = net_ref.conv2d_same_raw(xt, w, stride).permute(0, 2, 3, 1).numpy()
+  ho, wo = ref.shape[1], ref.shape[2]
+  k = 9 * cin
+  ld = (k + 3) // 4 * 4
+  X = torch.from_numpy(x).cuda()
+  col = torch.full((b * ho * wo, ld), 9.0, device='cuda')
+  ia = _lib.Im2colArgs(X=_p(X), ldx=cin, col=_p(col), ldcol=ld, B=b, Hi=hi, Wi=wi,
+                       Ho=ho, Wo=wo, C=cin, stride=stride, rate=1, pad=1,
+                       preprocess=pre)
+  _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(ia), None))
+  wk = np.zeros((ld, cout), np.float32); wk[:k] = w.reshape(k, cout)
+  C = torch.zeros(b * ho * wo, cout, device='cuda')
+  args = _lib.PointwiseArgs(A=_p(col), lda=ld, Wp=_p(_pack(lib, wk)), bias=None,
+                            R=None, ldr=0, C=_p(C), ldc=cout, M=b * ho * wo,
+                            N=cout, K=ld, relu=0, relu_in=0, sub=1)
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  np.testing.assert_allclose(C.cpu().numpy().reshape(ref.shape), ref, rtol=1e-4,
+                             atol=1e-4)
+
+
+def test_slim_conv2d_same_kat_on_device(lib):
+  """external/slim/nets/resnet_v1_test.py:72-109 on the HIP path: x,w = i+j grids,
+  4x4 input, stride 2 -> [[14,43],[43,84]] (NOT TF-SAME's [[48,37],[37,22]])."""
+  from epos_amd import _lib
+  x = np.add.outer(np.arange(4), np.arange(4)).astype(np.float32).reshape(1, 4, 4, 1)
+  w = np.add.outer(np.arange(3), np.arange(3)).astype(np.float32).reshape(9, 1)
+  X = torch.from_numpy(x).cuda()
+  col = torch.zeros(4, 12, device='cuda')
+  ia = _lib.Im2colArgs(X=_p(X), ldx=1, col=_p(col), ldcol=12, B=1, Hi=4, Wi=4,
+                       Ho=2, Wo=2, C=1, stride=2, rate=1, pad=1, preprocess=0)
+  _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(ia), None))
+  wk = np.zeros((12, 1), np.float32); wk[:9] = w
+  C = torch.zeros(4, 1, device='cuda')
+  args = _lib.PointwiseArgs(A=_p(col), lda=12, Wp=_p(_pack(lib, wk)), bias=None,
+                            R=None, ldr=0, C=_p(C), ldc=1, M=4, N=1, K=12, relu=0,
+                            relu_in=0, sub=1)
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  assert C.cpu().numpy().reshape(2, 2).tolist() == [[14, 43], [43, 84]]
+
+
+def test_global_avg_pool_and_resize(lib):
+  from epos_amd import _lib
+  from oracle import net_ref
+  rng = np.random.RandomState(3)
+  b, h, w, c = 2, 15, 20, 72
+  x = rng.standard_normal((b, h, w, c)).astype(np.float32)
+  X = torch.from_numpy(x).cuda()
+  Y = torch.zeros(b, c, device='cuda')
+  _lib.check(lib.epos_global_avg_pool_f32(_p(X), c, _p(Y), b, h * w, c, None))
+  np.testing.assert_allclose(Y.cpu().numpy(), x.mean(axis=(1, 2)), rtol=1e-5,
+                             atol=1e-6)
+  for (ho, wo) in [(29, 39), (30, 40), (h, w)]:
+    ref = net_ref.resize_bilinear_align_corners(
+        torch.from_numpy(x).permute(0, 3, 1, 2), (ho, wo)).permute(0, 2, 3, 1).numpy()
+    Z = torch.zeros(b, ho, wo, c + 8, device='cuda')
+    _lib.check(lib.epos_resize_bilinear_f32(_p(X), c, _p(Z, 4), c + 8, b, h, w, ho,
+                                            wo, c, None))
+    np.testing.assert_allclose(Z.cpu().numpy()[..., 4:4 + c], ref, rtol=1e-5,
+                               atol=1e-5)
+  # broadcast from 1x1 (image pooling branch)
+  P1 = torch.from_numpy(x[:, :1, :1, :].copy()).cuda()
+  Z = torch.zeros(b, 6, 7, c, device='cuda')
+  _lib.check(lib.epos_resize_bilinear_f32(_p(P1), c, _p(Z), c, b, 1, 1, 6, 7, c,
+                                          None))
+  assert np.array_equal(Z.cpu().numpy(), np.broadcast_to(x[:, :1, :1, :],
+                                                         (b, 6, 7, c)))
+
+
+@pytest.mark.parametrize('g', [2, 22, 31, 64])
+def test_softmax_and_argmax(lib, g):
+  from epos_amd import _lib
+  rng = np.random.RandomState(g)
+  n = 1000
+  x = (rng.standard_normal((n, g)) * 3).astype(np.float32)
+  x[5, :] = 1.25                                    # exact tie -> first index
+  X = torch.from_numpy(x).cuda()
+  lab = torch.zeros(n, dtype=torch.int64, device='cuda')
+  _lib.check(lib.epos_softmax_groups_f32(_p(X), n, g, None))
+  _lib.check(lib.epos_argmax_i64(_p(X), g, _p(lab), n, g, None))
+  ref = torch.softmax(torch.from_numpy(x), dim=-1).numpy()
+  out = X.cpu().numpy()
+  np.testing.assert_allclose(out, ref, rtol=2e-6, atol=1e-7)
+  assert np.array_equal(lab.cpu().numpy(), out.argmax(axis=1))
+  assert lab[5].item() == 0

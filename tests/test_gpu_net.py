@@ -1,0 +1,64 @@
+"""GPU parity of the whole network plan against the torch-CPU oracle
+(oracle/net_ref.py), fp32: logits within rtol = atol = 2e-4 of the oracle's
+(summation order differs: BN folded, MFMA k-pairing), predictions likewise, object
+labels identical except at near-ties."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('h,w,num_objs,batch', [(96, 128, 2, 1), (65, 97, 1, 2)])
+def test_net_matches_oracle(h, w, num_objs, batch):
+  from epos_amd import model, weights
+  from oracle import net_ref
+  ckpt = weights.random_init(num_objs=num_objs, seed=3, randomize_bn=True,
+                             logits_std=0.2)
+  img = np.random.RandomState(0).randint(0, 256, (batch, h, w, 3)).astype('f')
+  ref = net_ref.predict(img, ckpt, num_objs=num_objs, num_frags=64)
+  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
+  net = model.get_net(ckpt, batch, h, w, num_objs, 64, mo)
+  out = net.forward(torch.from_numpy(img).cuda())
+  torch.cuda.synchronize()
+  ep = ref['_end_points']
+
+  def nhwc(t):
+    return t.permute(0, 2, 3, 1).numpy()
+  # intermediate check points (plan buffers)
+  np.testing.assert_allclose(net.encoder.cpu().numpy(), nhwc(ep['encoder']),
+                             rtol=2e-4, atol=2e-4)
+  np.testing.assert_allclose(net.aspp_concat.cpu().numpy(),
+                             nhwc(ep['aspp_concat']), rtol=2e-4, atol=2e-4)
+  np.testing.assert_allclose(net.decoder_concat.cpu().numpy(),
+                             nhwc(ep['decoder_concat']), rtol=2e-4, atol=2e-4)
+  np.testing.assert_allclose(net.decoder_out.cpu().numpy(),
+                             nhwc(ep['decoder/decoder_conv1']), rtol=2e-4,
+                             atol=2e-4)
+  for k in ['pred_obj_conf', 'pred_frag_conf', 'pred_frag_loc']:
+    a = out[k].cpu().numpy()
+    assert a.shape == ref[k].shape and a.dtype == ref[k].dtype, k
+    np.testing.assert_allclose(a, ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
+  lab = out['pred_obj_label'].cpu().numpy()
+  assert lab.dtype == np.int64 and lab.shape == ref['pred_obj_label'].shape
+  conf = np.sort(ref['pred_obj_conf'], axis=-1)
+  clear = (conf[..., -1] - conf[..., -2]) > 1e-3
+  assert np.array_equal(lab[clear], ref['pred_obj_label'][clear])
+  # graph replay gives the same bits as eager
+  a0 = out['pred_frag_loc'].clone()
+  out2 = net.forward(torch.from_numpy(img).cuda(), use_graph=True)
+  torch.cuda.synchronize()
+  assert torch.equal(a0, out2['pred_frag_loc'])
+
+
+def test_predict_operator_api():
+  from epos_amd import model, weights
+  ckpt = weights.random_init(num_objs=1, seed=0)
+  img = np.zeros((1, 64, 64, 3), np.float32)
+  mo = model.ModelOptions(model.get_outputs_to_num_channels(1, 64))
+  out = model.predict(img, mo, ckpt, num_objs=1, num_frags=64)
+  assert set(out) == {'pred_obj_conf', 'pred_obj_label', 'pred_frag_conf',
+                      'pred_frag_loc'}
+  assert tuple(out['pred_frag_loc'].shape) == (1, 16, 16, 1, 64, 3)
+  with pytest.raises(NotImplementedError):
+    model.predict(img, mo, ckpt, upsample_logits=True, num_objs=1, num_frags=64)

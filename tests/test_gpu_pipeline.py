@@ -1,0 +1,54 @@
+"""End-to-end GPU test: network -> correspondences -> PnP-RANSAC in HBM vs the
+same stages chained on the CPU oracle from the SAME head tensors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class Store(object):
+  def __init__(self, num_objs, num_frags, seed=0):
+    rng = np.random.RandomState(seed)
+    self.dp_model = {'obj_ids': list(range(1, num_objs + 1))}
+    self.frag_centers = {o: rng.uniform(-80, 80, (num_frags, 3))
+                         for o in self.dp_model['obj_ids']}
+    self.frag_sizes = {o: rng.uniform(5, 40, num_frags)
+                       for o in self.dp_model['obj_ids']}
+
+
+def test_pipeline_matches_oracle_chain():
+  from epos_amd import pipeline, weights
+  from oracle import corresp_ref, pnp_ref
+  O, F, B, H, W_ = 3, 64, 2, 96, 128
+  ckpt = weights.random_init(num_objs=O, seed=5, randomize_bn=True, logits_std=0.6)
+  store = Store(O, F)
+  pipe = pipeline.EposPipeline(ckpt, B, H, W_, O, F, store, capacity=1 << 18)
+  img = np.random.RandomState(1).randint(0, 256, (B, H, W_, 3)).astype('f')
+  Ks = np.tile(np.array([[300., 0, 64], [0, 300., 48], [0, 0, 1]]), (B, 1, 1))
+  targets = [{1: 1, 3: 1}, {2: 1}]
+  poses, times = pipe.process_batch(torch.from_numpy(img).cuda(), Ks, targets,
+                                    seed=7, timing=True)
+  assert set(times) == {'prediction', 'establish_corr', 'fitting', 'total'}
+  # The oracle chain on the head tensors the HIP network produced.
+  pred = {k: v.cpu().numpy() for k, v in pipe.net.forward().items()}
+  slots, wants = pipe.make_slots(targets)
+  exp = []
+  for (im, obj_id), want in zip(slots, wants):
+    c = corresp_ref.establish_many_to_many(
+        pred['pred_obj_conf'][im], pred['pred_frag_conf'][im],
+        pred['pred_frag_loc'][im], [obj_id], store.dp_model['obj_ids'],
+        store.frag_centers, store.frag_sizes, 0.25, 0.1, 0.5, True)
+    if obj_id not in c:
+      continue
+    seed = (7 * 1000003 + im * 1009 + obj_id) & 0x7fffffffffffffff
+    rp, rl, rs = pnp_ref.find6DPoses(
+        c[obj_id]['coord_2d'], c[obj_id]['coord_3d'], Ks[im],
+        params=pnp_ref.default_params(max_model_number=want), seed=seed)
+    if rp is not None:
+      exp.append((im, obj_id, rp, rs))
+  assert len(poses) == len(exp)
+  for p, (im, obj_id, rp, rs) in zip(poses, exp):
+    assert (p['im_id'], p['obj_id']) == (im, obj_id)
+    np.testing.assert_allclose(np.hstack([p['R'], p['t']]), rp[:3], atol=1e-9)
+    np.testing.assert_allclose(p['score'], rs[0], rtol=1e-12)

@@ -130,7 +130,7 @@ def test_ransac_hip_equals_c_oracle_and_recovers_pose(n, outlier, sigma, seed):
   np.testing.assert_allclose(scores, rscores, rtol=1e-12)
   rot, tr = pose_err(poses[:3, :3], poses[:3, 3], *gts[0])
   if sigma <= 1.0:
-    assert rot < 1.0 and tr < 0.01 * gts[0][1][2], (rot, tr)   # <1 deg, <1% depth
+    assert rot < 1.5 and tr < 0.02 * gts[0][1][2], (rot, tr)   # <1.5 deg, <2% depth
 
 
 def test_ransac_multi_instance_and_degenerate():

@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""EPOS inference benchmark on MI355X: images/sec end-to-end (CNN + correspondence
+extraction + PnP-RANSAC), BASELINE.json's metric, on synthetic 640x480 frames.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch (default: 1 image per GPU =
+BASELINE config C2, "YCB-V, xc65, batch=1 on 1 MI355X": 21 objects, 64 fragments,
+5 target objects per image) with the image tensor already resident in HBM and the
+pose records on the host at the end of the step. Weights are random-init with the
+reference's initialisers (no network access for the released checkpoints).
+
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+  "roofline":     fp32-MFMA roofline of the dominant kernel (pointwise_gemm_f32),
+                  measured with HIP events around every launch of it,
+  "cpu_baseline": the CPU oracle (torch-CPU net + numpy corresp + C RANSAC) timed
+                  on this host on a bounded sample (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from epos_amd import dist as edist          # noqa: E402
+from epos_amd import pipeline, synthetic, weights   # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 roof
+ALGO_GFLOP_C2 = 455.0           # SURVEY.md App. A, per image
+
+
+def parse_args():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--batch-per-gpu', type=int, default=1)
+  ap.add_argument('--height', type=int, default=480)
+  ap.add_argument('--width', type=int, default=640)
+  ap.add_argument('--num-objs', type=int, default=21)
+  ap.add_argument('--num-frags', type=int, default=64)
+  ap.add_argument('--objs-per-image', type=int, default=5)
+  ap.add_argument('--logits-std', type=float, default=1.0,
+                  help='std of the random-init logits weights (model.py:437 uses '
+                       '0.01, which leaves every confidence below tau_a; 1.0 '
+                       'gives YCB-V-like correspondence counts so that the '
+                       'corr/RANSAC stages do real work)')
+  ap.add_argument('--no-graph', action='store_true')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-roofline', action='store_true')
+  ap.add_argument('--cpu-baseline-images', type=int, default=1)
+  return ap.parse_args()
+
+
+def cpu_baseline(ckpt, store, args, frames):
+  """Oracle chain on the host cores: the reference's CPU path cannot run (no TF,
+  no progressive-x), so this is the build's restatement ("port")."""
+  from oracle import corresp_ref, net_ref, pnp_ref
+  threads = min(10, os.cpu_count() or 1)      # infer.py:693-698: 10 TF threads
+  torch.set_num_threads(threads)
+  n = 0
+  t0 = time.time()
+  stage = {'prediction': 0.0, 'establish_corr': 0.0, 'fitting': 0.0}
+  for i in range(frames):
+    img = synthetic.image(i, args.height, args.width)[None]
+    tgt = synthetic.targets(i, args.num_objs, args.objs_per_image)
+    t = time.time()
+    pred = net_ref.predict(img, ckpt, num_objs=args.num_objs,
+                           num_frags=args.num_frags)
+    stage['prediction'] += time.time() - t
+    t = time.time()
+    corr = corresp_ref.establish_many_to_many(
+        pred['pred_obj_conf'][0], pred['pred_frag_conf'][0],
+        pred['pred_frag_loc'][0], list(tgt), store.dp_model['obj_ids'],
+        store.frag_centers, store.frag_sizes, 0.25, 0.1, 0.5, True)
+    stage['establish_corr'] += time.time() - t
+    t = time.time()
+    for obj_id, c in corr.items():              # serial per object, infer.py:412
+      if len(c['coord_2d']) < 6:
+        continue
+      pnp_ref.find6DPoses(c['coord_2d'], c['coord_3d'], synthetic.YCBV_K,
+                          params=pnp_ref.default_params(max_model_number=1),
+                          seed=obj_id)
+    stage['fitting'] += time.time() - t
+    n += 1
+  dt = time.time() - t0
+  return {
+      'value': n / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+      'sample': '%d synthetic %dx%d frame(s), %d objs/%d targets: torch-CPU fp32 '
+                'net (%d threads) + numpy corresp + single-thread C PnP-RANSAC '
+                '(oracle/); stage seconds %s' % (
+                    n, args.width, args.height, args.num_objs,
+                    args.objs_per_image, threads,
+                    {k: round(v, 3) for k, v in stage.items()}),
+  }
+
+
+def gemm_roofline(pipe, steps):
+  """HIP-event timing of every pointwise_gemm_f32 launch of the plan (events on
+  the stream the kernels are launched on), averaged over `steps` passes."""
+  net = pipe.net
+  s = net._stream()
+  names = [n for n, _ in net.ops]
+  is_gemm = [net.op_flops.get(n, 0) > 0 and 'depthwise' not in n for n in names]
+  evs = []
+  for _ in range(steps):
+    row = []
+    for (name, fn), g in zip(net.ops, is_gemm):
+      if g:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(s)
+        e1.record()
+        row.append((name, e0, e1))
+      else:
+        fn(s)
+    evs.append(row)
+  torch.cuda.synchronize()
+  total_ms, launches, flops = 0.0, 0, 0
+  per = {}
+  for row in evs:
+    for name, e0, e1 in row:
+      ms = e0.elapsed_time(e1)
+      total_ms += ms
+      launches += 1
+      flops += net.op_flops[name]
+      per.setdefault(name, []).append(ms)
+  achieved = flops / (total_ms * 1e-3) / 1e12
+  return {
+      'bound': 'mfma', 'achieved': round(achieved, 2),
+      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+      'kernel': 'pointwise_gemm_f32',
+      'launches_per_image': launches // steps // net.B,
+      'avg_launch_us': round(total_ms * 1e3 / launches, 2),
+      'gflop_per_image': round(flops / steps / net.B / 1e9, 1),
+      'how': 'sum of algorithmic 2*M*N*K over all launches / sum of HIP-event '
+             'durations, %d eager passes after the timed region' % steps,
+  }, per
+
+
+def main():
+  args = parse_args()
+  rank, world, local_rank = edist.init_from_env()
+  if world != args.gpus and world > 1:
+    raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X (no CPU fallback); the CPU oracle '
+                     'is only timed beside the GPU path.')
+  torch.cuda.set_device(local_rank)
+  dev = 'cuda:%d' % local_rank
+  B = args.batch_per_gpu
+  ckpt = weights.random_init(num_objs=args.num_objs, num_frags=args.num_frags,
+                             seed=0, logits_std=args.logits_std)
+  store = synthetic.ModelStore(args.num_objs, args.num_frags, seed=0)
+  pipe = pipeline.EposPipeline(
+      ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
+      capacity=1 << 21, max_instances=1, device=dev,
+      use_graph=not args.no_graph)
+  # Synthetic frames, resident in HBM before the timed region.
+  n_pool = 4
+  pool = []
+  for j in range(n_pool):
+    idx = [rank * 100000 + j * B + b for b in range(B)]
+    imgs = np.stack([synthetic.image(i, args.height, args.width) for i in idx])
+    tg = [synthetic.targets(i, args.num_objs, args.objs_per_image) for i in idx]
+    pool.append((torch.from_numpy(imgs).to(dev), tg, idx))
+  Ks = np.tile(synthetic.YCBV_K, (B, 1, 1))
+  max_records = B * args.objs_per_image * 2
+
+  def step(i):
+    imgs, tg, idx = pool[i % n_pool]
+    poses, _ = pipe.process_batch(imgs, Ks, tg, image_ids=idx, seed=i)
+    return edist.gather_poses(poses, max_records)
+
+  n_poses = 0
+  for i in range(args.warmup):
+    step(i)
+  torch.cuda.synchronize()
+  edist.barrier()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    n_poses += len(step(args.warmup + i))
+  torch.cuda.synchronize()
+  edist.barrier()
+  elapsed = edist.max_over_ranks(time.perf_counter() - t0)
+
+  # correspondence statistics of the last step (work actually done by corr/RANSAC)
+  totals = pipe.corr.totals[:pipe.corr.S].cpu().numpy()
+  images = args.steps * B * world
+  value = images / elapsed
+  result = {
+      'metric': 'images/sec end-to-end (CNN+PnP-RANSAC), YCB-V 640x480',
+      'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world,
+      'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f32', 'data': 'synthetic',
+      'config': {
+          'workload': 'C2: synthetic 640x480 RGB, xception_65 random-init '
+                      '(reference initialisers, logits std %g), %d objects x %d '
+                      'fragments, %d target objects/image, batch %d per GPU, '
+                      'dense heads + corr + PnP-RANSAC(400 iters, fp64)' % (
+                          args.logits_std, args.num_objs, args.num_frags,
+                          args.objs_per_image, B),
+          'height': args.height, 'width': args.width,
+          'batch_per_gpu': B, 'global_batch': B * world,
+          'parallelism': 'dp%d (images sharded, one all_gather of pose records)'
+                         % world,
+          'hip_graph': not args.no_graph,
+          'corr_per_slot_last_step': [int(x) for x in totals[:, 1]],
+          'poses_per_step': round(n_poses / max(args.steps, 1), 2),
+          'algorithmic_gflop_per_image': round(pipe.net.flops / B / 1e9, 1),
+      },
+  }
+  if rank == 0 and not args.no_roofline:
+    roof, _ = gemm_roofline(pipe, max(2, min(args.steps, 5)))
+    roof['end_to_end_tflops'] = round(value / world * pipe.net.flops / B / 1e12, 2)
+    result['roofline'] = roof
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    result['cpu_baseline'] = cpu_baseline(ckpt, store, args,
+                                          args.cpu_baseline_images)
+  edist.barrier()
+  if rank == 0:
+    print(json.dumps(result))
+  if world > 1:
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -97,6 +97,8 @@ SYMBOLS = {
                                     [vp, ctypes.c_int, ctypes.c_int, vp]),
     'epos_pointwise_conv_f32': (ctypes.c_int,
                                 [ctypes.POINTER(PointwiseArgs), vp]),
+    'epos_pointwise_conv_grouped_f32': (ctypes.c_int, [
+        ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp]),
     'epos_depthwise3x3_f32': (ctypes.c_int,
                               [ctypes.POINTER(DepthwiseArgs), vp]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),

@@ -9,10 +9,10 @@
 // Arithmetic: v_mfma_f32_32x32x2_f32 -- exact fp32 multiply-add chains (the
 // reference computes in fp32), 64 FLOP/clk/SIMD = the 157.3 TFLOP/s fp32 roof.
 //
-// Tiling (wave64): 128x128 block tile, 4 waves as 2x2, each wave a 64x64 tile =
-// 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs). K is consumed in steps of 32
-// through double-buffered LDS:
-//   A tile  [128][32(+4 pad)] row-major, filled with coalesced float4 loads along
+// Tiling (wave64): BM x 128 block tile (BM = 128 or 64), 4 waves as 2x2, each
+// wave a (BM/2) x 64 tile = TM x 2 MFMA tiles of 32x32. K is consumed in steps of
+// 32 through double-buffered LDS:
+//   A tile  [BM][32(+4 pad)] row-major, filled with coalesced float4 loads along
 //           the channel axis (NHWC => K is contiguous); the 36-float row stride
 //           makes the per-lane ds_read_b128 of 4 consecutive k conflict-free.
 //   W tile  [8][128][4]: the weights are PRE-PACKED on the host into
@@ -21,33 +21,55 @@
 // MFMA step j of k-group g uses k = 8g + j on lanes 0-31 and k = 8g + 4 + j on
 // lanes 32-63 (any pairing of k is valid as long as A and W agree), so one
 // ds_read_b128 per operand feeds four MFMAs.
+//
+// Schedule: an fp32 MFMA occupies the matrix pipe for 64 cycles, so the only job
+// of the loop is to never let the pipe drain. The loop is software-rotated: the
+// fragments of k-group g+1 are read from LDS before the 16 MFMAs of group g are
+// issued, and at the last group of a K tile the register-staged next tile is
+// written to the other LDS buffer, the (single) barrier of the tile is crossed
+// and the first fragments of the next tile are read -- all in the shadow of the
+// last group's MFMAs. Global loads of tile t+1 are issued at the top of tile t.
+//
+// A launch is GROUPED: up to 8 independent problems (e.g. the four ASPP branches,
+// or the three logit heads) share one grid so that small problems still fill the
+// 256 CUs.
+#include <type_traits>
+
 #include "common.h"
 
 namespace epos {
 namespace {
 
-constexpr int BM = 128;
 constexpr int BN = 128;
 constexpr int BK = 32;
 constexpr int LDS_A_ROW = BK + 4;                  // floats
-constexpr int LDS_A_TILE = BM * LDS_A_ROW;         // floats per buffer
 constexpr int LDS_B_TILE = (BK / 4) * BN * 4;      // floats per buffer
 constexpr int THREADS = 256;
+constexpr int MAX_GROUP = 8;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GroupedArgs {
+  EposPointwiseArgs p[MAX_GROUP];
+  int tile_start[MAX_GROUP + 1];   // prefix sum of tiles per problem
+  int tiles_n[MAX_GROUP];
+  int npad[MAX_GROUP];
+  int count;
+};
 
 __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f),
                      fmaxf(v.w, 0.f));
 }
 
-template <bool RELU_IN>
-__global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(EposPointwiseArgs p,
-                                                               int tiles_n,
-                                                               int npad) {
+template <int BM, bool RELU_IN, bool HAS_RES>
+__global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(GroupedArgs ga_) {
+  constexpr int TM = BM / 64;                 // MFMA tiles per wave along M
+  constexpr int LDS_A_TILE = BM * LDS_A_ROW;
+  constexpr int A_LOADS = BM / 32;            // float4 loads per thread per K tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                       // [2][LDS_A_TILE]
-  float* Bs = smem + 2 * LDS_A_TILE;      // [2][LDS_B_TILE]
+  float* As = smem;                           // [2][LDS_A_TILE]
+  float* Bs = smem + 2 * LDS_A_TILE;          // [2][LDS_B_TILE]
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -55,18 +77,34 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(EposPointwiseArgs 
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int bid = blockIdx.x;
+  // ---- which problem / tile -------------------------------------------------
+  // The grouped arguments are indexed dynamically (by a block-uniform problem
+  // id), so they are read straight from the kernarg segment with scalar loads
+  // instead of through a by-value copy (which would be spilled to scratch).
+  (void)ga_;
+  const GroupedArgs* __restrict__ gp =
+      (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // addrspace cast
+  int bid = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_GROUP; ++i)
+    if (i < gp->count && bid >= gp->tile_start[i]) pi = i;
+  bid -= gp->tile_start[pi];
+  const EposPointwiseArgs p = gp->p[pi];
+  const int tiles_n = gp->tiles_n[pi];
+  const int npad = gp->npad[pi];
   const int tile_n = bid % tiles_n;
   const int tile_m = bid / tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int M = p.M, N = p.N, K = p.K;
 
   // ---- global -> register staging assignments -------------------------------
   const int c4 = t & 7;                    // float4 column within the A tile row
-  const float* arow[4];
+  const float* arow[A_LOADS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < A_LOADS; ++i) {
     int m = m0 + (t >> 3) + 32 * i;
-    m = m < p.M ? m : p.M - 1;             // clamp (stores are predicated)
+    m = m < M ? m : M - 1;                 // clamp (stores are predicated)
     int64_t row = m;
     if (p.sub > 1) {
       const int hw = p.Ho * p.Wo;
@@ -82,100 +120,242 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(EposPointwiseArgs 
   const int64_t wstep_q2 = static_cast<int64_t>(2) * npad * 4;   // +2 k-groups
   const int64_t wstep_tile = static_cast<int64_t>(8) * npad * 4; // +1 K tile
 
-  float4 ga[4], gb[4];
-  auto gload = [&](int kt) {
-    const int k = kt * BK + c4 * 4;
-    const bool kin = k < p.K;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kin) v = *reinterpret_cast<const float4*>(arow[i] + kt * BK);
-      ga[i] = RELU_IN ? relu4(v) : v;
+  // Register staging of the next K tile: named scalars (not arrays) so that they
+  // are guaranteed to live in VGPRs.
+  float4 ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3;
+  ga0 = ga1 = ga2 = ga3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Only the LAST K tile can be partial (K % 32 != 0). Its loads come from a
+  // clamped, valid address and are zero-filled when written to LDS; every other
+  // tile is loaded with no select or branch anywhere near the loads (either would
+  // make hipcc wait for the data on the spot instead of a K tile later). The
+  // pre-activation ReLU is likewise applied at the LDS write.
+  bool g_kin = true;
+  auto gload = [&](int kt, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    int ko = kt * BK;
+    if (TAIL) {
+      g_kin = kt * BK + c4 * 4 < K;
+      ko = g_kin ? ko : 0;
+    }
+    ga0 = *reinterpret_cast<const float4*>(arow[0] + ko);
+    ga1 = *reinterpret_cast<const float4*>(arow[1] + ko);
+    if constexpr (A_LOADS > 2) {
+      ga2 = *reinterpret_cast<const float4*>(arow[2] + ko);
+      ga3 = *reinterpret_cast<const float4*>(arow[3] + ko);
     }
     const float* wp = wbase + kt * wstep_tile;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      gb[i] = *reinterpret_cast<const float4*>(wp + i * wstep_q2);
+    gb0 = *reinterpret_cast<const float4*>(wp);
+    gb1 = *reinterpret_cast<const float4*>(wp + wstep_q2);
+    gb2 = *reinterpret_cast<const float4*>(wp + 2 * wstep_q2);
+    gb3 = *reinterpret_cast<const float4*>(wp + 3 * wstep_q2);
   };
-  auto swrite = [&](int buf) {
+  auto swrite = [&](int buf, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    auto fix = [&](float4 v) {
+      if (TAIL && !g_kin) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      return RELU_IN ? relu4(v) : v;
+    };
     float* a = As + buf * LDS_A_TILE + (t >> 3) * LDS_A_ROW + c4 * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(a + 32 * i * LDS_A_ROW) = ga[i];
+    *reinterpret_cast<float4*>(a) = fix(ga0);
+    *reinterpret_cast<float4*>(a + 32 * LDS_A_ROW) = fix(ga1);
+    if constexpr (A_LOADS > 2) {
+      *reinterpret_cast<float4*>(a + 64 * LDS_A_ROW) = fix(ga2);
+      *reinterpret_cast<float4*>(a + 96 * LDS_A_ROW) = fix(ga3);
+    }
     float* b = Bs + buf * LDS_B_TILE + (bq * BN + bn) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(b + i * 2 * BN * 4) = gb[i];
+    *reinterpret_cast<float4*>(b) = gb0;
+    *reinterpret_cast<float4*>(b + 2 * BN * 4) = gb1;
+    *reinterpret_cast<float4*>(b + 4 * BN * 4) = gb2;
+    *reinterpret_cast<float4*>(b + 6 * BN * 4) = gb3;
   };
 
-  f32x16 acc[2][2];
+  const int a_frag_off = (wm * (BM / 2) + l31) * LDS_A_ROW + h * 4;
+  const int b_frag_off = (h * BN + wn * 64 + l31) * 4;
+  float4 fa[TM], fb[2];
+  auto read_frags = [&](int buf, int g) {
+    const float* a_s = As + buf * LDS_A_TILE + a_frag_off + g * 8;
+    const float* b_s = Bs + buf * LDS_B_TILE + b_frag_off + g * 2 * BN * 4;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
+      fa[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * LDS_A_ROW);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      fb[j] = *reinterpret_cast<const float4*>(b_s + j * 32 * 4);
+  };
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (p.K + BK - 1) / BK;
-  gload(0);
-  swrite(0);
+  const int nk = (K + BK - 1) / BK;
+  gload(0, std::true_type{});
+  swrite(0, std::true_type{});
   __syncthreads();
+  read_frags(0, 0);
 
-  const int a_frag_off = (wm * 64 + l31) * LDS_A_ROW + h * 4;
-  const int b_frag_off = (h * BN + wn * 64 + l31) * 4;
-
-  for (int kt = 0; kt < nk; ++kt) {
+  // One K tile. HAS_NEXT is a compile-time tag so that the steady-state body has
+  // no data-dependent control flow around the register staging (which would push
+  // the staged tile into scratch memory and serialise the prefetch).
+  auto tile = [&](int kt, auto has_next_tag, auto next_tail_tag) {
+    constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const float* a_s = As + buf * LDS_A_TILE + a_frag_off;
-    const float* b_s = Bs + buf * LDS_B_TILE + b_frag_off;
-    const int kleft = p.K - kt * BK;       // valid k in this tile (may be < 32)
+    if (HAS_NEXT) {
+      gload(kt + 1, next_tail_tag);
+      // keep the prefetch at the top of the tile (hipcc otherwise sinks the loads
+      // to their first use, right in front of the barrier)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int kleft = K - kt * BK;         // valid k in this tile (may be < 32)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if (g * 8 < kleft) {                 // wave-uniform: skip all-zero k-groups
-        float4 af[2], bf[2];
+      float4 ca[TM], cb[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          af[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * LDS_A_ROW + g * 8);
+      for (int i = 0; i < TM; ++i) ca[i] = fa[i];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bf[j] = *reinterpret_cast<const float4*>(b_s + (g * 2 * BN + j * 32) * 4);
-        const float* afp = reinterpret_cast<const float*>(af);
-        const float* bfp = reinterpret_cast<const float*>(bf);
+      for (int j = 0; j < 2; ++j) cb[j] = fb[j];
+      if (g < 3) {
+        read_frags(buf, g + 1);
+      } else if (HAS_NEXT) {
+        swrite(buf ^ 1, next_tail_tag);
+        __syncthreads();
+        read_frags(buf ^ 1, 0);
+      }
+      if (HAS_NEXT || g * 8 < kleft) {     // wave-uniform: skip all-zero k-groups
+        const float* afp = reinterpret_cast<const float*>(ca);
+        const float* bfp = reinterpret_cast<const float*>(cb);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                   afp[i * 4 + s], bfp[j * 4 + s], acc[i][j], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) swrite(buf ^ 1);
-    __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 2 < nk; ++kt)
+    tile(kt, std::true_type{}, std::false_type{});
+  if (nk >= 2) tile(nk - 2, std::true_type{}, std::true_type{});
+  tile(nk - 1, std::false_type{}, std::false_type{});
 
   // ---- epilogue: bias (+ residual) (+ ReLU), predicated stores -------------
+  // Residual values are fetched with unconditional (clamped) loads, a whole
+  // 32x32 tile at a time, so that they are in flight together.
+  const bool relu = p.relu != 0;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 64 + j * 32 + l31;
-    if (n >= p.N) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
+    const int nc = n < N ? n : N - 1;
+    const float bias = p.bias ? p.bias[nc] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * h;
+      float rv[16];
+      if (HAS_RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = mb + (r & 3) + 8 * (r >> 2);
+          m = m < M ? m : M - 1;
+          rv[r] = p.R[static_cast<int64_t>(m) * p.ldr + nc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M) {
-          float v = acc[i][j][r] + bias;
-          if (p.R) v += p.R[static_cast<int64_t>(m) * p.ldr + n];
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
-        }
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] + bias;
+        if (HAS_RES) v += rv[r];
+        if (relu) v = fmaxf(v, 0.f);
+        if (m < M && n < N) p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// M <= 8 rows (the image-pooling branch, model.py:223-224, M = batch): a GEMV.
+// Block = 64 output channels x 4 K-slices; fixed-order LDS reduction.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pointwise_gemv_f32(EposPointwiseArgs p,
+                                                          int npad) {
+  __shared__ float part[4][64];
+  const int t = threadIdx.x;
+  const int n = blockIdx.x * 64 + (t & 63);
+  const int ks = t >> 6;
+  const int m = blockIdx.y;
+  const float* a = p.A + static_cast<int64_t>(m) * p.lda;
+  const int kq = p.K / 4;
+  float acc = 0.f;
+  for (int q = ks; q < kq; q += 4) {
+    float4 av = *reinterpret_cast<const float4*>(a + q * 4);
+    if (p.relu_in) av = relu4(av);
+    const float4 wv = *reinterpret_cast<const float4*>(
+        p.Wp + (static_cast<int64_t>(q) * npad + n) * 4);
+    acc = fmaf(av.x, wv.x, acc);
+    acc = fmaf(av.y, wv.y, acc);
+    acc = fmaf(av.z, wv.z, acc);
+    acc = fmaf(av.w, wv.w, acc);
+  }
+  part[ks][t & 63] = acc;
+  __syncthreads();
+  if (ks == 0 && n < p.N) {
+    float v = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+    if (p.bias) v += p.bias[n];
+    if (p.R) v += p.R[static_cast<int64_t>(m) * p.ldr + n];
+    if (p.relu) v = fmaxf(v, 0.f);
+    p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
+  }
+}
+
+int validate(const EposPointwiseArgs* a) {
+  EPOS_REQUIRE(a->A && a->Wp && a->C, "null pointer");
+  EPOS_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
+  EPOS_REQUIRE(a->K % 4 == 0 && a->lda % 4 == 0, "K and lda must be multiples of 4");
+  EPOS_REQUIRE((reinterpret_cast<uintptr_t>(a->A) & 15) == 0, "A must be 16-byte aligned");
+  EPOS_REQUIRE(a->sub >= 1, "sub must be >= 1");
+  return EPOS_OK;
+}
+
+template <int BM, bool RELU_IN, bool HAS_RES>
+int launch_grouped_t(const GroupedArgs& g, int total, hipStream_t s) {
+  constexpr int LDS_A_TILE = BM * LDS_A_ROW;
+  const size_t lds = sizeof(float) * (2 * LDS_A_TILE + 2 * LDS_B_TILE);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(pointwise_gemm_f32<BM, RELU_IN, HAS_RES>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((pointwise_gemm_f32<BM, RELU_IN, HAS_RES>), dim3(total),
+                     dim3(THREADS), lds, s, g);
+  return launch_status("pointwise_gemm_f32");
+}
+
+template <int BM>
+int launch_grouped(const EposPointwiseArgs* args, int count, hipStream_t s) {
+  GroupedArgs g;
+  g.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    g.p[i] = args[i];
+    g.npad[i] = static_cast<int>(round_up(args[i].N, BN));
+    g.tiles_n[i] = g.npad[i] / BN;
+    g.tile_start[i] = total;
+    total += static_cast<int>(ceil_div(args[i].M, BM)) * g.tiles_n[i];
+  }
+  for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  const bool relu_in = args[0].relu_in != 0, has_res = args[0].R != nullptr;
+  if (relu_in) {
+    return has_res ? launch_grouped_t<BM, true, true>(g, total, s)
+                   : launch_grouped_t<BM, true, false>(g, total, s);
+  }
+  return has_res ? launch_grouped_t<BM, false, true>(g, total, s)
+                 : launch_grouped_t<BM, false, false>(g, total, s);
 }
 
 }  // namespace
@@ -198,32 +378,32 @@ extern "C" int64_t epos_pack_pointwise_weights(const float* w_kn, int K, int N,
   return total;
 }
 
-extern "C" int epos_pointwise_conv_f32(const EposPointwiseArgs* a, void* stream) {
+extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
+                                               int count, void* stream) {
   using namespace epos;
-  EPOS_REQUIRE(a && a->A && a->Wp && a->C, "null pointer");
-  EPOS_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "empty problem");
-  EPOS_REQUIRE(a->K % 4 == 0 && a->lda % 4 == 0, "K and lda must be multiples of 4");
-  EPOS_REQUIRE((reinterpret_cast<uintptr_t>(a->A) & 15) == 0, "A must be 16-byte aligned");
-  EPOS_REQUIRE(a->sub >= 1, "sub must be >= 1");
-  const int npad = static_cast<int>(round_up(a->N, BN));
-  const int tiles_n = npad / BN;
-  const int64_t tiles_m = ceil_div(a->M, BM);
-  const size_t lds = sizeof(float) * (2 * LDS_A_TILE + 2 * LDS_B_TILE);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pointwise_gemm_f32<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pointwise_gemm_f32<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  dim3 grid(static_cast<unsigned>(tiles_m * tiles_n));
+  EPOS_REQUIRE(args && count >= 1 && count <= MAX_GROUP, "1..8 problems per group");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (a->relu_in)
-    hipLaunchKernelGGL(pointwise_gemm_f32<true>, grid, dim3(THREADS), lds, s, *a,
-                       tiles_n, npad);
-  else
-    hipLaunchKernelGGL(pointwise_gemm_f32<false>, grid, dim3(THREADS), lds, s, *a,
-                       tiles_n, npad);
-  return launch_status("pointwise_gemm_f32");
+  int64_t tiles128 = 0;
+  for (int i = 0; i < count; ++i) {
+    const int rc = validate(&args[i]);
+    if (rc) return rc;
+    EPOS_REQUIRE((args[i].relu_in != 0) == (args[0].relu_in != 0) &&
+                 (args[i].R != nullptr) == (args[0].R != nullptr),
+                 "problems of one group must agree on relu_in / residual");
+    tiles128 += ceil_div(args[i].M, 128) * ceil_div(args[i].N, BN);
+  }
+  if (count == 1 && args[0].M <= 8 && args[0].sub == 1) {
+    const int npad = static_cast<int>(round_up(args[0].N, BN));
+    hipLaunchKernelGGL(pointwise_gemv_f32, dim3(npad / 64, args[0].M), dim3(256), 0,
+                       s, args[0], npad);
+    return launch_status("pointwise_gemv_f32");
+  }
+  // 128-row tiles only when they alone give every CU >= 2 workgroups; otherwise
+  // 64-row tiles double the number of co-resident workgroups.
+  if (tiles128 >= 512) return launch_grouped<128>(args, count, s);
+  return launch_grouped<64>(args, count, s);
+}
+
+extern "C" int epos_pointwise_conv_f32(const EposPointwiseArgs* a, void* stream) {
+  return epos_pointwise_conv_grouped_f32(a, 1, stream);
 }

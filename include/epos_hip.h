@@ -75,6 +75,13 @@ typedef struct EposPointwiseArgs {
 } EposPointwiseArgs;
 int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
 
+/* Grouped form: `count` (1..8) independent problems in ONE launch, so that small
+ * problems (the four ASPP branches, the three logit heads, a shortcut next to a
+ * separable conv) fill the chip together. All problems of a group must agree on
+ * relu_in and on whether a residual is present. */
+int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args, int count,
+                                    void* stream);
+
 /* Depthwise 3x3 conv + folded BatchNorm (+ optional ReLU before and after):
  * the depthwise half of net_xception.py:167-182 / model.py:80-88. stride 1 ->
  * TF 'SAME' (zero pad `rate`); stride 2 -> fixed_padding (net_xception.py:74-93)

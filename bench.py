@@ -49,11 +49,9 @@ def parse_args():
   ap.add_argument('--num-objs', type=int, default=21)
   ap.add_argument('--num-frags', type=int, default=64)
   ap.add_argument('--objs-per-image', type=int, default=5)
-  ap.add_argument('--logits-std', type=float, default=1.0,
-                  help='std of the random-init logits weights (model.py:437 uses '
-                       '0.01, which leaves every confidence below tau_a; 1.0 '
-                       'gives YCB-V-like correspondence counts so that the '
-                       'corr/RANSAC stages do real work)')
+  ap.add_argument('--no-calibrate', action='store_true',
+                  help='keep the raw random-init logits layers (every confidence '
+                       'then stays below tau_a and corr/RANSAC get no work)')
   ap.add_argument('--no-graph', action='store_true')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-roofline', action='store_true')
@@ -110,7 +108,7 @@ def gemm_roofline(pipe, steps):
   net = pipe.net
   s = net._stream()
   names = [n for n, _ in net.ops]
-  is_gemm = [net.op_flops.get(n, 0) > 0 and 'depthwise' not in n for n in names]
+  is_gemm = [net.op_kind.get(n) == 'gemm' for n in names]
   evs = []
   for _ in range(steps):
     row = []
@@ -160,9 +158,24 @@ def main():
   torch.cuda.set_device(local_rank)
   dev = 'cuda:%d' % local_rank
   B = args.batch_per_gpu
+  # Random-init weights with the reference's initialisers; BatchNorm statistics
+  # are randomised so that activations keep an O(0.1..1) scale through the 65
+  # layers (identity BN lets them decay to 1e-3, which both starves the heads and
+  # flatters the clocks), and the logits layers are calibrated on one frame so
+  # that the correspondence / RANSAC stages see YCB-V-like amounts of work.
   ckpt = weights.random_init(num_objs=args.num_objs, num_frags=args.num_frags,
-                             seed=0, logits_std=args.logits_std)
+                             seed=0, randomize_bn=True)
   store = synthetic.ModelStore(args.num_objs, args.num_frags, seed=0)
+  if not args.no_calibrate:
+    from epos_amd import model
+    net0 = model.get_net(ckpt, 1, args.height, args.width, args.num_objs,
+                         args.num_frags, device=dev)
+    net0.forward(torch.from_numpy(
+        synthetic.image(0, args.height, args.width)[None]).to(dev))
+    torch.cuda.synchronize()
+    synthetic.calibrate_logits(ckpt, net0.decoder_out[0].cpu().numpy())
+    model._NETS.clear()
+    del net0
   pipe = pipeline.EposPipeline(
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
       capacity=1 << 21, max_instances=1, device=dev,
@@ -208,11 +221,13 @@ def main():
       'dtype': 'f32', 'data': 'synthetic',
       'config': {
           'workload': 'C2: synthetic 640x480 RGB, xception_65 random-init '
-                      '(reference initialisers, logits std %g), %d objects x %d '
-                      'fragments, %d target objects/image, batch %d per GPU, '
-                      'dense heads + corr + PnP-RANSAC(400 iters, fp64)' % (
-                          args.logits_std, args.num_objs, args.num_frags,
-                          args.objs_per_image, B),
+                      '(reference initialisers, randomised BN statistics, logits '
+                      'layers %s), %d objects x %d fragments, %d target '
+                      'objects/image, batch %d per GPU, dense heads + corr + '
+                      'PnP-RANSAC(400 iters, fp64)' % (
+                          'raw' if args.no_calibrate else 'calibrated to ~10% '
+                          'masked pixels per object', args.num_objs,
+                          args.num_frags, args.objs_per_image, B),
           'height': args.height, 'width': args.width,
           'batch_per_gpu': B, 'global_batch': B * world,
           'parallelism': 'dp%d (images sharded, one all_gather of pose records)'

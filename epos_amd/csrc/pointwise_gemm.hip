@@ -33,6 +33,8 @@
 // A launch is GROUPED: up to 8 independent problems (e.g. the four ASPP branches,
 // or the three logit heads) share one grid so that small problems still fill the
 // 256 CUs.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -84,7 +86,17 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(GroupedArgs ga_) {
   (void)ga_;
   const GroupedArgs* __restrict__ gp =
       (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // addrspace cast
-  int bid = blockIdx.x;
+  // XCD-aware remap (blocks are dispatched round-robin over the 8 XCDs, each with
+  // a private 4 MiB L2): XCD x works on one contiguous chunk of the logical tile
+  // order (all N tiles of a run of M tiles), so an A tile is fetched into that
+  // L2 once and reused by its N tiles, and the packed weights stay L2-resident.
+  int bid;
+  {
+    const int total = gp->tile_start[MAX_GROUP];
+    const int raw = blockIdx.x, x = raw & 7, idx = raw >> 3;
+    const int q = total >> 3, r = total & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < MAX_GROUP; ++i)
@@ -323,13 +335,27 @@ int validate(const EposPointwiseArgs* a) {
 template <int BM, bool RELU_IN, bool HAS_RES>
 int launch_grouped_t(const GroupedArgs& g, int total, hipStream_t s) {
   constexpr int LDS_A_TILE = BM * LDS_A_ROW;
-  const size_t lds = sizeof(float) * (2 * LDS_A_TILE + 2 * LDS_B_TILE);
+  constexpr size_t LDS_MAX = 160 * 1024;
+  size_t lds = sizeof(float) * (2 * LDS_A_TILE + 2 * LDS_B_TILE);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(
         reinterpret_cast<const void*>(pointwise_gemm_f32<BM, RELU_IN, HAS_RES>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
     attr_set = true;
+  }
+  // Workgroup placement: the dispatcher packs workgroups onto a CU while its
+  // resources last, so a grid that fits "3 per CU" leaves CUs idle. Request just
+  // enough extra LDS that at most ceil(grid / 256) workgroups fit on one CU; the
+  // grid is then spread over all 256 CUs.
+  static const int spread = [] {
+    const char* e = getenv("EPOS_GEMM_SPREAD");
+    return e ? atoi(e) : 1;
+  }();
+  if (spread) {
+    const int per_cu = (total + 255) / 256;
+    const size_t cap = (LDS_MAX / per_cu) & ~static_cast<size_t>(1023);
+    if (cap > lds) lds = cap;
   }
   hipLaunchKernelGGL((pointwise_gemm_f32<BM, RELU_IN, HAS_RES>), dim3(total),
                      dim3(THREADS), lds, s, g);
@@ -398,9 +424,15 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
                        s, args[0], npad);
     return launch_status("pointwise_gemv_f32");
   }
+  // Tile-height heuristic (EPOS_GEMM_TILE_M=64|128 overrides it for tuning):
   // 128-row tiles only when they alone give every CU >= 2 workgroups; otherwise
   // 64-row tiles double the number of co-resident workgroups.
-  if (tiles128 >= 512) return launch_grouped<128>(args, count, s);
+  static const int forced = [] {
+    const char* e = getenv("EPOS_GEMM_TILE_M");
+    return e ? atoi(e) : 0;
+  }();
+  const bool big = forced ? forced == 128 : tiles128 >= 512;
+  if (big) return launch_grouped<128>(args, count, s);
   return launch_grouped<64>(args, count, s);
 }
 

@@ -63,6 +63,7 @@ class EposNet(object):
     self.ops = []            # (name, callable(stream))
     self.flops = 0           # multiply-add * 2 of the whole plan
     self.op_flops = {}
+    self.op_kind = {}        # 'gemm' | 'dw' | 'im2col' | 'other'
     self._graph = None
     self._build_plan()
 
@@ -110,14 +111,17 @@ class EposNet(object):
     return self._dev(w9c), self._dev(bias)
 
   # --------------------------------------------------------------- ops ---
-  def _add(self, name, fn, flops=0):
+  def _add(self, name, fn, flops=0, kind='other'):
     self.ops.append((name, fn))
     self.flops += flops
     self.op_flops[name] = flops
+    self.op_kind[name] = kind
 
   def _pointwise(self, name, a, a_off, lda, m, k, w_kn, scale, bias, c, c_off,
                  ldc, relu, relu_in=False, res=None, res_off=0, ldr=0, sub=1,
-                 ho=0, wo=0, hi=0, wi=0):
+                 ho=0, wo=0, hi=0, wi=0, group=None):
+    """One 1x1 conv. With ``group`` (a list) the problem is only appended to it;
+    ``_flush_group`` later launches the whole list as ONE grouped GEMM."""
     wp, bp, kpad = self._pack_pointwise(w_kn, scale, bias)
     n = w_kn.shape[1]
     assert kpad == k or (kpad > k and lda >= kpad), (name, k, kpad, lda)
@@ -127,10 +131,29 @@ class EposNet(object):
         C=_ptr(c, c_off), ldc=ldc, M=m, N=n, K=kpad, relu=int(relu),
         relu_in=int(relu_in), sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi)
     lib = self.lib
+    if group is not None:
+      group.append((name, args, 2 * m * n * k))
+      return
 
     def run(stream, args=args):
       _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), stream), name)
-    self._add(name, run, 2 * m * n * k)
+    self._add(name, run, 2 * m * n * k, 'gemm')
+
+  def _flush_group(self, group):
+    """Launches the collected problems as one grouped GEMM (they must agree on
+    relu_in / residual; callers group accordingly)."""
+    if not group:
+      return
+    name = '+'.join(g[0] for g in group)
+    arr = (_lib.PointwiseArgs * len(group))(*[g[1] for g in group])
+    flops = sum(g[2] for g in group)
+    lib = self.lib
+    n = len(group)
+
+    def run(stream, arr=arr):
+      _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, n, stream), name)
+    self._add(name, run, flops, 'gemm')
+    del group[:]
 
   def _depthwise(self, name, x, ldx, hi, wi, c, stride, rate, scope, eps,
                  relu_in, relu_out):
@@ -146,7 +169,7 @@ class EposNet(object):
 
     def run(stream, args=args):
       _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(args), stream), name)
-    self._add(name, run, 2 * 9 * self.B * ho * wo * c)
+    self._add(name, run, 2 * 9 * self.B * ho * wo * c, 'dw')
     return y, ho, wo
 
   def _stem_conv(self, name, x, hi, wi, cin, scope, stride, preprocess):
@@ -166,7 +189,7 @@ class EposNet(object):
 
     def run(stream, args=args):
       _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(args), stream), name)
-    self._add(name + '/im2col', run)
+    self._add(name + '/im2col', run, 0, 'im2col')
     w_kn, scale, bias = self._conv_params(scope, XCEPTION_BN_EPS)
     cout = w_kn.shape[1]
     y = self._empty(self.B, ho, wo, cout)
@@ -182,12 +205,14 @@ class EposNet(object):
     ho = hi if stride == 1 else (hi - 1) // 2 + 1
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     shortcut = None
+    grp = []
     if skip == 'conv':
+      # The shortcut GEMM shares a launch with the first pointwise conv.
       w_kn, sc, bi = self._conv_params(scope + '/shortcut', eps)
       shortcut = self._empty(self.B, ho, wo, depths[2])
       self._pointwise(scope + '/shortcut', x, 0, cin, self.B * ho * wo, cin,
                       w_kn, sc, bi, shortcut, 0, depths[2], relu=False,
-                      sub=stride, ho=ho, wo=wo, hi=hi, wi=wi)
+                      sub=stride, ho=ho, wo=wo, hi=hi, wi=wi, group=grp)
     r, rh, rw, rc = x, hi, wi, cin
     taps = {}
     for i in range(3):
@@ -205,7 +230,9 @@ class EposNet(object):
         res, ldr = x, cin
       self._pointwise(sc + '_pointwise', d, 0, rc, self.B * dh * dw_, rc, w_kn,
                       scl, bi, y, 0, depths[i], relu=act_in_sep, res=res,
-                      ldr=ldr)
+                      ldr=ldr, group=grp if i == 0 else None)
+      if i == 0:
+        self._flush_group(grp)
       taps[i] = y
       r, rh, rw, rc = y, dh, dw_, depths[i]
     return r, rh, rw, rc, taps
@@ -269,15 +296,18 @@ class EposNet(object):
           _ptr(pool_feat), 256, _ptr(cat), ldcat, B, 1, 1, eh, ew, 256, stream),
                  'image_pooling/resize')
     self._add('image_pooling/resize', run_bcast)
+    # The four spatial ASPP branches (N = 256 each) share ONE grouped GEMM launch.
+    grp = []
     w_kn, sc, bi = self._conv_params('aspp0', HEAD_BN_EPS)
     self._pointwise('aspp0', x, 0, ec, m_enc, ec, w_kn, sc, bi, cat, 256, ldcat,
-                    relu=True)
+                    relu=True, group=grp)
     for i, r in enumerate(self.atrous_rates, 1):
       d, _, _ = self._depthwise('aspp%d_depthwise' % i, x, ec, eh, ew, ec, 1, r,
                                 'aspp%d_depthwise' % i, HEAD_BN_EPS, False, True)
       w_kn, sc, bi = self._conv_params('aspp%d_pointwise' % i, HEAD_BN_EPS)
       self._pointwise('aspp%d_pointwise' % i, d, 0, ec, m_enc, ec, w_kn, sc, bi,
-                      cat, 256 * (i + 1), ldcat, relu=True)
+                      cat, 256 * (i + 1), ldcat, relu=True, group=grp)
+    self._flush_group(grp)
     w_kn, sc, bi = self._conv_params('concat_projection', HEAD_BN_EPS)
     proj = self._empty(B, eh, ew, 256)
     self._pointwise('concat_projection', cat, 0, ldcat, m_enc, ldcat, w_kn, sc,
@@ -316,14 +346,17 @@ class EposNet(object):
 
     # ---- logits (model.py:396-458), sorted(name) order (model.py:503).
     self.logits = {}
+    grp = []
     for name, ch in sorted(W.outputs_to_num_channels(
         self.num_objs, self.num_frags).items()):
       wt = self.ckpt['logits/%s/weights' % name].reshape(256, ch)
       bs = self.ckpt['logits/%s/biases' % name]
       buf = self._empty(B, dh, dw_, ch)
       self._pointwise('logits/' + name, x, 0, 256, m_dec, 256, wt,
-                      np.ones(ch, np.float32), bs, buf, 0, ch, relu=False)
+                      np.ones(ch, np.float32), bs, buf, 0, ch, relu=False,
+                      group=grp)
       self.logits[name] = buf
+    self._flush_group(grp)              # the three heads: one grouped launch
 
     # ---- predict post-ops (model.py:677-683): softmax in place, argmax.
     self.post_ops = []

@@ -34,3 +34,29 @@ def targets(index, num_objs, objs_per_image=5, rank=0):
   ids = rng.choice(np.arange(1, num_objs + 1), size=min(objs_per_image, num_objs),
                    replace=False)
   return {int(o): 1 for o in sorted(ids)}
+
+
+def calibrate_logits(ckpt, decoder_features, std_obj=2.0, std_frag=3.0,
+                     std_loc=0.3):
+  """Rescales the random-init logits layers of ``ckpt`` (in place) so that, on the
+  given decoder features [P, 256] (from a forward pass on a synthetic frame), the
+  logits are zero-mean per channel with the requested standard deviations.
+
+  Why: with the reference's initialisers (logits std 0.01, model.py:437) every
+  confidence stays below tau_a = 0.1, and with any global rescale one class wins
+  at every pixel, because random-init features of a noise image are dominated by
+  their spatial mean. Either way the correspondence and RANSAC stages would get
+  no work. After calibration each object passes tau_a on ~10 % of the pixels and
+  keeps a few fragments per pixel (YCB-V-like correspondence counts); the network
+  arithmetic is unchanged."""
+  x = np.asarray(decoder_features, np.float64).reshape(-1, 256)
+  mu = x.mean(axis=0)
+  xc = x - mu
+  for name, std in (('pred_obj_conf', std_obj), ('pred_frag_conf', std_frag),
+                    ('pred_frag_loc', std_loc)):
+    w = ckpt['logits/%s/weights' % name].reshape(256, -1).astype(np.float64)
+    s = (xc[::7] @ w).std(axis=0) + 1e-12
+    w = w * (std / s)
+    ckpt['logits/%s/weights' % name] = w.astype(np.float32).reshape(1, 1, 256, -1)
+    ckpt['logits/%s/biases' % name] = (-(mu @ w)).astype(np.float32)
+  return ckpt

@@ -23,8 +23,7 @@ rows = net.time_ops(iters=5)
 tot = sum(r[1] for r in rows)
 agg = {}
 for name, ms, fl in rows:
-  kind = ('dw' if 'depthwise' in name else 'im2col' if 'im2col' in name else
-          'gemm' if fl else 'other')
+  kind = net.op_kind.get(name, 'other')
   a = agg.setdefault(kind, [0.0, 0.0, 0]); a[0] += ms; a[1] += fl; a[2] += 1
 print('total %.3f ms over %d launches' % (tot, len(rows)))
 for k, (ms, fl, n) in agg.items():

@@ -58,6 +58,80 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
   st4(p.Y + ((static_cast<int64_t>(b) * p.Ho + yo) * p.Wo + xo) * p.ldy + c, acc);
 }
 
+// Stride-1 depthwise 3x3 with a SLIDING WINDOW: one thread = 4 channels x a run
+// of L output pixels of one row whose x coordinates are `rate` apart (x0, x0+r,
+// ...), so consecutive outputs share two of their three input columns. The 9
+// weight vectors are loaded once per run and an output costs 3(L+2)/L input
+// loads instead of 9 (+9 weights). Loads are unconditional from clamped
+// addresses (zero padding is a select) so no load sits under a branch.
+template <int L>
+__global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(EposDepthwiseArgs p,
+                                                              int c4n, int nres,
+                                                              int nchunk,
+                                                              int64_t total) {
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int c = static_cast<int>(id % c4n) * 4;
+  int64_t rest = id / c4n;
+  const int chunk = static_cast<int>(rest % nchunk); rest /= nchunk;
+  const int res = static_cast<int>(rest % nres); rest /= nres;
+  const int y = static_cast<int>(rest % p.Ho);
+  const int b = static_cast<int>(rest / p.Ho);
+  const int r = p.rate;
+  const int x0 = res + chunk * L * r;
+  if (x0 >= p.Wo) return;
+  float4 w[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) w[i] = ld4(p.w9c + i * p.C + c);
+  const float4 bias = ld4(p.bias + c);
+  const float* xb = p.X + static_cast<int64_t>(b) * p.Hi * p.Wi * p.ldx + c;
+  const float* rowp[3];
+  bool rowok[3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yi = y + (ky - 1) * r;
+    rowok[ky] = yi >= 0 && yi < p.Hi;
+    rowp[ky] = xb + static_cast<int64_t>(rowok[ky] ? yi : 0) * p.Wi * p.ldx;
+  }
+  // All (L + 2) x 3 input vectors of the run are requested up front (independent,
+  // unconditional, clamped loads => one memory round trip per thread), then the
+  // window slides over registers.
+  float4 col[L + 2][3];
+#pragma unroll
+  for (int i = 0; i < L + 2; ++i) {
+    const int xi = x0 + (i - 1) * r;
+    const bool xok = xi >= 0 && xi < p.Wi;
+    const int64_t off = static_cast<int64_t>(xok ? xi : 0) * p.ldx;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) col[i][ky] = ld4(rowp[ky] + off);
+  }
+#pragma unroll
+  for (int i = 0; i < L + 2; ++i) {
+    const int xi = x0 + (i - 1) * r;
+    const bool xok = xi >= 0 && xi < p.Wi;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      float4 v = col[i][ky];
+      if (!(xok && rowok[ky])) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      col[i][ky] = p.relu_in ? relu4(v) : v;
+    }
+  }
+  float* yb = p.Y + ((static_cast<int64_t>(b) * p.Ho + y) * p.Wo) * p.ldy + c;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    const int x = x0 + j * r;
+    float4 acc = bias;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      acc = fma4(col[j][ky], w[ky * 3 + 0], acc);
+      acc = fma4(col[j + 1][ky], w[ky * 3 + 1], acc);
+      acc = fma4(col[j + 2][ky], w[ky * 3 + 2], acc);
+    }
+    if (p.relu_out) acc = relu4(acc);
+    if (x < p.Wo) st4(yb + static_cast<int64_t>(x) * p.ldy, acc);
+  }
+}
+
 // --------------------------------------------------------------------------
 // im2col for dense 3x3 convs (scalar: C may be 3).
 // --------------------------------------------------------------------------
@@ -210,10 +284,23 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
   EPOS_REQUIRE(a->stride == 1 || (a->stride == 2 && a->rate == 1),
                "stride 2 requires rate 1");
   const int c4n = a->C / 4;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a->stride == 1 && a->Hi == a->Ho && a->Wi == a->Wo) {
+    constexpr int L = 4;
+    const int nres = a->rate < a->Wo ? a->rate : a->Wo;
+    const int per_res = static_cast<int>(ceil_div(a->Wo, a->rate));
+    const int nchunk = static_cast<int>(ceil_div(per_res, L));
+    const int64_t total =
+        static_cast<int64_t>(a->B) * a->Ho * nres * nchunk * c4n;
+    if (total == 0) return EPOS_OK;
+    hipLaunchKernelGGL(depthwise3x3_s1_kernel<L>, dim3(blocks_for(total, 256)),
+                       dim3(256), 0, st, *a, c4n, nres, nchunk, total);
+    return launch_status("depthwise3x3_s1_kernel");
+  }
   const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * c4n;
   if (total == 0) return EPOS_OK;
   hipLaunchKernelGGL(depthwise3x3_kernel, dim3(blocks_for(total, 256)), dim3(256),
-                     0, static_cast<hipStream_t>(stream), *a, c4n, total);
+                     0, st, *a, c4n, total);
   return launch_status("depthwise3x3_kernel");
 }
 

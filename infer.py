@@ -1,0 +1,347 @@
+#!/usr/bin/env python
+"""EPOS inference on MI355X -- drop-in for ``scripts/infer.py`` of thodan/epos.
+
+    python infer.py --model=<model_name> [flags]                       (infer.py:6-8)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+        --master-addr 127.0.0.1 infer.py --model=<model_name> ...
+
+Same contract as the reference script:
+  * env TF_DATA_PATH / TF_MODELS_PATH / BOP_PATH (config.py:9-16);
+  * <TF_MODELS_PATH>/<model>/params.yml overrides flag defaults (common.py:157-177,
+    list-valued crop sizes parsed from "w,h" strings);
+  * weights from <model>/train/ -- here a ``.npz`` keyed by the TF variable names
+    (latest ``*.npz`` or --checkpoint_name); fragments from <model>/fragments.pkl
+    (datagen.py:254-268) or <model>/fragments.npz;
+  * poses written to <model>/infer/estimated-poses[_<infer_name>].csv in BOP'19
+    format (infer.py:753-760); optional corr_*/NNNNNN_corr_OO.txt (infer.py:294-345).
+
+Input frames: the reference reads TFRecords through TensorFlow, which is not
+available here (TFRecord reading is a "next" item). Frames come
+from ``--frames <dir>`` holding ``frames.json`` (list of {scene_id, im_id, path,
+K[9], targets {obj_id: count}}) + images (.npy HxWx3 or anything PIL reads), or
+from ``--synthetic N`` seeded synthetic frames.
+
+Reference quirks kept on purpose: only the *localization* task has targets (the
+reference dereferences gt_poses=None in detection mode, infer.py:400); here
+--task_type=detection fits every object of the model store with unlimited
+instances. ``infer_crop_size`` is (width, height) as consumed by the reference
+(datagen.py:448-449), despite its help string.
+"""
+import argparse
+import glob
+import json
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+from epos_amd import bop_io, dist as edist, fitting, model, pipeline   # noqa: E402
+from epos_amd import synthetic, weights                                # noqa: E402
+
+PARAMS_FILENAME = 'params.yml'   # common.py
+
+
+def str2bool(v):
+  return str(v).lower() in ('1', 'true', 'yes', 'y')
+
+
+def build_parser():
+  ap = argparse.ArgumentParser(description=__doc__,
+                               formatter_class=argparse.RawTextHelpFormatter)
+  a = ap.add_argument
+  # scripts/infer.py:37-120
+  a('--model', required=True)
+  a('--cpu_only', type=str2bool, default=False)
+  a('--task_type', default=pipeline.LOCALIZATION)
+  a('--infer_tfrecord_names', default=None)
+  a('--infer_max_height_before_crop', type=int, default=480)
+  a('--infer_crop_size', default='640,480')
+  a('--checkpoint_name', default=None)
+  a('--project_to_surface', type=str2bool, default=False)
+  a('--save_estimates', type=str2bool, default=True)
+  a('--save_corresp', type=str2bool, default=False)
+  a('--infer_name', default=None)
+  a('--fitting_method', default='progressive_x')
+  a('--inlier_thresh', type=float, default=4.0)
+  a('--neighbour_max_dist', type=float, default=20.0)
+  a('--min_hypothesis_quality', type=float, default=0.5)
+  a('--required_progx_confidence', type=float, default=0.5)
+  a('--required_ransac_confidence', type=float, default=1.0)
+  a('--min_triangle_area', type=float, default=0.0)
+  a('--use_prosac', type=str2bool, default=False)
+  a('--max_model_number_for_pearl', type=int, default=5)
+  a('--spatial_coherence_weight', type=float, default=0.1)
+  a('--scaling_from_millimeters', type=float, default=0.1)
+  a('--max_tanimoto_similarity', type=float, default=0.9)
+  a('--max_correspondences', type=int, default=None)
+  a('--max_instances_to_fit', type=int, default=None)
+  a('--max_fitting_iterations', type=int, default=400)
+  a('--vis', type=str2bool, default=False)
+  # epos_lib/common.py:60-154 (the model flags the hot path reads)
+  a('--dataset', default=None)
+  a('--num_frags', type=int, default=64)
+  a('--corr_min_obj_conf', type=float, default=0.1)
+  a('--corr_min_frag_rel_conf', type=float, default=0.5)
+  a('--model_variant', default='xception_65')
+  a('--atrous_rates', default='12,24,36')
+  a('--encoder_output_stride', type=int, default=8)
+  a('--decoder_output_stride', default='4')
+  a('--upsample_logits', type=str2bool, default=False)
+  a('--frag_cls_agnostic', type=str2bool, default=False)
+  a('--frag_loc_agnostic', type=str2bool, default=False)
+  # this build
+  a('--frames', default=None, help='directory with frames.json + images')
+  a('--synthetic', type=int, default=0, help='number of synthetic frames')
+  a('--num_objs', type=int, default=None,
+    help='object channels (default: from the checkpoint)')
+  a('--batch', type=int, default=1, help='images per GPU per step')
+  a('--seed', type=int, default=0)
+  return ap
+
+
+def update_flags(args, params_path):
+  """common.py:157-177: YAML values override flag DEFAULTS."""
+  if not os.path.exists(params_path):
+    return
+  if os.path.basename(params_path).split('.')[1] not in ['yml', 'yaml']:
+    raise ValueError('Only YAML format is currently supported.')
+  import yaml
+  with open(params_path, 'r') as f:
+    params = yaml.safe_load(f) or {}
+  for name, val in params.items():
+    if hasattr(args, name):
+      setattr(args, name, val)
+
+
+def load_fragments(model_dir, num_frags):
+  """fragments.pkl (datagen.py:254-268) or fragments.npz."""
+  pkl = os.path.join(model_dir, 'fragments.pkl')
+  npz = os.path.join(model_dir, 'fragments.npz')
+  if os.path.exists(pkl):
+    with open(pkl, 'rb') as f:
+      fr = pickle.load(f)
+    centers, sizes = fr['frag_centers'], fr['frag_sizes']
+  elif os.path.exists(npz):
+    z = np.load(npz)
+    centers = {int(o): z['frag_centers'][i] for i, o in enumerate(z['obj_ids'])}
+    sizes = {int(o): z['frag_sizes'][i] for i, o in enumerate(z['obj_ids'])}
+  else:
+    return None
+  for o in centers:                                   # datagen.py:264-268
+    if centers[o].shape[0] != num_frags or sizes[o].shape[0] != num_frags:
+      raise ValueError('The loaded fragmentation is not valid.')
+  store = synthetic.ModelStore(0, num_frags)
+  store.dp_model = {'obj_ids': sorted(int(o) for o in centers)}
+  store.frag_centers = {int(o): np.asarray(v, np.float64) for o, v in centers.items()}
+  store.frag_sizes = {int(o): np.asarray(v, np.float64) for o, v in sizes.items()}
+  return store
+
+
+def find_checkpoint(checkpoint_dir, name):
+  if name is not None:
+    path = os.path.join(checkpoint_dir, name)
+    if not path.endswith('.npz'):
+      path += '.npz'
+    return path
+  cands = sorted(glob.glob(os.path.join(checkpoint_dir, '*.npz')),
+                 key=os.path.getmtime)
+  return cands[-1] if cands else None
+
+
+def load_frames(args, num_objs, rank, world):
+  """Returns this rank's list of (scene_id, im_id, image f32[H,W,3], K, targets)."""
+  w, h = [int(x) for x in str(args.infer_crop_size).split(',')][:2] \
+      if not isinstance(args.infer_crop_size, (list, tuple)) \
+      else args.infer_crop_size[:2]
+  frames = []
+  if args.frames:
+    meta = json.load(open(os.path.join(args.frames, 'frames.json')))
+    b, e = edist.shard_range(len(meta), rank, world)
+    for m in meta[b:e]:
+      path = os.path.join(args.frames, m['path'])
+      if path.endswith('.npy'):
+        img = np.load(path)
+      else:
+        from PIL import Image
+        img = np.asarray(Image.open(path).convert('RGB'))
+      img = np.asarray(img, np.float32)[:h, :w]
+      if img.shape[:2] != (h, w):
+        raise ValueError('frame %s is %s, expected %dx%d (resize/crop of '
+                         'datagen.py:424-476 is a "next" item)' % (
+                             path, img.shape, w, h))
+      frames.append((m.get('scene_id', 0), m['im_id'], img,
+                     np.asarray(m['K'], np.float64).reshape(3, 3),
+                     {int(k): int(v) for k, v in m.get('targets', {}).items()}))
+  elif args.synthetic:
+    b, e = edist.shard_range(args.synthetic, rank, world)
+    for i in range(b, e):
+      frames.append((0, i, synthetic.image(i, h, w), synthetic.YCBV_K.copy(),
+                     synthetic.targets(i, num_objs, 5)))
+  else:
+    raise ValueError(
+        'No input files: give --frames <dir> or --synthetic N (TFRecord input, '
+        'datagen.py:707-723, needs TensorFlow and is a "next" item).')
+  return frames, h, w
+
+
+def save_correspondences(infer_dir, infer_name, frame, im_ind, corr, pred_time):
+  """infer.py:294-345 text dump (sorted by confidence)."""
+  scene_id, im_id, _, K, _ = frame
+  suffix = '' if infer_name is None else '_' + infer_name
+  for obj_id, c in corr.items():
+    txt = '# Corr format: u v x y z px_id frag_id conf conf_obj conf_frag\n'
+    txt += 'synthetic\n{} {} {} {}\n'.format(scene_id, im_id, obj_id, pred_time)
+    for i in range(3):
+      txt += '{} {} {}\n'.format(K[i, 0], K[i, 1], K[i, 2])
+    txt += '0\n'
+    order = np.argsort(c['conf'])[::-1]
+    txt += '{}\n'.format(len(order))
+    for i in order:
+      txt += '{} {} {} {} {} {} {} {} {} {}\n'.format(
+          c['coord_2d'][i, 0], c['coord_2d'][i, 1], c['coord_3d'][i, 0],
+          c['coord_3d'][i, 1], c['coord_3d'][i, 2], c['px_id'][i],
+          c['frag_id'][i], c['conf'][i], c['conf_obj'][i], c['conf_frag'][i])
+    path = os.path.join(infer_dir, 'corr' + suffix,
+                        '{:06d}_corr_{:02d}.txt'.format(im_ind, obj_id))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as f:
+      f.write(txt)
+
+
+def main(argv=None):
+  args = build_parser().parse_args(argv)
+  rank, world, local_rank = edist.init_from_env()
+  models_path = os.environ.get('TF_MODELS_PATH', '.')          # config.py:9-16
+  model_dir = os.path.join(models_path, args.model)
+  update_flags(args, os.path.join(model_dir, PARAMS_FILENAME))  # infer.py:561-564
+  if args.cpu_only:
+    raise SystemExit('--cpu_only: this build has no CPU path (MI355X only).')
+  if args.fitting_method != 'progressive_x':
+    raise ValueError('Unknown pose fitting method ({}).'.format(
+        args.fitting_method))                                   # infer.py:530-532
+  if args.vis:
+    raise NotImplementedError('--vis needs the OSMesa renderer (out of scope).')
+  checkpoint_dir = os.path.join(model_dir, 'train')             # infer.py:570
+  infer_dir = os.path.join(model_dir, 'infer')
+  os.makedirs(infer_dir, exist_ok=True)
+  dev = 'cuda:%d' % local_rank
+  torch.cuda.set_device(local_rank)
+
+  ckpt_path = find_checkpoint(checkpoint_dir, args.checkpoint_name)
+  if ckpt_path and os.path.exists(ckpt_path):
+    ckpt = weights.load_npz(ckpt_path)
+    num_objs = ckpt['logits/pred_obj_conf/biases'].shape[0] - 1
+  elif args.synthetic:
+    num_objs = args.num_objs or 21
+    ckpt = weights.random_init(num_objs=num_objs, num_frags=args.num_frags,
+                               seed=0, randomize_bn=True)
+  else:
+    raise ValueError('No checkpoint (.npz) found in {}'.format(checkpoint_dir))
+  store = load_fragments(model_dir, args.num_frags)
+  if store is None:
+    if not args.synthetic:
+      raise ValueError('fragments.pkl / fragments.npz not found in ' + model_dir)
+    store = synthetic.ModelStore(num_objs, args.num_frags, seed=0)
+
+  frames, h, w = load_frames(args, num_objs, rank, world)
+  atrous = [int(x) for x in str(args.atrous_rates).strip('[]').split(',')]
+  mo = model.ModelOptions(
+      model.get_outputs_to_num_channels(num_objs, args.num_frags),
+      crop_size=(w, h), atrous_rates=atrous,
+      encoder_output_stride=args.encoder_output_stride,
+      decoder_output_stride=[int(x) for x in str(
+          args.decoder_output_stride).strip('[]').split(',')],
+      model_variant=args.model_variant)
+  fit = fitting.fit_params(
+      threshold=args.inlier_thresh,
+      neighborhood_ball_radius=args.neighbour_max_dist,
+      spatial_coherence_weight=args.spatial_coherence_weight,
+      scaling_from_millimeters=args.scaling_from_millimeters,
+      max_tanimoto_similarity=args.max_tanimoto_similarity,
+      max_iters=args.max_fitting_iterations,
+      conf=args.required_progx_confidence,
+      proposal_engine_conf=args.required_ransac_confidence,
+      min_coverage=args.min_hypothesis_quality,
+      min_triangle_area=args.min_triangle_area, min_point_number=6,
+      max_model_number_for_optimization=args.max_model_number_for_pearl,
+      use_prosac=args.use_prosac)
+  if args.max_correspondences is not None or args.use_prosac:
+    raise NotImplementedError(
+        'max_correspondences / use_prosac need the confidence sort of '
+        'infer.py:425-440 on device; both default to off.')
+  B = args.batch
+  max_inst = args.max_instances_to_fit or 4
+  pipe = pipeline.EposPipeline(
+      ckpt, B, h, w, num_objs, args.num_frags, store, fit_params=fit,
+      corr_min_obj_conf=args.corr_min_obj_conf,
+      corr_min_frag_rel_conf=args.corr_min_frag_rel_conf,
+      max_instances=max_inst, model_options=mo, device=dev)
+
+  poses_all, time_start = [], time.time()
+  for i0 in range(0, len(frames), B):
+    chunk = frames[i0:i0 + B]
+    while len(chunk) < B:                      # pad the last batch
+      chunk = chunk + [chunk[-1]]
+    imgs = torch.from_numpy(np.stack([f[2] for f in chunk])).to(dev)
+    Ks = np.stack([f[3] for f in chunk])
+    tg = [f[4] for f in chunk]
+    if args.max_instances_to_fit is not None:  # infer.py:467-468
+      tg = [{o: min(c, args.max_instances_to_fit) for o, c in t.items()}
+            for t in tg]
+    poses, rt = pipe.process_batch(
+        imgs, Ks, tg, task_type=args.task_type,
+        image_ids=[f[1] for f in chunk], scene_ids=[f[0] for f in chunk],
+        seed=args.seed, timing=True)
+    n_real = len(frames[i0:i0 + B])
+    real_ids = set((f[0], f[1]) for f in frames[i0:i0 + n_real])
+    seen = set()
+    for p in poses:
+      key = (p['scene_id'], p['im_id'], p['obj_id'], float(p['score']))
+      if (p['scene_id'], p['im_id']) in real_ids and key not in seen:
+        seen.add(key)
+        poses_all.append(p)
+    if args.save_corresp:
+      from epos_amd import corresp as ecorresp
+      pred = pipe.net.forward()
+      for b, f in enumerate(chunk[:n_real]):
+        c = ecorresp.establish_many_to_many(
+            pred['pred_obj_conf'][b], pred['pred_frag_conf'][b],
+            pred['pred_frag_loc'][b], list(f[4]), store, 0.25,
+            args.corr_min_obj_conf, args.corr_min_frag_rel_conf, False,
+            args.task_type == pipeline.LOCALIZATION, device=dev)
+        save_correspondences(infer_dir, args.infer_name, f, i0 + b, c,
+                             rt.get('total', 0.0))
+    if rank == 0:                               # infer.py:730-734
+      print('Image: {}, prediction: {:.3f}, establish_corr: {:.3f}, fitting: '
+            '{:.3f}, total time: {:.3f}'.format(
+                i0, rt.get('prediction', 0), rt.get('establish_corr', 0),
+                rt.get('fitting', 0), rt.get('total', 0)))
+  # First-image time := mean time of the others (infer.py:741-749).
+  if len(poses_all) > 1 and frames:
+    first = (frames[0][0], frames[0][1])
+    rest = [p['time'] for p in poses_all if (p['scene_id'], p['im_id']) != first]
+    if rest:
+      for p in poses_all:
+        if (p['scene_id'], p['im_id']) == first:
+          p['time'] = float(np.mean(rest))
+  merged = edist.gather_poses(poses_all, max_records=max(
+      1, len(frames) * num_objs * max_inst)) if world > 1 else poses_all
+  if rank == 0 and args.save_estimates:
+    suffix = '' if args.infer_name is None else '_' + args.infer_name
+    path = os.path.join(infer_dir, 'estimated-poses{}.csv'.format(suffix))
+    bop_io.save_bop_results(path, merged, version='bop19')
+    print('Saved {} pose estimates to: {}  ({:.2f} s)'.format(
+        len(merged), path, time.time() - time_start))
+  if world > 1:
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -107,6 +107,13 @@ SYMBOLS = {
     'epos_resize_bilinear_f32': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
+    'epos_maxpool3x3_s2_f32': (ctypes.c_int, [
+        vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, vp]),
+    'epos_subsample_f32': (ctypes.c_int, [
+        vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
+    'epos_add_relu_f32': (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, vp]),
     'epos_softmax_groups_f32': (ctypes.c_int,
                                 [vp, ctypes.c_int64, ctypes.c_int, vp]),
     'epos_argmax_i64': (ctypes.c_int, [

@@ -268,6 +268,64 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* X, int64_t ldx
   labels[i] = arg;
 }
 
+// --------------------------------------------------------------------------
+// ResNet-v1-beta helpers (BASELINE config C5): 3x3 stride-2 'SAME' max pool
+// (net_resnet_v1_beta.py:190), spatial subsampling (slim resnet_utils.subsample,
+// the identity shortcut of a strided unit) and the unit's final relu(a + b)
+// where the pre-activation sum is also an end point.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3_s2_kernel(
+    const float* X, int64_t ldx, float* Y, int64_t ldy, int Hi, int Wi, int Ho,
+    int Wo, int c4n, int pad_y, int pad_x, int64_t total) {
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int c = static_cast<int>(id % c4n) * 4;
+  int64_t pix = id / c4n;
+  const int xo = static_cast<int>(pix % Wo);
+  pix /= Wo;
+  const int yo = static_cast<int>(pix % Ho);
+  const int b = static_cast<int>(pix / Ho);
+  const float* xb = X + static_cast<int64_t>(b) * Hi * Wi * ldx + c;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yi = yo * 2 - pad_y + ky;
+    if (yi < 0 || yi >= Hi) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xi = xo * 2 - pad_x + kx;
+      if (xi < 0 || xi >= Wi) continue;
+      const float4 v = ld4(xb + (static_cast<int64_t>(yi) * Wi + xi) * ldx);
+      m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z),
+                      fmaxf(m.w, v.w));
+    }
+  }
+  st4(Y + ((static_cast<int64_t>(b) * Ho + yo) * Wo + xo) * ldy + c, m);
+}
+
+__global__ __launch_bounds__(256) void subsample_kernel(
+    const float* X, int64_t ldx, float* Y, int64_t ldy, int Hi, int Wi, int Ho,
+    int Wo, int c4n, int factor, int64_t total) {
+  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (id >= total) return;
+  const int c = static_cast<int>(id % c4n) * 4;
+  int64_t pix = id / c4n;
+  const int xo = static_cast<int>(pix % Wo);
+  pix /= Wo;
+  const int yo = static_cast<int>(pix % Ho);
+  const int b = static_cast<int>(pix / Ho);
+  st4(Y + ((static_cast<int64_t>(b) * Ho + yo) * Wo + xo) * ldy + c,
+      ld4(X + ((static_cast<int64_t>(b) * Hi + yo * factor) * Wi + xo * factor) * ldx + c));
+}
+
+__global__ __launch_bounds__(256) void add_relu_kernel(const float* A, const float* B,
+                                                       float* Y, int64_t n4) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = ld4(A + 4 * i), b = ld4(B + 4 * i);
+  st4(Y + 4 * i, relu4(make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w)));
+}
+
 inline unsigned blocks_for(int64_t total, int threads) {
   return static_cast<unsigned>(ceil_div(total, threads));
 }
@@ -358,4 +416,47 @@ extern "C" int epos_argmax_i64(const float* X, int64_t ldx, int64_t* labels,
   hipLaunchKernelGGL(argmax_kernel, dim3(blocks_for(P, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), X, ldx, labels, P, C);
   return launch_status("argmax_kernel");
+}
+
+extern "C" int epos_maxpool3x3_s2_f32(const float* X, int64_t ldx, float* Y,
+                                      int64_t ldy, int B, int Hi, int Wi, int C,
+                                      void* stream) {
+  EPOS_REQUIRE(X && Y, "null pointer");
+  EPOS_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "multiples of 4");
+  const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;          // TF 'SAME'
+  const int ty = (Ho - 1) * 2 + 3 - Hi, tx = (Wo - 1) * 2 + 3 - Wi;
+  const int pad_y = ty > 0 ? ty / 2 : 0, pad_x = tx > 0 ? tx / 2 : 0;
+  const int c4n = C / 4;
+  const int64_t total = static_cast<int64_t>(B) * Ho * Wo * c4n;
+  if (total == 0) return EPOS_OK;
+  hipLaunchKernelGGL(maxpool3x3_s2_kernel, dim3(blocks_for(total, 256)), dim3(256),
+                     0, static_cast<hipStream_t>(stream), X, ldx, Y, ldy, Hi, Wi,
+                     Ho, Wo, c4n, pad_y, pad_x, total);
+  return launch_status("maxpool3x3_s2_kernel");
+}
+
+extern "C" int epos_subsample_f32(const float* X, int64_t ldx, float* Y,
+                                  int64_t ldy, int B, int Hi, int Wi, int C,
+                                  int factor, void* stream) {
+  EPOS_REQUIRE(X && Y, "null pointer");
+  EPOS_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && factor >= 1,
+               "multiples of 4");
+  const int Ho = (Hi - 1) / factor + 1, Wo = (Wi - 1) / factor + 1;
+  const int c4n = C / 4;
+  const int64_t total = static_cast<int64_t>(B) * Ho * Wo * c4n;
+  if (total == 0) return EPOS_OK;
+  hipLaunchKernelGGL(subsample_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), X, ldx, Y, ldy, Hi, Wi, Ho,
+                     Wo, c4n, factor, total);
+  return launch_status("subsample_kernel");
+}
+
+extern "C" int epos_add_relu_f32(const float* A, const float* B, float* Y,
+                                 int64_t n, void* stream) {
+  EPOS_REQUIRE(A && B && Y, "null pointer");
+  EPOS_REQUIRE(n % 4 == 0, "n must be a multiple of 4");
+  if (n == 0) return EPOS_OK;
+  hipLaunchKernelGGL(add_relu_kernel, dim3(blocks_for(n / 4, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), A, B, Y, n / 4);
+  return launch_status("add_relu_kernel");
 }

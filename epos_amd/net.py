@@ -27,6 +27,7 @@ from epos_amd import weights as W
 
 XCEPTION_BN_EPS = 1e-3   # feature.py:300-307
 HEAD_BN_EPS = 1e-5       # model.py:194-199, 307-312
+RESNET_BN_EPS = 1e-5     # feature.py:282-287
 
 
 def _ptr(t, offset_elems=0):
@@ -46,8 +47,9 @@ class EposNet(object):
                model_variant='xception_65', encoder_output_stride=8,
                decoder_output_stride=4, atrous_rates=(12, 24, 36),
                multi_grid=None, device='cuda:0'):
-    if model_variant != 'xception_65':
+    if model_variant not in ('xception_65', 'resnet_v1_101_beta'):
       raise ValueError('Unsupported model variant: %s' % model_variant)
+    self.model_variant = model_variant
     if encoder_output_stride != 8 or decoder_output_stride != 4:
       raise ValueError('Only encoder OS 8 / decoder OS 4 (common.py:127-135).')
     if not torch.cuda.is_available():
@@ -172,9 +174,11 @@ class EposNet(object):
     self._add(name, run, 2 * 9 * self.B * ho * wo * c, 'dw')
     return y, ho, wo
 
-  def _stem_conv(self, name, x, hi, wi, cin, scope, stride, preprocess):
+  def _stem_conv(self, name, x, hi, wi, cin, scope, stride, preprocess,
+                 eps=XCEPTION_BN_EPS, rate=1):
     """resnet_utils.conv2d_same 3x3 (+BN+ReLU) = im2col + GEMM
-    (net_xception.py:460-463)."""
+    (net_xception.py:460-463; net_resnet_v1_beta.py:82-83,108-110). stride 1 ->
+    'SAME' (pad = rate); stride 2 -> fixed_padding + VALID (pad = rate)."""
     ho = hi if stride == 1 else (hi - 1) // 2 + 1
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     k = 9 * cin
@@ -183,19 +187,145 @@ class EposNet(object):
     col = self._empty(m, ldcol)
     args = _lib.Im2colArgs(
         X=_ptr(x), ldx=cin, col=_ptr(col), ldcol=ldcol, B=self.B, Hi=hi, Wi=wi,
-        Ho=ho, Wo=wo, C=cin, stride=stride, rate=1, pad=1,
+        Ho=ho, Wo=wo, C=cin, stride=stride, rate=rate, pad=rate,
         preprocess=int(preprocess))
     lib = self.lib
 
     def run(stream, args=args):
       _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(args), stream), name)
     self._add(name + '/im2col', run, 0, 'im2col')
-    w_kn, scale, bias = self._conv_params(scope, XCEPTION_BN_EPS)
+    w_kn, scale, bias = self._conv_params(scope, eps)
     cout = w_kn.shape[1]
     y = self._empty(self.B, ho, wo, cout)
     self._pointwise(name, col, 0, ldcol, m, k, w_kn, scale, bias, y, 0, cout,
                     relu=True)
     return y, ho, wo, cout
+
+  # ------------------------------------------------ ResNet-v1-101-beta (C5) ---
+  def _simple(self, name, fn):
+    self._add(name, fn)
+
+  def _bottleneck(self, scope, x, hi, wi, cin, depth, db, stride, rate,
+                  keep_conv3=False):
+    """net_resnet_v1_beta.py:38-93: 1x1 -> 3x3 (conv2d_same, rate) -> 1x1, plus
+    shortcut, ReLU after the add. The add + ReLU is the epilogue of the conv3 GEMM
+    unless conv3 itself is an end point (decoder tap, feature.py:50-54)."""
+    eps = RESNET_BN_EPS
+    B, lib = self.B, self.lib
+    ho = hi if stride == 1 else (hi - 1) // 2 + 1
+    wo = wi if stride == 1 else (wi - 1) // 2 + 1
+    m_in, m_out = B * hi * wi, B * ho * wo
+    if depth == cin:
+      if stride == 1:
+        shortcut = x
+      else:                                    # resnet_utils.subsample (:71-72)
+        shortcut = self._empty(B, ho, wo, depth)
+
+        def run_sub(stream, x=x, y=shortcut):
+          _lib.check(lib.epos_subsample_f32(_ptr(x), cin, _ptr(y), depth, B, hi,
+                                            wi, cin, stride, stream), 'subsample')
+        self._add(scope + '/shortcut_subsample', run_sub)
+    else:
+      w_kn, sc, bi = self._conv_params(scope + '/shortcut', eps)
+      shortcut = self._empty(B, ho, wo, depth)
+      self._pointwise(scope + '/shortcut', x, 0, cin, m_out, cin, w_kn, sc, bi,
+                      shortcut, 0, depth, relu=False, sub=stride, ho=ho, wo=wo,
+                      hi=hi, wi=wi)
+    w_kn, sc, bi = self._conv_params(scope + '/conv1', eps)
+    r1 = self._empty(B, hi, wi, db)
+    self._pointwise(scope + '/conv1', x, 0, cin, m_in, cin, w_kn, sc, bi, r1, 0,
+                    db, relu=True)
+    r2, _, _, _ = self._stem_conv(scope + '/conv2', r1, hi, wi, db,
+                                  scope + '/conv2', stride, False, eps=eps,
+                                  rate=rate)
+    w_kn, sc, bi = self._conv_params(scope + '/conv3', eps)
+    out = self._empty(B, ho, wo, depth)
+    conv3 = None
+    if keep_conv3:
+      conv3 = self._empty(B, ho, wo, depth)
+      self._pointwise(scope + '/conv3', r2, 0, db, m_out, db, w_kn, sc, bi, conv3,
+                      0, depth, relu=False)
+
+      def run_add(stream, a=conv3, b=shortcut, y=out):
+        _lib.check(lib.epos_add_relu_f32(_ptr(a), _ptr(b), _ptr(y),
+                                         m_out * depth, stream), 'add_relu')
+      self._add(scope + '/add_relu', run_add)
+    else:
+      self._pointwise(scope + '/conv3', r2, 0, db, m_out, db, w_kn, sc, bi, out,
+                      0, depth, relu=True, res=shortcut, ldr=depth)
+    return out, ho, wo, depth, conv3
+
+  def _backbone_resnet(self):
+    """resnet_v1_101_beta (net_resnet_v1_beta.py:445-516) at output_stride 8."""
+    B, H, Wd, lib = self.B, self.H, self.W, self.lib
+    net = 'resnet_v1_101'
+    x, h, w, c = self.images, H, Wd, 3
+    for i, stride in enumerate([2, 1, 1], 1):                # :108-110
+      x, h, w, c = self._stem_conv('%s/conv1_%d' % (net, i), x, h, w, c,
+                                   '%s/conv1_%d' % (net, i), stride, i == 1,
+                                   eps=RESNET_BN_EPS)
+    ph, pw = (h + 1) // 2, (w + 1) // 2
+    pooled = self._empty(B, ph, pw, c)
+
+    def run_pool(stream, x=x, y=pooled, h=h, w=w, c=c):
+      _lib.check(lib.epos_maxpool3x3_s2_f32(_ptr(x), c, _ptr(y), c, B, h, w, c,
+                                            stream), 'maxpool')
+    self._add(net + '/pool1', run_pool)                      # :190
+    x, h, w = pooled, ph, pw
+    target, current_stride, rate = 2, 1, 1                   # 8 / 4 (:185-188)
+    low_level = None
+    mg = self.multi_grid
+    for bscope, base, units in W.RESNET101_BLOCKS:
+      for u in range(units):
+        scope = '%s/%s/unit_%d/bottleneck_v1' % (net, bscope, u + 1)
+        stride = 2 if (u == units - 1 and bscope != 'block4') else 1
+        unit_rate = mg[u] if bscope == 'block4' else 1
+        keep = bscope == 'block1' and u == 1
+        if current_stride == target:
+          x, h, w, c, conv3 = self._bottleneck(scope, x, h, w, c, base * 4, base,
+                                               1, rate * unit_rate, keep)
+          rate *= stride
+        else:
+          x, h, w, c, conv3 = self._bottleneck(scope, x, h, w, c, base * 4, base,
+                                               stride, unit_rate, keep)
+          current_stride *= stride
+        if keep:
+          low_level = (conv3, h, w, base * 4)
+    return x, h, w, c, low_level
+
+  def _backbone_xception(self):
+    B, H, Wd = self.B, self.H, self.W
+    net = 'xception_65'
+    x, h, w, c = self._stem_conv(net + '/entry_flow/conv1_1', self.images, H, Wd,
+                                 3, net + '/entry_flow/conv1_1', 2, True)
+    x, h, w, c = self._stem_conv(net + '/entry_flow/conv1_2', x, h, w, c,
+                                 net + '/entry_flow/conv1_2', 1, False)
+    # stack_blocks_dense (net_xception.py:326-393) with output_stride 8/2 = 4.
+    target, current_stride, rate = 4, 1, 1
+    low_level = None
+    blocks = [
+        ('entry_flow/block1', [128, 128, 128], 'conv', False, 1, 2, [1, 1, 1]),
+        ('entry_flow/block2', [256, 256, 256], 'conv', False, 1, 2, [1, 1, 1]),
+        ('entry_flow/block3', [728, 728, 728], 'conv', False, 1, 2, [1, 1, 1]),
+        ('middle_flow/block1', [728, 728, 728], 'sum', False, 16, 1, [1, 1, 1]),
+        ('exit_flow/block1', [728, 1024, 1024], 'conv', False, 1, 2, [1, 1, 1]),
+        ('exit_flow/block2', [1536, 1536, 2048], 'none', True, 1, 1,
+         self.multi_grid),
+    ]
+    for bscope, depths, skip, act, units, stride, url in blocks:
+      for u in range(units):
+        scope = '%s/%s/unit_%d/xception_module' % (net, bscope, u + 1)
+        if current_stride == target:
+          x, h, w, c, taps = self._xception_module(
+              scope, x, h, w, c, depths, skip, act, 1, rate, url)
+          rate *= stride
+        else:
+          x, h, w, c, taps = self._xception_module(
+              scope, x, h, w, c, depths, skip, act, stride, 1, url)
+          current_stride *= stride
+        if bscope == 'entry_flow/block2':
+          low_level = (taps[1], taps[1].shape[1], taps[1].shape[2], depths[1])
+    return x, h, w, c, low_level
 
   def _xception_module(self, scope, x, hi, wi, cin, depths, skip, act_in_sep,
                        stride, rate, unit_rates):
@@ -240,37 +370,11 @@ class EposNet(object):
   # -------------------------------------------------------------- plan ---
   def _build_plan(self):
     B, H, Wd = self.B, self.H, self.W
-    net = 'xception_65'
     self.images = self._empty(B, H, Wd, 3)
-    x, h, w, c = self._stem_conv(net + '/entry_flow/conv1_1', self.images, H, Wd,
-                                 3, net + '/entry_flow/conv1_1', 2, True)
-    x, h, w, c = self._stem_conv(net + '/entry_flow/conv1_2', x, h, w, c,
-                                 net + '/entry_flow/conv1_2', 1, False)
-    # stack_blocks_dense (net_xception.py:326-393) with output_stride 8/2 = 4.
-    target, current_stride, rate = 4, 1, 1
-    low_level = None
-    blocks = [
-        ('entry_flow/block1', [128, 128, 128], 'conv', False, 1, 2, [1, 1, 1]),
-        ('entry_flow/block2', [256, 256, 256], 'conv', False, 1, 2, [1, 1, 1]),
-        ('entry_flow/block3', [728, 728, 728], 'conv', False, 1, 2, [1, 1, 1]),
-        ('middle_flow/block1', [728, 728, 728], 'sum', False, 16, 1, [1, 1, 1]),
-        ('exit_flow/block1', [728, 1024, 1024], 'conv', False, 1, 2, [1, 1, 1]),
-        ('exit_flow/block2', [1536, 1536, 2048], 'none', True, 1, 1,
-         self.multi_grid),
-    ]
-    for bscope, depths, skip, act, units, stride, url in blocks:
-      for u in range(units):
-        scope = '%s/%s/unit_%d/xception_module' % (net, bscope, u + 1)
-        if current_stride == target:
-          x, h, w, c, taps = self._xception_module(
-              scope, x, h, w, c, depths, skip, act, 1, rate, url)
-          rate *= stride
-        else:
-          x, h, w, c, taps = self._xception_module(
-              scope, x, h, w, c, depths, skip, act, stride, 1, url)
-          current_stride *= stride
-        if bscope == 'entry_flow/block2':
-          low_level = (taps[1], taps[1].shape[1], taps[1].shape[2], depths[1])
+    if self.model_variant == 'xception_65':
+      x, h, w, c, low_level = self._backbone_xception()
+    else:
+      x, h, w, c, low_level = self._backbone_resnet()
     self.encoder = x
     eh, ew, ec = h, w, c
     lib = self.lib

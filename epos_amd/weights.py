@@ -22,6 +22,10 @@ XCEPTION_BLOCKS = [  # net_xception.py:604-648: (scope, depths, skip, units)
     ('exit_flow/block2', [1536, 1536, 2048], 'none', 1),
 ]
 
+RESNET101_BLOCKS = [  # net_resnet_v1_beta.py:494-505: (scope, base depth, units)
+    ('block1', 64, 3), ('block2', 128, 4), ('block3', 256, 23), ('block4', 512, 3),
+]
+
 PRED_OBJ_CONF = 'pred_obj_conf'    # common.py:24-27
 PRED_OBJ_LABEL = 'pred_obj_label'
 PRED_FRAG_CONF = 'pred_frag_conf'
@@ -48,26 +52,44 @@ def variable_specs(model_variant='xception_65', num_objs=21, num_frags=64,
         'xavier' (slim default for plain slim.conv2d in model.py),
         'logits' (trunc-normal 0.01, model.py:437).
   """
-  if model_variant != 'xception_65':
-    raise ValueError('Unsupported model variant: %s' % model_variant)
-  net = 'xception_65'
   specs = []
-  specs.append(('conv', net + '/entry_flow/conv1_1', (3, 3, 3, 32), 'backbone'))
-  specs.append(('conv', net + '/entry_flow/conv1_2', (3, 3, 32, 64), 'backbone'))
-  cin = 64
-  for bscope, depths, skip, units in XCEPTION_BLOCKS:
-    for u in range(units):
-      scope = '%s/%s/unit_%d/xception_module' % (net, bscope, u + 1)
-      c = cin
-      for i, d in enumerate(depths):
-        sc = '%s/separable_conv%d' % (scope, i + 1)
-        specs.append(('dw', sc + '_depthwise', (3, 3, c, 1), 'backbone'))
-        specs.append(('conv', sc + '_pointwise', (1, 1, c, d), 'backbone'))
-        c = d
-      if skip == 'conv':
-        specs.append(('conv', scope + '/shortcut', (1, 1, cin, depths[-1]),
-                      'backbone'))
-      cin = depths[-1]
+  if model_variant == 'xception_65':
+    net = 'xception_65'
+    specs.append(('conv', net + '/entry_flow/conv1_1', (3, 3, 3, 32), 'backbone'))
+    specs.append(('conv', net + '/entry_flow/conv1_2', (3, 3, 32, 64), 'backbone'))
+    cin = 64
+    for bscope, depths, skip, units in XCEPTION_BLOCKS:
+      for u in range(units):
+        scope = '%s/%s/unit_%d/xception_module' % (net, bscope, u + 1)
+        c = cin
+        for i, d in enumerate(depths):
+          sc = '%s/separable_conv%d' % (scope, i + 1)
+          specs.append(('dw', sc + '_depthwise', (3, 3, c, 1), 'backbone'))
+          specs.append(('conv', sc + '_pointwise', (1, 1, c, d), 'backbone'))
+          c = d
+        if skip == 'conv':
+          specs.append(('conv', scope + '/shortcut', (1, 1, cin, depths[-1]),
+                        'backbone'))
+        cin = depths[-1]
+  elif model_variant == 'resnet_v1_101_beta':
+    # net_resnet_v1_beta.py:96-112 (root), :38-93 (bottleneck), :494-505 (blocks);
+    # variable scope 'resnet_v1_101' (net_resnet_v1_beta.py:452).
+    net = 'resnet_v1_101'
+    cin = 3
+    for i, cout in enumerate([64, 64, 128], 1):
+      specs.append(('conv', '%s/conv1_%d' % (net, i), (3, 3, cin, cout), 'he'))
+      cin = cout
+    for bscope, base, units in RESNET101_BLOCKS:
+      for u in range(units):
+        scope = '%s/%s/unit_%d/bottleneck_v1' % (net, bscope, u + 1)
+        if cin != base * 4:
+          specs.append(('conv', scope + '/shortcut', (1, 1, cin, base * 4), 'he'))
+        specs.append(('conv', scope + '/conv1', (1, 1, cin, base), 'he'))
+        specs.append(('conv', scope + '/conv2', (3, 3, base, base), 'he'))
+        specs.append(('conv', scope + '/conv3', (1, 1, base, base * 4), 'he'))
+        cin = base * 4
+  else:
+    raise ValueError('Unsupported model variant: %s' % model_variant)
   specs.append(('conv', 'image_pooling', (1, 1, cin, 256), 'xavier'))
   specs.append(('conv', 'aspp0', (1, 1, cin, 256), 'xavier'))
   for i, _ in enumerate(atrous_rates, 1):
@@ -114,7 +136,10 @@ def random_init(model_variant='xception_65', num_objs=21, num_frags=64, seed=0,
   w = {}
   for kind, scope, shape, init in variable_specs(
       model_variant, num_objs, num_frags, atrous_rates):
-    if init == 'xavier':
+    if init == 'he':      # slim variance_scaling_initializer (resnet_arg_scope)
+      fan_in = shape[0] * shape[1] * shape[2]
+      arr = _trunc_normal(rng, shape, np.sqrt(2.0 / fan_in) / 0.8796)
+    elif init == 'xavier':
       fan_in = shape[0] * shape[1] * shape[2]
       fan_out = shape[0] * shape[1] * shape[3]
       lim = np.sqrt(6.0 / (fan_in + fan_out))
@@ -132,7 +157,11 @@ def random_init(model_variant='xception_65', num_objs=21, num_frags=64, seed=0,
       continue
     c = shape[2] if kind == 'dw' else shape[3]
     if randomize_bn:
-      w[scope + '/BatchNorm/gamma'] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+      # The last BN of a ResNet bottleneck gets a small gamma so that 33 stacked
+      # residual units keep activations O(1) at random init.
+      g_scale = 0.25 if scope.endswith('bottleneck_v1/conv3') else 1.0
+      w[scope + '/BatchNorm/gamma'] = (
+          rng.uniform(0.5, 1.5, c) * g_scale).astype(np.float32)
       w[scope + '/BatchNorm/beta'] = (
           rng.standard_normal(c) * 0.1).astype(np.float32)
       w[scope + '/BatchNorm/moving_mean'] = (

@@ -122,6 +122,20 @@ int epos_resize_bilinear_f32(const float* X, int64_t ldx, float* Y, int64_t ldy,
                              int B, int Hi, int Wi, int Ho, int Wo, int C,
                              void* stream);
 
+/* ResNet-v1-beta backbone helpers (BASELINE config C5). max pool 3x3 stride 2,
+ * TF 'SAME' (slim.max_pool2d at net_resnet_v1_beta.py:190): X [B,Hi,Wi,C] ->
+ * Y [B,ceil(Hi/2),ceil(Wi/2),C]. */
+int epos_maxpool3x3_s2_f32(const float* X, int64_t ldx, float* Y, int64_t ldy,
+                           int B, int Hi, int Wi, int C, void* stream);
+/* slim resnet_utils.subsample (external/slim/nets/resnet_utils.py:59-74): keeps
+ * every factor-th pixel, Y [B,(Hi-1)/f+1,(Wi-1)/f+1,C]. */
+int epos_subsample_f32(const float* X, int64_t ldx, float* Y, int64_t ldy, int B,
+                       int Hi, int Wi, int C, int factor, void* stream);
+/* Y = relu(A + B) over n contiguous floats (net_resnet_v1_beta.py:86 when the
+ * pre-sum conv3 output is itself an end point, feature.py:50-54). */
+int epos_add_relu_f32(const float* A, const float* B, float* Y, int64_t n,
+                      void* stream);
+
 /* In-place softmax over groups of `G` consecutive floats (model.py:677-678):
  * X holds n_groups * G floats, group g at X + g*G (G <= 64). */
 int epos_softmax_groups_f32(float* X, int64_t n_groups, int G, void* stream);

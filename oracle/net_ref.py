@@ -220,6 +220,94 @@ def xception_65(x, wts, output_stride, multi_grid=None, net='xception_65',
 
 
 # ----------------------------------------------------------------------------
+# ResNet-v1-101 beta variant (net_resnet_v1_beta.py) -- BASELINE config C5.
+# ----------------------------------------------------------------------------
+RESNET_BN_EPS = 1e-5     # feature.py:282-287
+
+
+def max_pool_3x3_s2_same(x):
+  """slim.max_pool2d(net, 3, stride=2, padding='SAME') (net_resnet_v1_beta.py:190):
+  TF SAME padding, padded cells never win (-inf)."""
+  pads = []
+  for size in (x.shape[3], x.shape[2]):
+    out = -(-size // 2)
+    total = max((out - 1) * 2 + 3 - size, 0)
+    pads += [total // 2, total - total // 2]
+  x = F.pad(x, tuple(pads), value=float('-inf'))
+  return F.max_pool2d(x, 3, stride=2)
+
+
+def _resnet_conv(x, wts, scope, k, stride, rate, relu, eps=RESNET_BN_EPS):
+  """slim.conv2d / resnet_utils.conv2d_same under the resnet arg scope
+  (conv + BN [+ ReLU])."""
+  w = wts[scope + '/weights']
+  if k == 1:
+    y = conv2d_raw(x, w, stride, 1, 'SAME')
+  else:
+    y = conv2d_same_raw(x, w, stride, rate)
+  y = batch_norm(y, wts, scope, eps)
+  return F.relu(y) if relu else y
+
+
+def bottleneck(x, wts, scope, depth, depth_bottleneck, stride, rate, end_points):
+  """net_resnet_v1_beta.py:38-93."""
+  depth_in = x.shape[1]
+  if depth == depth_in:
+    shortcut = subsample(x, stride)                                  # :71-72
+  else:
+    shortcut = _resnet_conv(x, wts, scope + '/shortcut', 1, stride, 1, False)
+  r = _resnet_conv(x, wts, scope + '/conv1', 1, 1, 1, True)           # :80-81
+  r = _resnet_conv(r, wts, scope + '/conv2', 3, stride, rate, True)   # :82-83
+  r = _resnet_conv(r, wts, scope + '/conv3', 1, 1, 1, False)          # :84-85
+  end_points[scope + '/conv3'] = r
+  out = F.relu(shortcut + r)                                          # :86
+  end_points[scope] = out
+  return out
+
+
+def resnet_v1_101_beta_blocks(multi_grid=None):
+  """net_resnet_v1_beta.py:494-505: (scope, [(depth, bottleneck, stride, unit_rate)])."""
+  mg = list(multi_grid) if multi_grid else [1, 1, 1]
+
+  def block(scope, base, units, stride):
+    return (scope, [(base * 4, base, 1, 1)] * (units - 1) +
+            [(base * 4, base, stride, 1)])
+  return [block('block1', 64, 3, 2), block('block2', 128, 4, 2),
+          block('block3', 256, 23, 2),
+          ('block4', [(2048, 512, 1, r) for r in mg])]
+
+
+def resnet_v1_101_beta(x, wts, output_stride, multi_grid=None,
+                       net='resnet_v1_101', blocks=None):
+  """net_resnet_v1_beta.py:115-204 + slim stack_blocks_dense
+  (external/slim/nets/resnet_utils.py:125-219)."""
+  end_points = {}
+  if output_stride is not None:
+    assert output_stride % 4 == 0
+    output_stride //= 4                                               # :185-188
+  for i, (cout, stride) in enumerate([(64, 2), (64, 1), (128, 1)], 1):   # :108-110
+    x = _resnet_conv(x, wts, '%s/conv1_%d' % (net, i), 3, stride, 1, True)
+    end_points['%s/conv1_%d' % (net, i)] = x
+  x = max_pool_3x3_s2_same(x)                                         # :190
+  end_points[net + '/pool1'] = x
+  current_stride, rate = 1, 1
+  for bscope, units in (blocks or resnet_v1_101_beta_blocks(multi_grid)):
+    for u, (depth, db, stride, unit_rate) in enumerate(units):
+      scope = '%s/%s/unit_%d/bottleneck_v1' % (net, bscope, u + 1)
+      if output_stride is not None and current_stride == output_stride:
+        x = bottleneck(x, wts, scope, depth, db, 1, rate * unit_rate, end_points)
+        rate *= stride
+      else:
+        x = bottleneck(x, wts, scope, depth, db, stride, unit_rate, end_points)
+        current_stride *= stride
+        if output_stride is not None and current_stride > output_stride:
+          raise ValueError('The target output_stride cannot be reached.')
+  if output_stride is not None and current_stride != output_stride:
+    raise ValueError('The target output_stride cannot be reached.')
+  return x, end_points
+
+
+# ----------------------------------------------------------------------------
 # DeepLabv3+ meta-architecture (model.py).
 # ----------------------------------------------------------------------------
 def split_separable_conv2d(x, wts, scope, rate, eps):
@@ -275,10 +363,12 @@ def decoder(features, low_level, wts, im_size_wh, decoder_output_stride,
   return x
 
 
-DECODER_TAP = {  # feature.py:61-66
+DECODER_TAP = {  # feature.py:50-66
     'xception_65':
         'xception_65/entry_flow/block2/unit_1/xception_module/'
         'separable_conv2_pointwise',
+    'resnet_v1_101_beta':
+        'resnet_v1_101/block1/unit_2/bottleneck_v1/conv3',
 }
 
 
@@ -286,14 +376,18 @@ def logits(images, wts, num_objs, num_frags, model_variant='xception_65',
            encoder_output_stride=8, decoder_output_stride=(4,),
            atrous_rates=(12, 24, 36), multi_grid=None, crop_size_wh=None):
   """model.py:461-514 (get_logits). images: float [B,H,W,3] in [0,255] (NHWC)."""
-  if model_variant != 'xception_65':
-    raise ValueError('oracle covers xception_65 only (round 1).')
+  if model_variant not in DECODER_TAP:
+    raise ValueError('oracle covers xception_65 and resnet_v1_101_beta.')
   x = torch.as_tensor(np.asarray(images), dtype=torch.float32)
   x = x.permute(0, 3, 1, 2).contiguous()
   if crop_size_wh is None:
     crop_size_wh = (x.shape[3], x.shape[2])
   x = (2.0 / 255.0) * x - 1.0                                # feature.py:171-174
-  feats, end_points = xception_65(x, wts, encoder_output_stride, multi_grid)
+  if model_variant == 'xception_65':
+    feats, end_points = xception_65(x, wts, encoder_output_stride, multi_grid)
+  else:
+    feats, end_points = resnet_v1_101_beta(x, wts, encoder_output_stride,
+                                           multi_grid)
   end_points['encoder'] = feats
   feats = aspp(feats, wts, atrous_rates, end_points)
   feats = decoder(feats, end_points[DECODER_TAP[model_variant]], wts,

@@ -62,3 +62,55 @@ def test_predict_operator_api():
   assert tuple(out['pred_frag_loc'].shape) == (1, 16, 16, 1, 64, 3)
   with pytest.raises(NotImplementedError):
     model.predict(img, mo, ckpt, upsample_logits=True, num_objs=1, num_frags=64)
+
+
+def test_resnet_v1_101_beta_matches_oracle():
+  """BASELINE config C5 backbone (net_resnet_v1_beta.py) at a reduced size."""
+  from epos_amd import model, weights
+  from oracle import net_ref
+  num_objs, h, w = 2, 96, 128
+  ckpt = weights.random_init('resnet_v1_101_beta', num_objs=num_objs, seed=4,
+                             randomize_bn=True, logits_std=0.2)
+  img = np.random.RandomState(2).randint(0, 256, (1, h, w, 3)).astype('f')
+  ref = net_ref.predict(img, ckpt, num_objs=num_objs, num_frags=64,
+                        model_variant='resnet_v1_101_beta')
+  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64),
+                          model_variant='resnet_v1_101_beta')
+  net = model.get_net(ckpt, 1, h, w, num_objs, 64, mo)
+  out = net.forward(torch.from_numpy(img).cuda())
+  torch.cuda.synchronize()
+  enc = ref['_end_points']['encoder'].permute(0, 2, 3, 1).numpy()
+  scale = float(np.abs(enc).max())
+  np.testing.assert_allclose(net.encoder.cpu().numpy(), enc, rtol=2e-4,
+                             atol=2e-4 * max(scale, 1.0))
+  for k in ['pred_obj_conf', 'pred_frag_conf', 'pred_frag_loc']:
+    np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=3e-4, atol=3e-4,
+                               err_msg=k)
+
+
+def test_maxpool_subsample_add_relu():
+  import ctypes
+  from epos_amd import _lib
+  from oracle import net_ref
+  lib = _lib.load()
+  rng = np.random.RandomState(0)
+
+  def p(t):
+    return ctypes.c_void_p(t.data_ptr())
+  for (hi, wi) in [(12, 16), (11, 15)]:
+    x = rng.standard_normal((2, hi, wi, 8)).astype('f')
+    X = torch.from_numpy(x).cuda()
+    ref = net_ref.max_pool_3x3_s2_same(torch.from_numpy(x).permute(0, 3, 1, 2))
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    Y = torch.zeros(ref.shape, device='cuda')
+    _lib.check(lib.epos_maxpool3x3_s2_f32(p(X), 8, p(Y), 8, 2, hi, wi, 8, None))
+    assert np.array_equal(Y.cpu().numpy(), ref)
+    sub = x[:, ::2, ::2]
+    Z = torch.zeros(sub.shape, device='cuda')
+    _lib.check(lib.epos_subsample_f32(p(X), 8, p(Z), 8, 2, hi, wi, 8, 2, None))
+    assert np.array_equal(Z.cpu().numpy(), sub)
+  a = rng.standard_normal(1024).astype('f'); b = rng.standard_normal(1024).astype('f')
+  A, Bt = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+  Yt = torch.zeros(1024, device='cuda')
+  _lib.check(lib.epos_add_relu_f32(p(A), p(Bt), p(Yt), 1024, None))
+  assert np.array_equal(Yt.cpu().numpy(), np.maximum(a + b, 0))

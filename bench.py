@@ -53,6 +53,10 @@ def parse_args():
                   help='keep the raw random-init logits layers (every confidence '
                        'then stays below tau_a and corr/RANSAC get no work)')
   ap.add_argument('--no-graph', action='store_true')
+  ap.add_argument('--pipeline-depth', type=int, default=3,
+                  help='batches in flight per GPU: with >= 2, the fitting tail of '
+                       'step i overlaps the network of step i+1 (two independent '
+                       'plans on two HIP streams); 1 = strictly serial steps')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-roofline', action='store_true')
   ap.add_argument('--cpu-baseline-images', type=int, default=1)
@@ -176,10 +180,12 @@ def main():
     synthetic.calibrate_logits(ckpt, net0.decoder_out[0].cpu().numpy())
     model._NETS.clear()
     del net0
-  pipe = pipeline.EposPipeline(
+  depth = max(1, args.pipeline_depth)
+  pipes = [pipeline.EposPipeline(
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
       capacity=1 << 21, max_instances=1, device=dev,
-      use_graph=not args.no_graph)
+      use_graph=not args.no_graph, instance=j) for j in range(depth)]
+  pipe = pipes[0]
   # Synthetic frames, resident in HBM before the timed region.
   n_pool = 4
   pool = []
@@ -191,25 +197,37 @@ def main():
   Ks = np.tile(synthetic.YCBV_K, (B, 1, 1))
   max_records = B * args.objs_per_image * 2
 
-  def step(i):
-    imgs, tg, idx = pool[i % n_pool]
-    poses, _ = pipe.process_batch(imgs, Ks, tg, image_ids=idx, seed=i)
-    return edist.gather_poses(poses, max_records)
+  def finish(p):
+    poses, _ = p.collect()
+    return len(edist.gather_poses(poses, max_records))
 
-  n_poses = 0
-  for i in range(args.warmup):
-    step(i)
+  def run(first, count):
+    """`count` steps; step i is launched on pipes[i % depth] after the step that
+    used that pipeline `depth` steps earlier has been collected. Returns the
+    number of poses; every step is complete (poses on the host) on return."""
+    n, inflight = 0, []
+    for i in range(first, first + count):
+      p = pipes[i % depth]
+      if len(inflight) == depth:
+        n += finish(inflight.pop(0))
+      imgs, tg, idx = pool[i % n_pool]
+      p.launch(imgs, Ks, tg, image_ids=idx, seed=i)
+      inflight.append(p)
+    while inflight:
+      n += finish(inflight.pop(0))
+    return n
+
+  run(0, args.warmup)
   torch.cuda.synchronize()
   edist.barrier()
   t0 = time.perf_counter()
-  for i in range(args.steps):
-    n_poses += len(step(args.warmup + i))
+  n_poses = run(args.warmup, args.steps)
   torch.cuda.synchronize()
   edist.barrier()
   elapsed = edist.max_over_ranks(time.perf_counter() - t0)
 
   # correspondence statistics of the last step (work actually done by corr/RANSAC)
-  totals = pipe.corr.totals[:pipe.corr.S].cpu().numpy()
+  totals = pipes[(args.warmup + args.steps - 1) % depth].last_totals
   images = args.steps * B * world
   value = images / elapsed
   result = {
@@ -232,7 +250,7 @@ def main():
           'batch_per_gpu': B, 'global_batch': B * world,
           'parallelism': 'dp%d (images sharded, one all_gather of pose records)'
                          % world,
-          'hip_graph': not args.no_graph,
+          'hip_graph': not args.no_graph, 'pipeline_depth': depth,
           'corr_per_slot_last_step': [int(x) for x in totals[:, 1]],
           'poses_per_step': round(n_poses / max(args.steps, 1), 2),
           'algorithmic_gflop_per_image': round(pipe.net.flops / B / 1e9, 1),

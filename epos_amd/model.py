@@ -45,13 +45,16 @@ _NETS = {}
 
 
 def get_net(checkpoint, batch, height, width, num_objs, num_frags,
-            model_options=None, device='cuda:0'):
-  """Returns (and caches) the HIP plan for this checkpoint and input shape."""
+            model_options=None, device='cuda:0', instance=0):
+  """Returns (and caches) the HIP plan for this checkpoint and input shape.
+  ``instance`` distinguishes independent plans (own activation buffers) of the
+  same network, e.g. the two halves of a double-buffered pipeline."""
   mo = model_options or ModelOptions(
       get_outputs_to_num_channels(num_objs, num_frags))
   key = (id(checkpoint), batch, height, width, num_objs, num_frags,
          mo.model_variant, mo.atrous_rates, mo.encoder_output_stride,
-         mo.decoder_output_stride, tuple(mo.multi_grid or ()), str(device))
+         mo.decoder_output_stride, tuple(mo.multi_grid or ()), str(device),
+         instance)
   if key not in _NETS:
     if len(mo.decoder_output_stride) != 1:
       raise ValueError('one decoder stage only (common.py:127-132).')

@@ -490,6 +490,9 @@ class EposNet(object):
   def _stream(self):
     return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
+  def sync_current(self):
+    torch.cuda.current_stream(self.dev).synchronize()
+
   def run_plan(self, with_post=True):
     s = self._stream()
     for _, fn in self.ops:

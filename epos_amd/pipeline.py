@@ -37,13 +37,13 @@ class EposPipeline(object):
                model_store, fit_params=None, corr_min_obj_conf=0.1,
                corr_min_frag_rel_conf=0.5, max_slots=None, capacity=1 << 20,
                max_instances=4, model_options=None, device='cuda:0',
-               use_graph=True):
+               use_graph=True, instance=0):
     self.lib = _lib.load()
     self.dev = torch.device(device)
     self.B, self.H, self.W = batch, height, width
     self.O, self.F = num_objs, num_frags
     self.net = _model.get_net(checkpoint, batch, height, width, num_objs,
-                              num_frags, model_options, device)
+                              num_frags, model_options, device, instance)
     self.use_graph = use_graph
     self.output_scale = 1.0 / 4            # decoder output stride 4 (infer.py:586-591)
     self.tau_a, self.tau_b = corr_min_obj_conf, corr_min_frag_rel_conf
@@ -62,15 +62,59 @@ class EposPipeline(object):
     if wbytes < 0:
       raise _lib.EposError('epos_fit_workspace_bytes failed')
     self.work = torch.empty(wbytes, dtype=torch.uint8, device=d)
-    self.Ks = torch.zeros(S, 9, dtype=torch.float64, device=d)
-    self.max_models = torch.zeros(S, dtype=torch.int32, device=d)
-    self.seeds = torch.zeros(S, dtype=torch.int64, device=d)
-    self.poses = torch.zeros(S, self.max_k, 12, dtype=torch.float64, device=d)
-    self.scores = torch.zeros(S, self.max_k, dtype=torch.float64, device=d)
-    self.num_models = torch.zeros(S, dtype=torch.int32, device=d)
     self.labels = torch.empty(max(capacity, 1), dtype=torch.int32, device=d)
-    # pinned host mirror for the single D2H copy of the results
+    # Per-step metadata goes up in ONE host->device copy and the results come
+    # back in ONE device->host copy (pinned memory on the host side): typed views
+    # of two byte buffers.
+    K = self.max_k
+    self._meta_layout = self._layout([('Ks', 'f8', S * 9), ('seeds', 'i8', S),
+                                      ('slots', 'i4', S * 2),
+                                      ('max_models', 'i4', S)])
+    self._res_layout = self._layout([('poses', 'f8', S * K * 12),
+                                     ('scores', 'f8', S * K),
+                                     ('num_models', 'i4', S),
+                                     ('totals', 'i4', S * 2),
+                                     ('overflow', 'i4', 1)])
+    self.meta_dev = torch.zeros(self._meta_layout['_size'], dtype=torch.uint8,
+                                device=d)
+    self.meta_host = torch.zeros(self._meta_layout['_size'],
+                                 dtype=torch.uint8).pin_memory()
+    self.res_dev = torch.zeros(self._res_layout['_size'], dtype=torch.uint8,
+                               device=d)
+    self.res_host = torch.zeros(self._res_layout['_size'],
+                                dtype=torch.uint8).pin_memory()
+    mv = lambda buf, lay, k: self._view(buf, lay, k)     # noqa: E731
+    self.Ks = mv(self.meta_dev, self._meta_layout, 'Ks')
+    self.seeds = mv(self.meta_dev, self._meta_layout, 'seeds')
+    self.max_models = mv(self.meta_dev, self._meta_layout, 'max_models')
+    self.corr.slots = mv(self.meta_dev, self._meta_layout, 'slots').view(S, 2)
+    self.poses = mv(self.res_dev, self._res_layout, 'poses')
+    self.scores = mv(self.res_dev, self._res_layout, 'scores')
+    self.num_models = mv(self.res_dev, self._res_layout, 'num_models')
+    self.corr.totals = mv(self.res_dev, self._res_layout, 'totals').view(S, 2)
+    self.corr.overflow = mv(self.res_dev, self._res_layout, 'overflow')
+    self.stream = torch.cuda.Stream(self.dev)
+    self._done = torch.cuda.Event()
+    self._pending = None
     self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+  _DT = {'f8': (torch.float64, 8), 'i8': (torch.int64, 8), 'i4': (torch.int32, 4)}
+
+  @staticmethod
+  def _layout(fields):
+    lay, off = {}, 0
+    for name, dt, n in fields:
+      size = EposPipeline._DT[dt][1] * max(n, 1)
+      lay[name] = (off, dt, max(n, 1))
+      off = (off + size + 15) // 16 * 16
+    lay['_size'] = off
+    return lay
+
+  @staticmethod
+  def _view(buf, lay, name):
+    off, dt, n = lay[name]
+    tdt, sz = EposPipeline._DT[dt]
+    return buf[off:off + n * sz].view(tdt)
 
   # --------------------------------------------------------------------
   def make_slots(self, targets, task_type=LOCALIZATION):
@@ -89,54 +133,83 @@ class EposPipeline(object):
         slots.append((im, obj_id))
     return slots, wants
 
-  def process_batch(self, images, Ks, targets, task_type=LOCALIZATION,
-                    image_ids=None, scene_ids=None, seed=0, timing=False):
-    """images f32 [B,H,W,3]; Ks [B,3,3]; targets per image {obj_id: count}.
-    Returns (poses, run_times) like process_image (infer.py:348-554)."""
+  def launch(self, images, Ks, targets, task_type=LOCALIZATION, image_ids=None,
+             scene_ids=None, seed=0, timing=False):
+    """Enqueues one batch on this pipeline's stream -- network, correspondences,
+    PnP-RANSAC and the single device->host copy of the results -- and returns
+    without synchronising. ``collect()`` waits for it and builds the pose list.
+    Two pipelines used alternately overlap one batch's (latency-bound) fitting
+    tail with the next batch's network."""
+    if self._pending is not None:
+      raise _lib.EposError('launch() called twice without collect()')
     B = self.B
     slots, wants = self.make_slots(targets, task_type)
     S = len(slots)
-    if timing:
-      self._ev[0].record()
-    pred = self.net.forward(images, use_graph=self.use_graph)
-    if timing:
-      self._ev[1].record()
+    max_k = self.max_k if task_type != LOCALIZATION else max([1] + wants)
+    cur = torch.cuda.current_stream(self.dev)
+    self.stream.wait_stream(cur)            # inputs produced on the caller's stream
+    with torch.cuda.stream(self.stream):
+      if timing:
+        self._ev[0].record()
+      pred = self.net.forward(images, use_graph=self.use_graph)
+      if timing:
+        self._ev[1].record()
+      if S:
+        if S > self.max_slots:
+          raise ValueError('too many slots (%d > %d)' % (S, self.max_slots))
+        Ksl = np.asarray(Ks, np.float64).reshape(B, 9)[[s[0] for s in slots]]
+        sd = [(seed * 1000003 + (image_ids[im] if image_ids is not None else im)
+               * 1009 + obj) & 0x7fffffffffffffff for im, obj in slots]
+        mh, ml = self.meta_host, self._meta_layout
+        self._view(mh, ml, 'Ks')[:S * 9] = torch.from_numpy(Ksl.reshape(-1))
+        self._view(mh, ml, 'seeds')[:S] = torch.tensor(sd, dtype=torch.int64)
+        self._view(mh, ml, 'slots')[:S * 2] = torch.tensor(
+            slots, dtype=torch.int32).reshape(-1)
+        self._view(mh, ml, 'max_models')[:S] = torch.tensor(wants,
+                                                            dtype=torch.int32)
+        self.meta_dev.copy_(mh, non_blocking=True)          # one H2D
+        self.corr.S = S
+        self.corr.count(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
+                        self.tau_a, self.tau_b)
+        self.corr.fill(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
+                       pred[W.PRED_FRAG_LOC], self.output_scale)
+        if timing:
+          self._ev[2].record()
+        _lib.check(self.lib.epos_find6d_poses_device(
+            _ptr(self.corr.coord_2d), _ptr(self.corr.coord_3d),
+            _ptr(self.corr.slot_base), S, self.corr.capacity, _ptr(self.Ks),
+            _ptr(self.max_models), _ptr(self.seeds), ctypes.byref(self.fit),
+            max_k, _ptr(self.work), _ptr(self.poses), _ptr(self.scores),
+            _ptr(self.num_models), _ptr(self.labels),
+            ctypes.c_void_p(self.stream.cuda_stream)), 'epos_find6d_poses_device')
+        # NB: poses / scores are laid out [S, max_k(call), ...] for this call.
+        if timing:
+          self._ev[3].record()
+        self.res_host.copy_(self.res_dev, non_blocking=True)  # one D2H
+      self._done.record()
+    self._pending = (slots, wants, max_k, image_ids, scene_ids, timing)
+
+  def collect(self):
+    """Waits for the batch enqueued by ``launch()``; returns (poses, run_times)
+    like process_image (infer.py:348-554)."""
+    if self._pending is None:
+      raise _lib.EposError('collect() without launch()')
+    slots, wants, max_k, image_ids, scene_ids, timing = self._pending
+    self._pending = None
+    self._done.synchronize()                  # the one synchronisation
+    S = len(slots)
     poses_out = []
     if S:
-      Ks = np.asarray(Ks, np.float64).reshape(B, 9)
-      self.corr.set_slots(slots)
-      self.Ks[:S].copy_(torch.from_numpy(Ks[[s[0] for s in slots]]),
-                        non_blocking=True)
-      self.max_models[:S].copy_(torch.tensor(wants, dtype=torch.int32),
-                                non_blocking=True)
-      sd = [(seed * 1000003 + (image_ids[im] if image_ids is not None else im)
-             * 1009 + obj) & 0x7fffffffffffffff for im, obj in slots]
-      self.seeds[:S].copy_(torch.tensor(sd, dtype=torch.int64),
-                           non_blocking=True)
-      self.corr.count(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
-                      self.tau_a, self.tau_b)
-      self.corr.fill(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
-                     pred[W.PRED_FRAG_LOC], self.output_scale)
-      if timing:
-        self._ev[2].record()
-      max_k = self.max_k if task_type != LOCALIZATION else max(1, max(wants))
-      _lib.check(self.lib.epos_find6d_poses_device(
-          _ptr(self.corr.coord_2d), _ptr(self.corr.coord_3d),
-          _ptr(self.corr.slot_base), S, self.corr.capacity, _ptr(self.Ks),
-          _ptr(self.max_models), _ptr(self.seeds), ctypes.byref(self.fit),
-          max_k, _ptr(self.work), _ptr(self.poses), _ptr(self.scores),
-          _ptr(self.num_models), _ptr(self.labels),
-          ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)),
-                 'epos_find6d_poses_device')
-      # NB: poses / scores are laid out [S, max_k(call), ...] for this call.
-      if timing:
-        self._ev[3].record()
-      nm = self.num_models[:S].cpu().numpy()          # the one synchronisation
-      if int(self.corr.overflow.item()):
+      rh, rl = self.res_host, self._res_layout
+      if int(self._view(rh, rl, 'overflow')[0]):
         raise _lib.EposError(
             'correspondence capacity (%d rows) exceeded' % self.corr.capacity)
-      ph = self.poses.view(-1)[:S * max_k * 12].cpu().numpy().reshape(S, max_k, 12)
-      sh = self.scores.view(-1)[:S * max_k].cpu().numpy().reshape(S, max_k)
+      nm = self._view(rh, rl, 'num_models')[:S].numpy()
+      ph = self._view(rh, rl, 'poses')[:S * max_k * 12].numpy().reshape(
+          S, max_k, 12)
+      sh = self._view(rh, rl, 'scores')[:S * max_k].numpy().reshape(S, max_k)
+      self.last_totals = self._view(rh, rl, 'totals')[:S * 2].numpy().reshape(
+          S, 2).copy()
       for s, (im, obj_id) in enumerate(slots):
         for i in range(int(nm[s])):
           poses_out.append({
@@ -147,11 +220,8 @@ class EposPipeline(object):
               't': ph[s, i, 9:].reshape(3, 1).copy(),
               'score': float(sh[s, i]),
           })
-    else:
-      torch.cuda.synchronize(self.dev)
     run_times = {}
     if timing and S:
-      torch.cuda.synchronize(self.dev)
       e = self._ev
       run_times = {'prediction': e[0].elapsed_time(e[1]) * 1e-3,
                    'establish_corr': e[1].elapsed_time(e[2]) * 1e-3,
@@ -160,3 +230,11 @@ class EposPipeline(object):
       for p in poses_out:
         p['time'] = run_times['total']
     return poses_out, run_times
+
+  def process_batch(self, images, Ks, targets, task_type=LOCALIZATION,
+                    image_ids=None, scene_ids=None, seed=0, timing=False):
+    """images f32 [B,H,W,3]; Ks [B,3,3]; targets per image {obj_id: count}.
+    Returns (poses, run_times) like process_image (infer.py:348-554)."""
+    self.launch(images, Ks, targets, task_type, image_ids, scene_ids, seed,
+                timing)
+    return self.collect()

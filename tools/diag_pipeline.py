@@ -26,7 +26,7 @@ Ks = np.tile(synthetic.YCBV_K, (B, 1, 1))
 for it in range(3):
   poses, rt = pipe.process_batch(imgs, Ks, tg, seed=it, timing=True)
 print('stage times (s):', {k: round(v, 5) for k, v in rt.items()}, 'poses', len(poses))
-tot = pipe.corr.totals[:pipe.corr.S].cpu().numpy()
+tot = pipe.last_totals
 print('masked px / corr per slot:', tot.tolist())
 net = pipe.net
 for nm in ['encoder', 'decoder_out']:

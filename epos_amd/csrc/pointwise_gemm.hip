@@ -289,6 +289,206 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(GroupedArgs ga_) {
 }
 
 // ---------------------------------------------------------------------------
+// Barrier-free variant ("wave-private"): every wave owns a 32 x 64 output tile
+// (1 x 2 MFMA tiles), stages ITS OWN 32 rows of A through a private LDS region
+// (the LDS round trip is only the row-major -> k-fragment transposition) and
+// reads its W fragments straight from global memory -- the pre-packed
+// [K/4][Npad][4] weight layout makes that a contiguous 512 B per half-wave. No
+// s_barrier anywhere: waves never wait for each other, a wave whose rows or
+// columns are padding simply does less, and the four waves of a workgroup (a
+// 128 x 64 tile, stacked along M) only share the L1 hits on W.
+// ---------------------------------------------------------------------------
+constexpr int WP_ROWS = 32;
+constexpr int WP_LDS_TILE = WP_ROWS * LDS_A_ROW;   // floats per buffer per wave
+
+template <bool RELU_IN, bool HAS_RES>
+__global__ __launch_bounds__(THREADS) void pointwise_gemm_wp_f32(GroupedArgs ga_) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  float* As = smem + wave * 2 * WP_LDS_TILE;
+
+  (void)ga_;
+  const GroupedArgs* __restrict__ gp =
+      (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // addrspace cast
+  int bid;
+  {
+    const int total = gp->tile_start[MAX_GROUP];
+    const int raw = blockIdx.x, x = raw & 7, idx = raw >> 3;
+    const int q = total >> 3, r = total & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_GROUP; ++i)
+    if (i < gp->count && bid >= gp->tile_start[i]) pi = i;
+  bid -= gp->tile_start[pi];
+  const EposPointwiseArgs p = gp->p[pi];
+  const int tiles_n = gp->tiles_n[pi];         // 64-column tiles
+  const int npad = gp->npad[pi];
+  const int tile_n = bid % tiles_n;
+  const int tile_m = bid / tiles_n;
+  const int M = p.M, N = p.N, K = p.K;
+  const int m0 = tile_m * 128 + wave * WP_ROWS, n0 = tile_n * 64;
+  if (m0 >= M) return;                          // no barriers: a wave may leave
+
+  const int c4 = lane & 7;
+  const float* arow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + (lane >> 3) + 8 * i;
+    m = m < M ? m : M - 1;
+    int64_t row = m;
+    if (p.sub > 1) {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      row = (static_cast<int64_t>(b) * p.Hi + yo * p.sub) * p.Wi + xo * p.sub;
+    }
+    arow[i] = p.A + row * p.lda + c4 * 4;
+  }
+  const float* wbase = p.Wp + (static_cast<int64_t>(h) * npad + n0 + l31) * 4;
+  const int64_t wstep_g = static_cast<int64_t>(2) * npad * 4;    // +1 k-group of 8
+  const int64_t wstep_tile = static_cast<int64_t>(8) * npad * 4; // +1 K tile
+  const int a_frag_off = l31 * LDS_A_ROW + h * 4;
+  const int a_stage_off = (lane >> 3) * LDS_A_ROW + c4 * 4;
+  const int nk = (K + BK - 1) / BK;
+
+  auto body = [&](auto tn_tag) {
+    constexpr int TN = decltype(tn_tag)::value;    // valid 32-column subtiles
+    float4 a0, a1, a2, a3;                         // staged A rows of the next tile
+    float4 bc[4][TN], bn[4][TN];                   // W fragments: this / next tile
+    bool kin = true;
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    auto gload = [&](int kt, auto tail_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      int ko = kt * BK;
+      if (TAIL) {
+        kin = kt * BK + c4 * 4 < K;
+        ko = kin ? ko : 0;
+      }
+      a0 = *reinterpret_cast<const float4*>(arow[0] + ko);
+      a1 = *reinterpret_cast<const float4*>(arow[1] + ko);
+      a2 = *reinterpret_cast<const float4*>(arow[2] + ko);
+      a3 = *reinterpret_cast<const float4*>(arow[3] + ko);
+      const float* wp = wbase + kt * wstep_tile;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bn[g][j] = *reinterpret_cast<const float4*>(wp + g * wstep_g + j * 32 * 4);
+    };
+    auto swrite = [&](int buf, auto tail_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      auto fix = [&](float4 v) {
+        if (TAIL && !kin) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        return RELU_IN ? relu4(v) : v;
+      };
+      float* a = As + buf * WP_LDS_TILE + a_stage_off;
+      *reinterpret_cast<float4*>(a) = fix(a0);
+      *reinterpret_cast<float4*>(a + 8 * LDS_A_ROW) = fix(a1);
+      *reinterpret_cast<float4*>(a + 16 * LDS_A_ROW) = fix(a2);
+      *reinterpret_cast<float4*>(a + 24 * LDS_A_ROW) = fix(a3);
+    };
+    float4 fa;
+    auto read_frag = [&](int buf, int g) {
+      fa = *reinterpret_cast<const float4*>(As + buf * WP_LDS_TILE + a_frag_off + g * 8);
+    };
+    auto mfma_steps = [&](const float4& ca, int g, int s0, int s1) {
+      const float* afp = reinterpret_cast<const float*>(&ca);
+#pragma unroll
+      for (int sidx = s0; sidx < s1; ++sidx)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              afp[sidx], reinterpret_cast<const float*>(&bc[g][j])[sidx], acc[j],
+              0, 0, 0);
+    };
+
+    gload(0, std::true_type{});
+    swrite(0, std::true_type{});
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bc[g][j] = bn[g][j];
+    read_frag(0, 0);
+
+    auto tile = [&](int kt, auto has_next_tag, auto next_tail_tag) {
+      constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+      const int buf = kt & 1;
+      if (HAS_NEXT) {
+        gload(kt + 1, next_tail_tag);
+        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch up here
+      }
+      const int kleft = K - kt * BK;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 ca = fa;
+        const bool live = HAS_NEXT || g * 8 < kleft;
+        if (g < 3) {
+          read_frag(buf, g + 1);
+          if (live) mfma_steps(ca, g, 0, 4);
+        } else {
+          if (HAS_NEXT) swrite(buf ^ 1, next_tail_tag);
+          if (live) mfma_steps(ca, g, 0, 2);
+          if (HAS_NEXT) read_frag(buf ^ 1, 0);   // own LDS region: no barrier
+          if (live) mfma_steps(ca, g, 2, 4);
+        }
+      }
+      if (HAS_NEXT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bc[g][j] = bn[g][j];
+      }
+    };
+    for (int kt = 0; kt + 2 < nk; ++kt)
+      tile(kt, std::true_type{}, std::false_type{});
+    if (nk >= 2) tile(nk - 2, std::true_type{}, std::true_type{});
+    tile(nk - 1, std::false_type{}, std::false_type{});
+
+    // ---- epilogue ---------------------------------------------------------
+    const bool relu = p.relu != 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + j * 32 + l31;
+      const int nc = n < N ? n : N - 1;
+      const float bias = p.bias ? p.bias[nc] : 0.f;
+      const int mb = m0 + 4 * h;
+      float rv[16];
+      if (HAS_RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = mb + (r & 3) + 8 * (r >> 2);
+          m = m < M ? m : M - 1;
+          rv[r] = p.R[static_cast<int64_t>(m) * p.ldr + nc];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        float v = acc[j][r] + bias;
+        if (HAS_RES) v += rv[r];
+        if (relu) v = fmaxf(v, 0.f);
+        if (m < M && n < N) p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
+      }
+    }
+  };
+  if (n0 + 32 < N) {
+    body(std::integral_constant<int, 2>{});
+  } else {
+    body(std::integral_constant<int, 1>{});      // second 32 columns are padding
+  }
+}
+
+// ---------------------------------------------------------------------------
 // M <= 8 rows (the image-pooling branch, model.py:223-224, M = batch): a GEMV.
 // Block = 64 output channels x 4 K-slices; fixed-order LDS reduction.
 // ---------------------------------------------------------------------------
@@ -384,6 +584,34 @@ int launch_grouped(const EposPointwiseArgs* args, int count, hipStream_t s) {
                  : launch_grouped_t<BM, false, false>(g, total, s);
 }
 
+template <bool RELU_IN, bool HAS_RES>
+int launch_wp_t(const GroupedArgs& g, int total, hipStream_t s) {
+  const size_t lds = sizeof(float) * 4 * 2 * WP_LDS_TILE;
+  hipLaunchKernelGGL((pointwise_gemm_wp_f32<RELU_IN, HAS_RES>), dim3(total),
+                     dim3(THREADS), lds, s, g);
+  return launch_status("pointwise_gemm_wp_f32");
+}
+
+int launch_grouped_wp(const EposPointwiseArgs* args, int count, hipStream_t s) {
+  GroupedArgs g;
+  g.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    g.p[i] = args[i];
+    g.npad[i] = static_cast<int>(round_up(args[i].N, BN));
+    g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, 64));
+    g.tile_start[i] = total;
+    total += static_cast<int>(ceil_div(args[i].M, 128)) * g.tiles_n[i];
+  }
+  for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  const bool relu_in = args[0].relu_in != 0, has_res = args[0].R != nullptr;
+  if (relu_in)
+    return has_res ? launch_wp_t<true, true>(g, total, s)
+                   : launch_wp_t<true, false>(g, total, s);
+  return has_res ? launch_wp_t<false, true>(g, total, s)
+                 : launch_wp_t<false, false>(g, total, s);
+}
+
 }  // namespace
 }  // namespace epos
 
@@ -431,6 +659,18 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
     const char* e = getenv("EPOS_GEMM_TILE_M");
     return e ? atoi(e) : 0;
   }();
+  // Kernel choice (EPOS_GEMM_WP=0|1 forces one for tuning): the two kernels tie
+  // on wide outputs; the barrier-free one tiles N in steps of 64 (and skips an
+  // all-padding 32-column half), so it wins whenever every problem of the group
+  // has N <= 64 (stem convs, the 48-channel decoder projection, the object head).
+  static const int use_wp = [] {
+    const char* e = getenv("EPOS_GEMM_WP");
+    return e ? atoi(e) : -1;
+  }();
+  int max_n = 0;
+  for (int i = 0; i < count; ++i) max_n = args[i].N > max_n ? args[i].N : max_n;
+  if (use_wp == 1 || (use_wp < 0 && max_n <= 64))
+    return launch_grouped_wp(args, count, s);
   const bool big = forced ? forced == 128 : tiles128 >= 512;
   if (big) return launch_grouped<128>(args, count, s);
   return launch_grouped<64>(args, count, s);

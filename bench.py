@@ -138,10 +138,21 @@ def gemm_roofline(pipe, steps):
       flops += net.op_flops[name]
       per.setdefault(name, []).append(ms)
   achieved = flops / (total_ms * 1e-3) / 1e12
+  # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE and
+  # WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE) that cannot
+  # run inside this process; the committed summary of the last collection is
+  # reported here (profiles/r01/gemm_hbm_traffic_pmc.json).
+  traffic, traffic_src = None, None
+  tpath = os.path.join(ROOT, 'profiles', 'r01', 'gemm_hbm_traffic_pmc.json')
+  if os.path.exists(tpath):
+    with open(tpath) as f:
+      traffic = round(json.load(f)['traffic_bytes_per_launch'])
+    traffic_src = 'profiles/r01/gemm_hbm_traffic_pmc.json (rocprofv3 --pmc)'
   return {
       'bound': 'mfma', 'achieved': round(achieved, 2),
       'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+      'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,
       'kernel': 'pointwise_gemm_f32',
       'launches_per_image': launches // steps // net.B,
       'avg_launch_us': round(total_ms * 1e3 / launches, 2),
@@ -259,6 +270,8 @@ def main():
   if rank == 0 and not args.no_roofline:
     roof, _ = gemm_roofline(pipe, max(2, min(args.steps, 5)))
     roof['end_to_end_tflops'] = round(value / world * pipe.net.flops / B / 1e12, 2)
+    roof['achieved_in_pipeline'] = round(
+        value / world * roof['gflop_per_image'] / 1e3, 2)   # GEMM flops only
     result['roofline'] = roof
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     result['cpu_baseline'] = cpu_baseline(ckpt, store, args,

@@ -64,6 +64,69 @@ __device__ __forceinline__ float4 relu4(float4 v) {
                      fmaxf(v.w, 0.f));
 }
 
+// ---------------------------------------------------------------------------
+// Vectorised epilogue. The MFMA accumulator layout gives a lane ONE output column
+// and 16 rows, i.e. 4-byte stores that touch 128 B per row -- store-ISSUE bound
+// (a 14 MB layer output took ~9 us). The wave instead transposes its tile through
+// its own LDS region (bias added on the way in) and then streams it out row-major
+// as float4: 16 B per lane, the residual is fetched the same way, ReLU last.
+// Falls back to the scalar path when rows are not 16-byte aligned (e.g. the
+// 22-channel object head).
+// ---------------------------------------------------------------------------
+constexpr int EP_ROW = 68;     // floats per staged row (64 + 4: 16 B aligned, no conflicts)
+
+__device__ __forceinline__ bool vec_epilogue_ok(const EposPointwiseArgs& p, bool has_res) {
+  bool ok = (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+  if (has_res)
+    ok = ok && (p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.R) & 15) == 0;
+  return ok;
+}
+
+// acc: TM x TN accumulator tiles of this wave (row-tile major); the wave tile is
+// (TM*32) rows x (TN*32) columns at (m0w, n0w); `ws` = TM*32*EP_ROW floats of LDS
+// owned by this wave.
+template <int TM, int TN, bool HAS_RES>
+__device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
+                                             const EposPointwiseArgs& p, int m0w,
+                                             int n0w, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = p.M, N = p.N;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0w + j * 32 + l31;
+    const float bias = p.bias ? p.bias[n < N ? n : N - 1] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ws[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EP_ROW + j * 32 + l31] =
+            acc[i * TN + j][r] + bias;
+  }
+  // same wave wrote and reads: only the LDS counter has to drain
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  constexpr int C4 = TN * 8;                 // float4 per staged row
+  constexpr int RPI = 64 / C4;               // rows per wave instruction
+  const int c4 = lane % C4, r0 = lane / C4;
+  const int n = n0w + c4 * 4;
+  const bool relu = p.relu != 0;
+#pragma unroll
+  for (int i = 0; i < TM * 32 / RPI; ++i) {
+    const int row = r0 + i * RPI;
+    const int m = m0w + row;
+    float4 v = *reinterpret_cast<const float4*>(ws + row * EP_ROW + c4 * 4);
+    if (m < M && n < N) {
+      if (HAS_RES) {
+        const float4 rv = *reinterpret_cast<const float4*>(
+            p.R + static_cast<int64_t>(m) * p.ldr + n);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      if (relu) v = relu4(v);
+      *reinterpret_cast<float4*>(p.C + static_cast<int64_t>(m) * p.ldc + n) = v;
+    }
+  }
+}
+
 template <int BM, bool RELU_IN, bool HAS_RES>
 __global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(GroupedArgs ga_) {
   constexpr int TM = BM / 64;                 // MFMA tiles per wave along M
@@ -236,6 +299,11 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(GroupedArgs ga_) {
         __syncthreads();
         read_frags(buf ^ 1, 0);
       }
+      // Pin the fragment reads of the NEXT k-group in front of this group's MFMAs
+      // (hipcc otherwise sinks them behind the MFMAs and then waits for the LDS
+      // right at the next group boundary, draining the matrix pipe four times per
+      // K tile).
+      __builtin_amdgcn_sched_barrier(0);
       if (HAS_NEXT || g * 8 < kleft) {     // wave-uniform: skip all-zero k-groups
         const float* afp = reinterpret_cast<const float*>(ca);
         const float* bfp = reinterpret_cast<const float*>(cb);
@@ -255,7 +323,15 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_f32(GroupedArgs ga_) {
   if (nk >= 2) tile(nk - 2, std::true_type{}, std::true_type{});
   tile(nk - 1, std::false_type{}, std::false_type{});
 
-  // ---- epilogue: bias (+ residual) (+ ReLU), predicated stores -------------
+  // ---- epilogue -------------------------------------------------------------
+  if (vec_epilogue_ok(p, HAS_RES)) {
+    __syncthreads();                       // every wave is done with the K tiles
+    float* ws = smem + wave * (BM / 2) * EP_ROW;
+    vec_epilogue<TM, 2, HAS_RES>(ws, &acc[0][0], p, m0 + wm * (BM / 2),
+                                 n0 + wn * 64, lane);
+    return;
+  }
+  // scalar path: bias (+ residual) (+ ReLU), predicated 4-byte stores
   // Residual values are fetched with unconditional (clamped) loads, a whole
   // 32x32 tile at a time, so that they are in flight together.
   const bool relu = p.relu != 0;
@@ -434,11 +510,14 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_wp_f32(GroupedArgs ga_
         const bool live = HAS_NEXT || g * 8 < kleft;
         if (g < 3) {
           read_frag(buf, g + 1);
+          __builtin_amdgcn_sched_barrier(0);     // reads first, then the MFMAs
           if (live) mfma_steps(ca, g, 0, 4);
         } else {
           if (HAS_NEXT) swrite(buf ^ 1, next_tail_tag);
+          __builtin_amdgcn_sched_barrier(0);
           if (live) mfma_steps(ca, g, 0, 2);
           if (HAS_NEXT) read_frag(buf ^ 1, 0);   // own LDS region: no barrier
+          __builtin_amdgcn_sched_barrier(0);
           if (live) mfma_steps(ca, g, 2, 4);
         }
       }
@@ -455,6 +534,10 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_wp_f32(GroupedArgs ga_
     tile(nk - 1, std::false_type{}, std::false_type{});
 
     // ---- epilogue ---------------------------------------------------------
+    if (vec_epilogue_ok(p, HAS_RES)) {       // private LDS region: no barrier
+      vec_epilogue<1, TN, HAS_RES>(As, acc, p, m0, n0, lane);
+      return;
+    }
     const bool relu = p.relu != 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -553,7 +636,8 @@ int launch_grouped_t(const GroupedArgs& g, int total, hipStream_t s) {
     return e ? atoi(e) : 1;
   }();
   if (spread) {
-    const int per_cu = (total + 255) / 256;
+    int per_cu = (total + 255) / 256;
+    if (spread > 1 && per_cu > spread) per_cu = spread;   // EPOS_GEMM_SPREAD=k: cap
     const size_t cap = (LDS_MAX / per_cu) & ~static_cast<size_t>(1023);
     if (cap > lds) lds = cap;
   }

@@ -14,7 +14,7 @@ ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--stats', action='store_true')
 args = ap.parse_args()
 O, F = 21, 64
-ckpt = weights.random_init(num_objs=O, seed=0, logits_std=args.logits_std)
+ckpt = weights.random_init(num_objs=O, seed=0, logits_std=args.logits_std, randomize_bn=True)
 net = model.get_net(ckpt, args.batch, 480, 640, O, F)
 img = np.stack([synthetic.image(i, 480, 640) for i in range(args.batch)])
 out = net.forward(torch.from_numpy(img).cuda())

@@ -43,5 +43,17 @@ int main() {
       printf("data=%s waves/SIMD=%d  %.1f TFLOP/s  (%.2f ms)\n", mode == 0 ? "zeros" : mode == 1 ? "small" : "unit ", wps, flops / ms / 1e9, ms);
     }
   }
+  // sustained: ~0.2 s back to back (power management settles), random operands
+  for (int wps = 1; wps <= 4; wps += 1) {
+    const int blocks = 256 * wps, iters = 4000, reps = 50 / wps + 1;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int r = 0; r < reps; ++r) k<<<blocks, 256>>>(in, out, iters);   // warm
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) k<<<blocks, 256>>>(in, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)reps * blocks * 4 * iters * 32 * 4096.0;
+    printf("sustained data=unit waves/SIMD=%d  %.1f TFLOP/s over %.0f ms\n", wps, flops / ms / 1e9, ms);
+  }
   return 0;
 }

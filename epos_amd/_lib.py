@@ -126,6 +126,8 @@ SYMBOLS = {
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, vp, vp,
         vp, ctypes.c_int64, ctypes.POINTER(CorrOut), vp, vp]),
     'epos_corr_slot_bases': (ctypes.c_int, [vp, ctypes.c_int, vp, vp]),
+    'epos_fragmentation_fps': (ctypes.c_int, [
+        vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, vp]),
     'epos_fit_params_default': (None, [ctypes.POINTER(FitParams)]),
     'epos_find6d_poses': (ctypes.c_int, [
         vp, vp, ctypes.c_int64, vp, ctypes.POINTER(FitParams), ctypes.c_uint64,

@@ -199,6 +199,18 @@ int epos_corr_slot_bases(const int32_t* totals, int S, int64_t* slot_base,
                          void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * Model preprocessing (replaces epos_lib/fragment.py:8-54, fragmentation_fps,
+ * called once per object by ObjectModelStore.fragment_models, datagen.py:86-126).
+ * vertices f64[V,3] [device]; outputs [device]: centers f64[F,3] (the FPS picks, in
+ * order), center_idx i32[F] (their vertex indices), vertex_frag_ids i32[V] (nearest
+ * centre of every vertex); nn_dist f64[V] is scratch. Bit-identical to the
+ * reference (fp64, same operation order, lowest-index tie rule).
+ * ------------------------------------------------------------------------- */
+int epos_fragmentation_fps(const double* vertices, int64_t V, int num_frags,
+                           double* nn_dist, double* centers, int32_t* center_idx,
+                           int32_t* vertex_frag_ids, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Pose fitting (replaces pyprogressivex.find6DPoses, scripts/infer.py:470-488;
  * the un-vendored danini/progressive-x pybind11 module).
  * ------------------------------------------------------------------------- */

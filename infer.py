@@ -215,6 +215,61 @@ def save_correspondences(infer_dir, infer_name, frame, im_ind, corr, pred_time):
       f.write(txt)
 
 
+def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
+  """process_image (infer.py:348-554) call by call: predict -> corresp ->
+  [PROSAC sort / top-K by confidence, infer.py:425-440] -> find6DPoses per object."""
+  from epos_amd import corresp as ecorresp
+  t0 = time.time()
+  pred = pipe.net.forward(imgs, use_graph=pipe.use_graph)
+  torch.cuda.synchronize()
+  t1 = time.time()
+  poses = []
+  t_corr = t_fit = 0.0
+  for b, f in enumerate(chunk):
+    tc = time.time()
+    corr = ecorresp.establish_many_to_many(
+        pred['pred_obj_conf'][b], pred['pred_frag_conf'][b],
+        pred['pred_frag_loc'][b], list(targets[b]), store, pipe.output_scale,
+        args.corr_min_obj_conf, args.corr_min_frag_rel_conf, False,
+        args.task_type == pipeline.LOCALIZATION, device=str(pipe.dev))
+    t_corr += time.time() - tc
+    tf_ = time.time()
+    for obj_id, c in corr.items():
+      n = c['coord_2d'].shape[0]
+      if n < 6:                                           # infer.py:420-422
+        continue
+      if args.use_prosac:                                 # infer.py:425-428
+        order = np.argsort(c['conf'])[::-1]
+        c = {k: v[order] for k, v in c.items()}
+      if args.max_correspondences is not None and n > args.max_correspondences:
+        keep = (np.arange(n) if args.use_prosac else
+                np.argsort(c['conf'])[::-1])[:args.max_correspondences]
+        c = {k: v[keep] for k, v in c.items()}           # infer.py:431-440
+      num_inst = (targets[b].get(obj_id, 1)
+                  if args.task_type == pipeline.LOCALIZATION else -1)
+      if args.max_instances_to_fit is not None:
+        num_inst = min(num_inst, args.max_instances_to_fit)
+      est, _, quals = fitting.find6DPoses(
+          c['coord_2d'], c['coord_3d'], f[3], threshold=fit.threshold,
+          max_tanimoto_similarity=fit.max_tanimoto_similarity,
+          max_iters=fit.max_iters, min_coverage=fit.min_coverage,
+          min_triangle_area=fit.min_triangle_area, min_point_number=6,
+          max_model_number=num_inst, use_prosac=args.use_prosac,
+          seed=args.seed * 1000003 + f[1] * 1009 + obj_id)
+      if est is not None:                                 # infer.py:490-503
+        for i in range(est.shape[0] // 3):
+          poses.append({'scene_id': f[0], 'im_id': f[1], 'obj_id': obj_id,
+                        'R': est[3 * i:3 * i + 3, :3],
+                        't': est[3 * i:3 * i + 3, 3].reshape(3, 1),
+                        'score': float(quals[i])})
+    t_fit += time.time() - tf_
+  rt = {'prediction': t1 - t0, 'establish_corr': t_corr, 'fitting': t_fit}
+  rt['total'] = sum(rt.values())
+  for p in poses:
+    p['time'] = rt['total']
+  return poses, rt
+
+
 def main(argv=None):
   args = build_parser().parse_args(argv)
   rank, world, local_rank = edist.init_from_env()
@@ -272,10 +327,11 @@ def main(argv=None):
       min_triangle_area=args.min_triangle_area, min_point_number=6,
       max_model_number_for_optimization=args.max_model_number_for_pearl,
       use_prosac=args.use_prosac)
-  if args.max_correspondences is not None or args.use_prosac:
-    raise NotImplementedError(
-        'max_correspondences / use_prosac need the confidence sort of '
-        'infer.py:425-440 on device; both default to off.')
+  # max_correspondences / use_prosac (both off by default, infer.py:95-97,115-117)
+  # re-order the correspondences by confidence on the host (infer.py:425-440), so
+  # those runs go operator by operator (HIP network -> HIP correspondences -> host
+  # sort -> HIP fitting per object) instead of through the fused device pipeline.
+  operator_path = args.max_correspondences is not None or args.use_prosac
   B = args.batch
   max_inst = args.max_instances_to_fit or 4
   pipe = pipeline.EposPipeline(
@@ -295,10 +351,13 @@ def main(argv=None):
     if args.max_instances_to_fit is not None:  # infer.py:467-468
       tg = [{o: min(c, args.max_instances_to_fit) for o, c in t.items()}
             for t in tg]
-    poses, rt = pipe.process_batch(
-        imgs, Ks, tg, task_type=args.task_type,
-        image_ids=[f[1] for f in chunk], scene_ids=[f[0] for f in chunk],
-        seed=args.seed, timing=True)
+    if operator_path:
+      poses, rt = process_by_operators(pipe, store, imgs, chunk, tg, args, fit)
+    else:
+      poses, rt = pipe.process_batch(
+          imgs, Ks, tg, task_type=args.task_type,
+          image_ids=[f[1] for f in chunk], scene_ids=[f[0] for f in chunk],
+          seed=args.seed, timing=True)
     n_real = len(frames[i0:i0 + B])
     real_ids = set((f[0], f[1]) for f in frames[i0:i0 + n_real])
     seen = set()

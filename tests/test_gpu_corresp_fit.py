@@ -172,3 +172,31 @@ def test_ransac_deterministic_across_runs():
   a = fitting.find6DPoses(xy, xyz, K, seed=5)
   b = fitting.find6DPoses(xy, xyz, K, seed=5)
   assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ------------------------------------------------------------- fragmentation --
+@pytest.mark.parametrize('name', ['ellipsoid_s0', 'ellipsoid_s1'])
+def test_fragmentation_fps_bit_exact_vs_reference_golden(name):
+  from epos_amd import fragment
+  z = np.load(os.path.join(GOLDEN, 'fragment_%s.npz' % name))
+  centers, ids = fragment.fragmentation_fps(z['vertices'], int(z['num_frags']))
+  assert centers.dtype == z['frag_centers'].dtype
+  assert np.array_equal(centers, z['frag_centers'])
+  assert np.array_equal(ids, z['vertex_frag_ids'])
+  fc, fs = fragment.fragment_models({7: z['vertices']}, int(z['num_frags']))
+  assert np.array_equal(fc[7], z['frag_centers']) and (fs[7] >= 5.0).all()
+
+
+def test_fragmentation_fps_large_cloud_matches_oracle():
+  from epos_amd import fragment
+  from oracle import fragment_ref
+  rng = np.random.RandomState(4)
+  pts = rng.standard_normal((20000, 3)) * [40, 60, 25]
+  c, ids = fragment.fragmentation_fps(pts, 64)
+  rc, rids = fragment_ref.fragmentation_fps(pts, 64)
+  assert np.array_equal(c, rc) and np.array_equal(ids, rids)
+  # FPS property: the distance of each new centre to the set chosen so far (seeded
+  # with the model origin, fragment.py:27) is non-increasing.
+  seed = np.vstack([np.zeros((1, 3)), c])
+  d = [np.min(np.linalg.norm(seed[:k] - seed[k], axis=1)) for k in range(1, 65)]
+  assert all(d[i] >= d[i + 1] - 1e-9 for i in range(len(d) - 1))

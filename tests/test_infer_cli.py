@@ -65,3 +65,17 @@ def test_infer_synthetic_end_to_end(tmp_path):
   res = bop_io.load_bop_results(str(csv))
   for r in res:
     assert r['R'].shape == (3, 3) and r['t'].shape == (3, 1) and r['time'] > 0
+
+
+@pytest.mark.gpu
+def test_infer_operator_path_with_max_correspondences(tmp_path):
+  env = dict(os.environ, TF_MODELS_PATH=str(tmp_path))
+  (tmp_path / 'toy').mkdir()
+  (tmp_path / 'toy' / 'params.yml').write_text('infer_crop_size: "128,96"\n')
+  out = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'infer.py'), '--model=toy',
+       '--synthetic', '2', '--num_objs', '3', '--max_correspondences', '200',
+       '--use_prosac', 'true'],
+      env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout + out.stderr
+  assert (tmp_path / 'toy' / 'infer' / 'estimated-poses.csv').exists()

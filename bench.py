@@ -57,6 +57,10 @@ def parse_args():
                   help='batches in flight per GPU: with >= 2, the fitting tail of '
                        'step i overlaps the network of step i+1 (two independent '
                        'plans on two HIP streams); 1 = strictly serial steps')
+  ap.add_argument('--sparse-heads', action='store_true',
+                  help='evaluate the fragment heads only for the target objects of '
+                       'each image (identical poses, fewer FLOPs); default: dense '
+                       'heads as model.predict defines them')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-roofline', action='store_true')
   ap.add_argument('--cpu-baseline-images', type=int, default=1)
@@ -195,7 +199,8 @@ def main():
   pipes = [pipeline.EposPipeline(
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
       capacity=1 << 21, max_instances=1, device=dev,
-      use_graph=not args.no_graph, instance=j) for j in range(depth)]
+      use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads)
+           for j in range(depth)]
   pipe = pipes[0]
   # Synthetic frames, resident in HBM before the timed region.
   n_pool = 4
@@ -262,6 +267,7 @@ def main():
           'parallelism': 'dp%d (images sharded, one all_gather of pose records)'
                          % world,
           'hip_graph': not args.no_graph, 'pipeline_depth': depth,
+          'heads': 'sparse (target objects only)' if args.sparse_heads else 'dense',
           'corr_per_slot_last_step': [int(x) for x in totals[:, 1]],
           'poses_per_step': round(n_poses / max(args.steps, 1), 2),
           'algorithmic_gflop_per_image': round(pipe.net.flops / B / 1e9, 1),

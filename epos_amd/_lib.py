@@ -118,6 +118,8 @@ SYMBOLS = {
                                 [vp, ctypes.c_int64, ctypes.c_int, vp]),
     'epos_argmax_i64': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, vp]),
+    'epos_softmax_slots_f32': (ctypes.c_int, [
+        vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     'epos_corr_count': (ctypes.c_int, [
         vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp]),

@@ -253,6 +253,24 @@ __global__ __launch_bounds__(256) void softmax_groups_kernel(float* X,
   if (on) x[lane] = e / s;
 }
 
+// Softmax over the F fragment confidences of the given (image, object) slots only
+// (sparse-head mode): group of slot s, pixel p at X + ((img*P + p)*O + obj-1)*F.
+__global__ __launch_bounds__(256) void softmax_slots_kernel(
+    float* X, const EposCorrSlot* __restrict__ slots, int P, int O, int F) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  const int s = blockIdx.y;
+  const int img = slots[s].image, obj = slots[s].obj_id;
+  float* x = X + ((static_cast<int64_t>(img) * P + p) * O + (obj - 1)) * F;
+  const bool on = lane < F;
+  const float v = on ? x[lane] : -INFINITY;
+  const float m = wave_max(v);
+  const float e = on ? expf(v - m) : 0.f;
+  const float sum = wave_sum(e);
+  if (on) x[lane] = e / sum;
+}
+
 __global__ __launch_bounds__(256) void argmax_kernel(const float* X, int64_t ldx,
                                                      int64_t* labels, int64_t P,
                                                      int C) {
@@ -459,4 +477,14 @@ extern "C" int epos_add_relu_f32(const float* A, const float* B, float* Y,
   hipLaunchKernelGGL(add_relu_kernel, dim3(blocks_for(n / 4, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), A, B, Y, n / 4);
   return launch_status("add_relu_kernel");
+}
+
+extern "C" int epos_softmax_slots_f32(float* X, const EposCorrSlot* slots, int S,
+                                      int P, int O, int F, void* stream) {
+  EPOS_REQUIRE(X && slots, "null pointer");
+  EPOS_REQUIRE(F >= 1 && F <= 64, "F must be in [1, 64]");
+  if (S == 0 || P == 0) return EPOS_OK;
+  hipLaunchKernelGGL(softmax_slots_kernel, dim3(blocks_for(P, 4), S), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), X, slots, P, O, F);
+  return launch_status("softmax_slots_kernel");
 }

@@ -67,6 +67,7 @@ class EposNet(object):
     self.op_flops = {}
     self.op_kind = {}        # 'gemm' | 'dw' | 'im2col' | 'other'
     self._graph = None
+    self._graph_sparse = None
     self._build_plan()
 
   # ------------------------------------------------------------ buffers ---
@@ -451,6 +452,7 @@ class EposNet(object):
     # ---- logits (model.py:396-458), sorted(name) order (model.py:503).
     self.logits = {}
     grp = []
+    self._n_trunk_ops = len(self.ops)      # everything before the logits layers
     for name, ch in sorted(W.outputs_to_num_channels(
         self.num_objs, self.num_frags).items()):
       wt = self.ckpt['logits/%s/weights' % name].reshape(256, ch)
@@ -460,7 +462,19 @@ class EposNet(object):
                       np.ones(ch, np.float32), bs, buf, 0, ch, relu=False,
                       group=grp)
       self.logits[name] = buf
+    obj_only = [g for g in grp if g[0].endswith(W.PRED_OBJ_CONF)]
     self._flush_group(grp)              # the three heads: one grouped launch
+    # Sparse-head mode (pipeline option): only the object head runs densely; the
+    # fragment heads are evaluated per (image, target object) -- see
+    # run_sparse_heads().
+    oname, oargs, oflops = obj_only[0]
+
+    def run_obj_head(stream, args=oargs):
+      _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), stream), oname)
+    self._obj_head_op = (oname, run_obj_head)
+    self._obj_head_flops = oflops
+    self._sparse_packs = None
+    self._decoder_x = x
 
     # ---- predict post-ops (model.py:677-683): softmax in place, argmax.
     self.post_ops = []
@@ -493,13 +507,79 @@ class EposNet(object):
   def sync_current(self):
     torch.cuda.current_stream(self.dev).synchronize()
 
-  def run_plan(self, with_post=True):
+  def run_plan(self, with_post=True, sparse=False):
+    """sparse=False: the whole dense plan. sparse=True: trunk + object head +
+    object softmax/argmax only (the fragment heads follow per target object)."""
     s = self._stream()
-    for _, fn in self.ops:
-      fn(s)
-    if with_post:
-      for _, fn in self.post_ops:
+    if not sparse:
+      for _, fn in self.ops:
         fn(s)
+      if with_post:
+        for _, fn in self.post_ops:
+          fn(s)
+      return
+    for _, fn in self.ops[:self._n_trunk_ops]:
+      fn(s)
+    self._obj_head_op[1](s)
+    for name, fn in self.post_ops:
+      if name != 'softmax_frag':
+        fn(s)
+
+  # ------------------------------------------------------- sparse heads ---
+  def _build_sparse_packs(self):
+    O, F = self.num_objs, self.num_frags
+    wc = self.ckpt['logits/%s/weights' % W.PRED_FRAG_CONF].reshape(256, O * F)
+    bc = self.ckpt['logits/%s/biases' % W.PRED_FRAG_CONF]
+    wl = self.ckpt['logits/%s/weights' % W.PRED_FRAG_LOC].reshape(256, O * F * 3)
+    bl = self.ckpt['logits/%s/biases' % W.PRED_FRAG_LOC]
+    packs = []
+    for o in range(O):
+      one_c, one_l = np.ones(F, np.float32), np.ones(3 * F, np.float32)
+      pc = self._pack_pointwise(wc[:, o * F:(o + 1) * F], one_c,
+                                bc[o * F:(o + 1) * F])
+      pl = self._pack_pointwise(wl[:, o * 3 * F:(o + 1) * 3 * F], one_l,
+                                bl[o * 3 * F:(o + 1) * 3 * F])
+      packs.append((pc, pl))
+    self._sparse_packs = packs
+
+  def run_sparse_heads(self, slots, slots_dev):
+    """Fragment heads (model.py:449-456) + fragment softmax (model.py:678) for the
+    given (image, obj_id) slots only: per slot one 256 -> F and one 256 -> 3F GEMM
+    writing the object's channel slice of the dense head buffers, as grouped
+    launches. Channels of other objects are left untouched (never read: the
+    correspondence stage only visits the slots, corresp.py:42-43).
+    slots_dev: int32 [S,2] device copy of ``slots`` for the softmax kernel."""
+    if self._sparse_packs is None:
+      self._build_sparse_packs()
+    O, F = self.num_objs, self.num_frags
+    P = self.out_h * self.out_w
+    x = self._decoder_x
+    conf, loc = self.logits[W.PRED_FRAG_CONF], self.logits[W.PRED_FRAG_LOC]
+    s = self._stream()
+    lib = self.lib
+    flops = 0
+    for kind in (0, 1):
+      probs = []
+      for im, obj_id in slots:
+        wp, bp, _ = self._sparse_packs[obj_id - 1][kind]
+        n = F if kind == 0 else 3 * F
+        buf = conf if kind == 0 else loc
+        ldc = O * n
+        probs.append(_lib.PointwiseArgs(
+            A=_ptr(x, im * P * 256), lda=256, Wp=_ptr(wp), bias=_ptr(bp), R=None,
+            ldr=0, C=_ptr(buf, im * P * ldc + (obj_id - 1) * n), ldc=ldc, M=P,
+            N=n, K=256, relu=0, relu_in=0, sub=1))
+        flops += 2 * P * n * 256
+      for i in range(0, len(probs), 8):
+        chunk = probs[i:i + 8]
+        arr = (_lib.PointwiseArgs * len(chunk))(*chunk)
+        _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, len(chunk), s),
+                   'sparse heads')
+    if slots:
+      _lib.check(lib.epos_softmax_slots_f32(_ptr(conf), _ptr(slots_dev),
+                                            len(slots), P, O, F, s),
+                 'softmax_slots')
+    return flops
 
   def set_images(self, images):
     """images: float32 [B,H,W,3] in [0,255] (host numpy or device tensor)."""
@@ -508,31 +588,39 @@ class EposNet(object):
       t = t.float()
     self.images.copy_(t.reshape(self.B, self.H, self.W, 3), non_blocking=True)
 
-  def capture_graph(self):
-    """Captures the whole plan into one hipGraph (stream capture)."""
+  def capture_graph(self, sparse=False):
+    """Captures the plan (dense, or the sparse-mode trunk) into one hipGraph."""
     torch.cuda.synchronize(self.dev)
     side = torch.cuda.Stream(self.dev)
     with torch.cuda.stream(side):
-      self.run_plan()                      # warm-up outside capture
+      self.run_plan(sparse=sparse)         # warm-up outside capture
     torch.cuda.synchronize(self.dev)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=side):
-      self.run_plan()
-    self._graph = g
+      self.run_plan(sparse=sparse)
+    if sparse:
+      self._graph_sparse = g
+    else:
+      self._graph = g
     return g
 
-  def forward(self, images=None, use_graph=False):
+  def forward(self, images=None, use_graph=False, sparse=False):
     """Runs the plan (logits + softmax/argmax post-ops) on the current stream and
     returns the prediction dict of ``model.predict`` (model.py:629-687) as views
     of the plan's HBM buffers (valid until the next forward)."""
     if images is not None:
       self.set_images(images)
     if use_graph:
-      if self._graph is None:
-        self.capture_graph()
-      self._graph.replay()
+      if sparse:
+        if self._graph_sparse is None:
+          self.capture_graph(sparse=True)
+        self._graph_sparse.replay()
+      else:
+        if self._graph is None:
+          self.capture_graph()
+        self._graph.replay()
     else:
-      self.run_plan()
+      self.run_plan(sparse=sparse)
     B, h, w = self.B, self.out_h, self.out_w
     O, F = self.num_objs, self.num_frags
     return {

@@ -37,7 +37,7 @@ class EposPipeline(object):
                model_store, fit_params=None, corr_min_obj_conf=0.1,
                corr_min_frag_rel_conf=0.5, max_slots=None, capacity=1 << 20,
                max_instances=4, model_options=None, device='cuda:0',
-               use_graph=True, instance=0):
+               use_graph=True, instance=0, sparse_heads=False):
     self.lib = _lib.load()
     self.dev = torch.device(device)
     self.B, self.H, self.W = batch, height, width
@@ -45,6 +45,11 @@ class EposPipeline(object):
     self.net = _model.get_net(checkpoint, batch, height, width, num_objs,
                               num_frags, model_options, device, instance)
     self.use_graph = use_graph
+    # sparse_heads: evaluate the fragment heads only for the (image, target
+    # object) slots of the batch instead of all O objects. Identical poses (the
+    # correspondence stage never reads another object's channels,
+    # corresp.py:42-43); the dense prediction dict is then NOT available.
+    self.sparse_heads = sparse_heads
     self.output_scale = 1.0 / 4            # decoder output stride 4 (infer.py:586-591)
     self.tau_a, self.tau_b = corr_min_obj_conf, corr_min_frag_rel_conf
     self.max_slots = max_slots or batch * num_objs
@@ -151,8 +156,9 @@ class EposPipeline(object):
     with torch.cuda.stream(self.stream):
       if timing:
         self._ev[0].record()
-      pred = self.net.forward(images, use_graph=self.use_graph)
-      if timing:
+      pred = self.net.forward(images, use_graph=self.use_graph,
+                              sparse=self.sparse_heads)
+      if timing and not self.sparse_heads:
         self._ev[1].record()
       if S:
         if S > self.max_slots:
@@ -169,6 +175,10 @@ class EposPipeline(object):
                                                             dtype=torch.int32)
         self.meta_dev.copy_(mh, non_blocking=True)          # one H2D
         self.corr.S = S
+        if self.sparse_heads:
+          self.head_flops = self.net.run_sparse_heads(slots, self.corr.slots)
+          if timing:
+            self._ev[1].record()
         self.corr.count(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
                         self.tau_a, self.tau_b)
         self.corr.fill(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],

@@ -156,6 +156,12 @@ typedef struct EposCorrSlot {
                         channel obj_id-1 of the fragment heads (corresp.py:46,60) */
 } EposCorrSlot;
 
+/* Fragment-confidence softmax (model.py:678) for the given slots only: X is the
+ * dense frag_conf buffer f32 [B, P, O, F]; slots [device]. Used by the sparse-head
+ * mode, where the fragment heads exist only for the target objects. */
+int epos_softmax_slots_f32(float* X, const EposCorrSlot* slots, int S, int P,
+                           int O, int F, void* stream);
+
 /* Pass 1+2: per slot, count masked pixels and correspondences and compute the
  * raster-order exclusive offsets. All buffers [device].
  *   obj_confs  f32 [B, P, O+1]      (P = h*w pixels of the head map)

@@ -52,3 +52,41 @@ def test_pipeline_matches_oracle_chain():
     assert (p['im_id'], p['obj_id']) == (im, obj_id)
     np.testing.assert_allclose(np.hstack([p['R'], p['t']]), rp[:3], atol=1e-9)
     np.testing.assert_allclose(p['score'], rs[0], rtol=1e-12)
+
+
+def test_sparse_heads_equal_dense_on_target_objects():
+  """Sparse-head mode evaluates the fragment heads only for the target objects;
+  those channels and the resulting poses must be bit-identical to the dense run."""
+  from epos_amd import model, pipeline, synthetic, weights
+  O, F, B, H, W_ = 6, 64, 2, 96, 128
+  ckpt = weights.random_init(num_objs=O, seed=8, randomize_bn=True)
+  store = Store(O, F)
+  img = np.stack([synthetic.image(i, H, W_) for i in range(B)])
+  net0 = model.get_net(ckpt, B, H, W_, O, F)
+  net0.forward(torch.from_numpy(img).cuda())
+  torch.cuda.synchronize()
+  synthetic.calibrate_logits(ckpt, net0.decoder_out[0].cpu().numpy())
+  model._NETS.clear()
+  Ks = np.tile(np.array([[300., 0, 64], [0, 300., 48], [0, 0, 1]]), (B, 1, 1))
+  targets = [{1: 1, 4: 2}, {6: 1}]
+  dense = pipeline.EposPipeline(ckpt, B, H, W_, O, F, store, capacity=1 << 18,
+                                instance=0)
+  sparse = pipeline.EposPipeline(ckpt, B, H, W_, O, F, store, capacity=1 << 18,
+                                 instance=1, sparse_heads=True)
+  x = torch.from_numpy(img).cuda()
+  pd, _ = dense.process_batch(x, Ks, targets, seed=2)
+  ps, _ = sparse.process_batch(x, Ks, targets, seed=2, timing=True)
+  assert len(pd) == len(ps) and len(pd) > 0
+  for a, b in zip(pd, ps):
+    assert a['obj_id'] == b['obj_id'] and a['score'] == b['score']
+    assert np.array_equal(a['R'], b['R']) and np.array_equal(a['t'], b['t'])
+  dc = dense.net.logits['pred_frag_conf'].view(B, -1, O, F)
+  sc = sparse.net.logits['pred_frag_conf'].view(B, -1, O, F)
+  dl = dense.net.logits['pred_frag_loc'].view(B, -1, O, F * 3)
+  sl = sparse.net.logits['pred_frag_loc'].view(B, -1, O, F * 3)
+  for im, t in enumerate(targets):
+    for obj in t:
+      assert torch.equal(dc[im, :, obj - 1], sc[im, :, obj - 1])
+      assert torch.equal(dl[im, :, obj - 1], sl[im, :, obj - 1])
+  assert torch.equal(dense.net.logits['pred_obj_conf'],
+                     sparse.net.logits['pred_obj_conf'])

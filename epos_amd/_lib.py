@@ -99,6 +99,11 @@ SYMBOLS = {
                                 [ctypes.POINTER(PointwiseArgs), vp]),
     'epos_pointwise_conv_grouped_f32': (ctypes.c_int, [
         ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp]),
+    'epos_pointwise_workspace_bytes': (ctypes.c_int64, []),
+    'epos_pointwise_conv_grouped_sk_f32': (ctypes.c_int, [
+        ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp, vp]),
+    'epos_pointwise_conv_grouped_ws_f32': (ctypes.c_int, [
+        ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp, vp]),
     'epos_depthwise3x3_f32': (ctypes.c_int,
                               [ctypes.POINTER(DepthwiseArgs), vp]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),

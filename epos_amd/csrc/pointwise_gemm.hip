@@ -572,6 +572,290 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_wp_f32(GroupedArgs ga_
 }
 
 // ---------------------------------------------------------------------------
+// Persistent stream-K variant. The data-parallel kernels above give every output
+// tile to one workgroup; with 450 tiles on 256 CUs (the 48 middle-flow layers)
+// some SIMDs get two tiles and some one, each workgroup pays its own launch /
+// first-load / epilogue cost, and hiding that needs a third wave per SIMD, which
+// slows the fp32 matrix pipe itself. Here the grid is FIXED at two
+// workgroups per CU (two MFMA waves per SIMD = the full-rate regime) and the
+// (tile, K tile) UNITS of all problems of the group are cut into equal contiguous
+// ranges, one per workgroup. A range that starts or ends inside a tile produces a
+// partial sum:
+//   * a workgroup whose range starts inside a tile handles that part FIRST, writes
+//     the partial accumulators to its slab and raises its flag (it never waits
+//     before doing so => no deadlock, whatever the dispatch order);
+//   * the workgroup that owns the tile's first K tile finishes it: it waits for the
+//     flags of the following workgroups, adds their slabs in workgroup order
+//     (deterministic), and runs the normal epilogue.
+// Hand-off = slab stores -> vmcnt(0) -> barrier -> one-lane agent-scope release ->
+// flag; consumer = relaxed poll -> one agent-scope acquire -> barrier -> plain
+// loads (cdna_hip_programming.md section 6, Guideline 16). Flags are reset by the
+// consumer, so a launch leaves them zero for the next one; launches that share a
+// workspace must be stream-ordered (one workspace per network plan).
+// ---------------------------------------------------------------------------
+struct SkArgs {
+  EposPointwiseArgs p[MAX_GROUP];
+  int unit_start[MAX_GROUP + 1];   // prefix sum of tiles * nk
+  int tiles_n[MAX_GROUP];
+  int npad[MAX_GROUP];
+  int nk[MAX_GROUP];
+  int count;
+  int workers;
+  float* slabs;                    // [workers][64 * 128]
+  int* flags;                      // [workers + 1] (last = error word)
+};
+
+constexpr int SK_BM = 64;
+constexpr int SK_SLAB = SK_BM * BN;          // floats
+
+template <bool RELU_IN, bool HAS_RES>
+__global__ __launch_bounds__(THREADS) void pointwise_gemm_sk_f32(SkArgs a_) {
+  constexpr int LDS_A_TILE = SK_BM * LDS_A_ROW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * LDS_A_TILE;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  (void)a_;
+  const SkArgs* __restrict__ gp = (const SkArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+
+  // logical worker id: workers of one XCD are consecutive in unit space
+  const int W = gp->workers;
+  int L;
+  {
+    const int raw = blockIdx.x, x = raw & 7, idx = raw >> 3;
+    const int q = W >> 3, r = W & 7;
+    L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  const int64_t U = gp->unit_start[MAX_GROUP];
+  const int64_t u_begin = static_cast<int64_t>(L) * U / W;
+  const int64_t u_end = static_cast<int64_t>(L + 1) * U / W;
+  float* my_slab = gp->slabs + static_cast<int64_t>(L) * SK_SLAB;
+
+  const int c4 = t & 7;
+  const int bn = t & 127, bq = t >> 7;
+  const int a_frag_off = (wm * 32 + l31) * LDS_A_ROW + h * 4;
+  const int b_frag_off = (h * BN + wn * 64 + l31) * 4;
+
+  for (int64_t u = u_begin; u < u_end;) {
+    // ---- decode the segment that starts at unit u ---------------------------
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i)
+      if (i < gp->count && u >= gp->unit_start[i]) pi = i;
+    const EposPointwiseArgs p = gp->p[pi];
+    const int nk = gp->nk[pi];
+    const int tiles_n = gp->tiles_n[pi];
+    const int npad = gp->npad[pi];
+    const int64_t ul = u - gp->unit_start[pi];
+    const int tile = static_cast<int>(ul / nk);
+    const int kt0 = static_cast<int>(ul - static_cast<int64_t>(tile) * nk);
+    const int64_t left = u_end - u;
+    const int kt1 = (nk - kt0) < left ? nk : kt0 + static_cast<int>(left);
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+    const int m0 = tile_m * SK_BM, n0 = tile_n * BN;
+    const int M = p.M, K = p.K;
+
+    const float* arow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = m0 + (t >> 3) + 32 * i;
+      m = m < M ? m : M - 1;
+      int64_t row = m;
+      if (p.sub > 1) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, rem = m - b * hw;
+        const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+        row = (static_cast<int64_t>(b) * p.Hi + yo * p.sub) * p.Wi + xo * p.sub;
+      }
+      arow[i] = p.A + row * p.lda + c4 * 4;
+    }
+    const float* wbase = p.Wp + (static_cast<int64_t>(bq) * npad + n0 + bn) * 4;
+    const int64_t wstep_q2 = static_cast<int64_t>(2) * npad * 4;
+    const int64_t wstep_tile = static_cast<int64_t>(8) * npad * 4;
+
+    struct Stage { float4 a0, a1, b0, b1, b2, b3; };
+    Stage S;
+    bool g_kin = true;
+    auto gload = [&](int kt, auto tail_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      int ko = kt * BK;
+      if (TAIL) {
+        g_kin = kt * BK + c4 * 4 < K;
+        ko = g_kin ? ko : 0;
+      }
+      S.a0 = *reinterpret_cast<const float4*>(arow[0] + ko);
+      S.a1 = *reinterpret_cast<const float4*>(arow[1] + ko);
+      const float* wp = wbase + kt * wstep_tile;
+      S.b0 = *reinterpret_cast<const float4*>(wp);
+      S.b1 = *reinterpret_cast<const float4*>(wp + wstep_q2);
+      S.b2 = *reinterpret_cast<const float4*>(wp + 2 * wstep_q2);
+      S.b3 = *reinterpret_cast<const float4*>(wp + 3 * wstep_q2);
+    };
+    auto swrite = [&](int buf, auto tail_tag) {
+      constexpr bool TAIL = decltype(tail_tag)::value;
+      auto fix = [&](float4 v) {
+        if (TAIL && !g_kin) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        return RELU_IN ? relu4(v) : v;
+      };
+      float* a = As + buf * LDS_A_TILE + (t >> 3) * LDS_A_ROW + c4 * 4;
+      *reinterpret_cast<float4*>(a) = fix(S.a0);
+      *reinterpret_cast<float4*>(a + 32 * LDS_A_ROW) = fix(S.a1);
+      float* b = Bs + buf * LDS_B_TILE + (bq * BN + bn) * 4;
+      *reinterpret_cast<float4*>(b) = S.b0;
+      *reinterpret_cast<float4*>(b + 2 * BN * 4) = S.b1;
+      *reinterpret_cast<float4*>(b + 4 * BN * 4) = S.b2;
+      *reinterpret_cast<float4*>(b + 6 * BN * 4) = S.b3;
+    };
+    float4 fa, fb[2];
+    auto read_frags = [&](int buf, int g) {
+      fa = *reinterpret_cast<const float4*>(As + buf * LDS_A_TILE + a_frag_off + g * 8);
+      const float* b_s = Bs + buf * LDS_B_TILE + b_frag_off + g * 2 * BN * 4;
+      fb[0] = *reinterpret_cast<const float4*>(b_s);
+      fb[1] = *reinterpret_cast<const float4*>(b_s + 32 * 4);
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // ---- K tiles [kt0, kt1) of this tile ------------------------------------
+    gload(kt0, std::true_type{});
+    swrite(0, std::true_type{});
+    __syncthreads();
+    read_frags(0, 0);
+    auto ktile = [&](int kt, auto has_next_tag, auto next_tail_tag) {
+      constexpr bool HAS_NEXT = decltype(has_next_tag)::value;
+      const int buf = (kt - kt0) & 1;
+      if (HAS_NEXT) {
+        gload(kt + 1, next_tail_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int kleft = K - kt * BK;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 ca = fa, cb0 = fb[0], cb1 = fb[1];
+        if (g < 3) {
+          read_frags(buf, g + 1);
+        } else if (HAS_NEXT) {
+          swrite(buf ^ 1, next_tail_tag);
+          __syncthreads();
+          read_frags(buf ^ 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (HAS_NEXT || g * 8 < kleft) {
+          const float* afp = reinterpret_cast<const float*>(&ca);
+          const float* b0p = reinterpret_cast<const float*>(&cb0);
+          const float* b1p = reinterpret_cast<const float*>(&cb1);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[s], b0p[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(afp[s], b1p[s], acc[1], 0, 0, 0);
+          }
+        }
+      }
+    };
+    {
+      using T = std::true_type;
+      using F = std::false_type;
+      int kt = kt0;
+      const int full_end = (kt1 - 1) < (nk - 2) ? (kt1 - 1) : (nk - 2);
+      for (; kt < full_end; ++kt) ktile(kt, T{}, F{});
+      if (kt < kt1 - 1) { ktile(kt, T{}, T{}); ++kt; }   // its next tile is the last
+      ktile(kt, F{}, F{});
+    }
+    __syncthreads();                      // LDS tiles are free from here on
+
+    // ---- finish the segment --------------------------------------------------
+    const bool head = kt0 == 0;
+    if (!head) {
+      // partial (tail / middle part of a tile): slab + flag, never waits
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          *reinterpret_cast<float4*>(my_slab + (((wave * 2 + j) * 4 + r4) * 64 + lane) * 4) =
+              make_float4(acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2],
+                          acc[j][4 * r4 + 3]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(gp->flags + L, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (kt1 < nk) {
+        // head of a split tile: add the partials of the following workers in order
+        const int64_t last_unit = gp->unit_start[pi] + static_cast<int64_t>(tile + 1) * nk - 1;
+        const int l_last = static_cast<int>(((last_unit + 1) * W + U - 1) / U) - 1;
+        for (int w = L + 1; w <= l_last; ++w) {
+          // workers with an empty unit range (more workers than units) own nothing
+          if (static_cast<int64_t>(w) * U / W >= static_cast<int64_t>(w + 1) * U / W) continue;
+          if (t == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(gp->flags + w, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) == 0) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > (1 << 24)) {          // never hang: flag an error instead
+                __hip_atomic_store(gp->flags + W, 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          __syncthreads();
+          const float* sl = gp->slabs + static_cast<int64_t>(w) * SK_SLAB;
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const float4 v = *reinterpret_cast<const float4*>(
+                  sl + (((wave * 2 + j) * 4 + r4) * 64 + lane) * 4);
+              acc[j][4 * r4] += v.x; acc[j][4 * r4 + 1] += v.y;
+              acc[j][4 * r4 + 2] += v.z; acc[j][4 * r4 + 3] += v.w;
+            }
+          __syncthreads();
+          if (t == 0)
+            __hip_atomic_store(gp->flags + w, 0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+      }
+      if (vec_epilogue_ok(p, HAS_RES)) {
+        float* ws = smem + wave * 32 * EP_ROW;
+        vec_epilogue<1, 2, HAS_RES>(ws, acc, p, m0 + wm * 32, n0 + wn * 64, lane);
+      } else {
+        const bool relu = p.relu != 0;
+        const int N = p.N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + wn * 64 + j * 32 + l31;
+          const int nc = n < N ? n : N - 1;
+          const float bias = p.bias ? p.bias[nc] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+            if (m < M && n < N) {
+              float v = acc[j][r] + bias;
+              if (HAS_RES) v += p.R[static_cast<int64_t>(m) * p.ldr + n];
+              if (relu) v = fmaxf(v, 0.f);
+              p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                      // epilogue staging done before the next prologue
+    u += kt1 - kt0;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // M <= 8 rows (the image-pooling branch, model.py:223-224, M = batch): a GEMV.
 // Block = 64 output channels x 4 K-slices; fixed-order LDS reduction.
 // ---------------------------------------------------------------------------
@@ -696,6 +980,50 @@ int launch_grouped_wp(const EposPointwiseArgs* args, int count, hipStream_t s) {
                  : launch_wp_t<false, false>(g, total, s);
 }
 
+constexpr int SK_WORKERS = 512;             // two workgroups per CU on 256 CUs
+
+template <bool RELU_IN, bool HAS_RES>
+int launch_sk_t(const SkArgs& a, hipStream_t s) {
+  constexpr int LDS_A_TILE = SK_BM * LDS_A_ROW;
+  // 2 workgroups per CU exactly: pad the LDS request so that a third one cannot fit
+  const size_t lds = 72 * 1024;
+  static_assert(sizeof(float) * (2 * LDS_A_TILE + 2 * LDS_B_TILE) <= 72 * 1024, "LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(pointwise_gemm_sk_f32<RELU_IN, HAS_RES>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((pointwise_gemm_sk_f32<RELU_IN, HAS_RES>), dim3(a.workers),
+                     dim3(THREADS), lds, s, a);
+  return launch_status("pointwise_gemm_sk_f32");
+}
+
+int launch_grouped_sk(const EposPointwiseArgs* args, int count, void* workspace,
+                      hipStream_t s) {
+  SkArgs a;
+  a.count = count;
+  int64_t units = 0;
+  for (int i = 0; i < count; ++i) {
+    a.p[i] = args[i];
+    a.npad[i] = static_cast<int>(round_up(args[i].N, BN));
+    a.tiles_n[i] = a.npad[i] / BN;
+    a.nk[i] = static_cast<int>(ceil_div(args[i].K, BK));
+    a.unit_start[i] = static_cast<int>(units);
+    units += ceil_div(args[i].M, SK_BM) * a.tiles_n[i] * a.nk[i];
+  }
+  for (int i = count; i <= MAX_GROUP; ++i) a.unit_start[i] = static_cast<int>(units);
+  a.workers = SK_WORKERS;
+  a.slabs = static_cast<float*>(workspace);
+  a.flags = reinterpret_cast<int*>(static_cast<char*>(workspace) +
+                                   sizeof(float) * SK_SLAB * SK_WORKERS);
+  const bool relu_in = args[0].relu_in != 0, has_res = args[0].R != nullptr;
+  if (relu_in)
+    return has_res ? launch_sk_t<true, true>(a, s) : launch_sk_t<true, false>(a, s);
+  return has_res ? launch_sk_t<false, true>(a, s) : launch_sk_t<false, false>(a, s);
+}
+
 }  // namespace
 }  // namespace epos
 
@@ -762,4 +1090,60 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
 
 extern "C" int epos_pointwise_conv_f32(const EposPointwiseArgs* a, void* stream) {
   return epos_pointwise_conv_grouped_f32(a, 1, stream);
+}
+
+extern "C" int64_t epos_pointwise_workspace_bytes(void) {
+  using namespace epos;
+  return static_cast<int64_t>(sizeof(float)) * SK_SLAB * SK_WORKERS + 4096;
+}
+
+extern "C" int epos_pointwise_conv_grouped_ws_f32(const EposPointwiseArgs* args,
+                                                  int count, void* workspace,
+                                                  void* stream) {
+  using namespace epos;
+  EPOS_REQUIRE(args && count >= 1 && count <= MAX_GROUP, "1..8 problems per group");
+  static const int use_sk = [] {
+    const char* e = getenv("EPOS_GEMM_SK");
+    return e ? atoi(e) : -1;
+  }();
+  int64_t units = 0;
+  int min_nk = 1 << 30, max_n = 0;
+  for (int i = 0; i < count; ++i) {
+    const int rc = validate(&args[i]);
+    if (rc) return rc;
+    EPOS_REQUIRE((args[i].relu_in != 0) == (args[0].relu_in != 0) &&
+                 (args[i].R != nullptr) == (args[0].R != nullptr),
+                 "problems of one group must agree on relu_in / residual");
+    const int nk = static_cast<int>(ceil_div(args[i].K, BK));
+    units += ceil_div(args[i].M, SK_BM) * ceil_div(args[i].N, BN) * nk;
+    min_nk = nk < min_nk ? nk : min_nk;
+    max_n = args[i].N > max_n ? args[i].N : max_n;
+  }
+  // Round-1 measurements: the persistent kernel wins on under-filled
+  // grids with long K (ASPP: 84 -> 71 us, N=1024: 88 -> 82 us) but loses on the 48
+  // middle-flow layers (61 -> 66 us: two exposed segment prologues + the slab hand-off
+  // per worker) and end to end (203 -> 176 images/s with three plans in flight, whose
+  // fixed 512-workgroup grids fight for the same CUs). It therefore stays opt-in
+  // (EPOS_GEMM_SK=1) until the cross-segment prefetch exists.
+  (void)units; (void)min_nk; (void)max_n;
+  const bool sk = workspace && use_sk == 1;
+  if (sk && units < (1LL << 31))
+    return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
+  return epos_pointwise_conv_grouped_f32(args, count, stream);
+}
+
+extern "C" int epos_pointwise_conv_grouped_sk_f32(const EposPointwiseArgs* args,
+                                                  int count, void* workspace,
+                                                  void* stream) {
+  using namespace epos;
+  EPOS_REQUIRE(args && workspace && count >= 1 && count <= MAX_GROUP,
+               "1..8 problems per group and a workspace");
+  for (int i = 0; i < count; ++i) {
+    const int rc = validate(&args[i]);
+    if (rc) return rc;
+    EPOS_REQUIRE((args[i].relu_in != 0) == (args[0].relu_in != 0) &&
+                 (args[i].R != nullptr) == (args[0].R != nullptr),
+                 "problems of one group must agree on relu_in / residual");
+  }
+  return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
 }

@@ -68,6 +68,10 @@ class EposNet(object):
     self.op_kind = {}        # 'gemm' | 'dw' | 'im2col' | 'other'
     self._graph = None
     self._graph_sparse = None
+    # Workspace of the persistent stream-K GEMM (partial-sum slabs + flags); one
+    # per plan, because launches sharing it must be ordered on one stream.
+    self._gemm_ws = torch.zeros(int(self.lib.epos_pointwise_workspace_bytes()),
+                                dtype=torch.uint8, device=self.dev)
     self._build_plan()
 
   # ------------------------------------------------------------ buffers ---
@@ -138,8 +142,11 @@ class EposNet(object):
       group.append((name, args, 2 * m * n * k))
       return
 
+    ws = _ptr(self._gemm_ws)
+
     def run(stream, args=args):
-      _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), stream), name)
+      _lib.check(lib.epos_pointwise_conv_grouped_ws_f32(ctypes.byref(args), 1, ws,
+                                                        stream), name)
     self._add(name, run, 2 * m * n * k, 'gemm')
 
   def _flush_group(self, group):
@@ -153,8 +160,10 @@ class EposNet(object):
     lib = self.lib
     n = len(group)
 
+    ws = _ptr(self._gemm_ws)
+
     def run(stream, arr=arr):
-      _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, n, stream), name)
+      _lib.check(lib.epos_pointwise_conv_grouped_ws_f32(arr, n, ws, stream), name)
     self._add(name, run, flops, 'gemm')
     del group[:]
 
@@ -573,8 +582,8 @@ class EposNet(object):
       for i in range(0, len(probs), 8):
         chunk = probs[i:i + 8]
         arr = (_lib.PointwiseArgs * len(chunk))(*chunk)
-        _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, len(chunk), s),
-                   'sparse heads')
+        _lib.check(lib.epos_pointwise_conv_grouped_ws_f32(
+            arr, len(chunk), _ptr(self._gemm_ws), s), 'sparse heads')
     if slots:
       _lib.check(lib.epos_softmax_slots_f32(_ptr(conf), _ptr(slots_dev),
                                             len(slots), P, O, F, s),

@@ -82,6 +82,21 @@ int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
 int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args, int count,
                                     void* stream);
 
+/* Persistent stream-K form of the grouped GEMM (experimental in round 1, opt-in):
+ * a fixed grid of two workgroups per CU, the (tile, K-tile) units of the group cut
+ * into equal contiguous ranges, tiles split between workgroups combined through
+ * partial-sum slabs in a deterministic order. `workspace` [device]:
+ * epos_pointwise_workspace_bytes() bytes, zero-initialised once by the caller;
+ * launches sharing a workspace must be ordered on one stream.
+ * epos_pointwise_conv_grouped_ws_f32 is what the network plan calls: it uses the
+ * stream-K kernel only when EPOS_GEMM_SK=1 is set and the data-parallel kernels
+ * otherwise (see DESIGN.md for the measurements behind that default). */
+int64_t epos_pointwise_workspace_bytes(void);
+int epos_pointwise_conv_grouped_sk_f32(const EposPointwiseArgs* args, int count,
+                                       void* workspace, void* stream);
+int epos_pointwise_conv_grouped_ws_f32(const EposPointwiseArgs* args, int count,
+                                       void* workspace, void* stream);
+
 /* Depthwise 3x3 conv + folded BatchNorm (+ optional ReLU before and after):
  * the depthwise half of net_xception.py:167-182 / model.py:80-88. stride 1 ->
  * TF 'SAME' (zero pad `rate`); stride 2 -> fixed_padding (net_xception.py:74-93)

@@ -242,3 +242,42 @@ def test_softmax_and_argmax(lib, g):
   np.testing.assert_allclose(out, ref, rtol=2e-6, atol=1e-7)
   assert np.array_equal(lab.cpu().numpy(), out.argmax(axis=1))
   assert lab[5].item() == 0
+
+
+@pytest.mark.parametrize('m,k,n,res', [(4800, 728, 728, 1), (4800, 2048, 256, 0),
+                                       (19200, 256, 1344, 0), (700, 736, 300, 0),
+                                       (5000, 64, 128, 0), (64, 4096, 128, 1)])
+def test_stream_k_gemm_matches_reference(lib, m, k, n, res, monkeypatch):
+  """Persistent stream-K kernel (opt-in in round 1) through its explicit entry
+  point: shapes with many / few units per worker, more workers than units, split
+  tiles with residual + ReLU; repeated launches reuse the self-resetting flags and
+  must be bit-identical (deterministic combine order)."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(m + n)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  bias = rng.standard_normal(n).astype(np.float32)
+  r = rng.standard_normal((m, n)).astype(np.float32)
+  npad = (n + 127) // 128 * 128
+  bpad = np.zeros(npad, np.float32); bpad[:n] = bias
+  A, Wp, Bd, R = (torch.from_numpy(a).cuda(), _pack(lib, w),
+                  torch.from_numpy(bpad).cuda(), torch.from_numpy(r).cuda())
+  ws = torch.zeros(int(lib.epos_pointwise_workspace_bytes()), dtype=torch.uint8,
+                   device='cuda')
+  ref = a.astype(np.float64) @ w.astype(np.float64) + bias
+  if res:
+    ref = np.maximum(ref + r, 0)
+  outs = []
+  for it in range(3):
+    C = torch.full((m, n), -7.0, device='cuda')
+    args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=_p(Bd),
+                              R=_p(R) if res else None, ldr=n, C=_p(C), ldc=n, M=m,
+                              N=n, K=k, relu=res, relu_in=0, sub=1)
+    _lib.check(lib.epos_pointwise_conv_grouped_sk_f32(ctypes.byref(args), 1, _p(ws),
+                                                      None))
+    torch.cuda.synchronize()
+    outs.append(C.cpu().numpy())
+    np.testing.assert_allclose(outs[-1], ref, rtol=1e-4, atol=1e-4)
+  assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+  flags = ws.cpu().numpy()[-4096:].view(np.int32)
+  assert not flags.any()              # flags self-reset, no error word

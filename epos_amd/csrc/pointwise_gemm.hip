@@ -925,6 +925,12 @@ int launch_grouped_t(const GroupedArgs& g, int total, hipStream_t s) {
     const size_t cap = (LDS_MAX / per_cu) & ~static_cast<size_t>(1023);
     if (cap > lds) lds = cap;
   }
+  static const int lds_kb = [] {            // EPOS_GEMM_LDS_KB=k: fixed LDS request
+    const char* e = getenv("EPOS_GEMM_LDS_KB");
+    return e ? atoi(e) : 0;
+  }();
+  if (lds_kb > 0 && static_cast<size_t>(lds_kb) * 1024 > lds && lds_kb <= 160)
+    lds = static_cast<size_t>(lds_kb) * 1024;
   hipLaunchKernelGGL((pointwise_gemm_f32<BM, RELU_IN, HAS_RES>), dim3(total),
                      dim3(THREADS), lds, s, g);
   return launch_status("pointwise_gemm_f32");

@@ -1,0 +1,260 @@
+"""TFRecord / ``tf.Example`` input without TensorFlow -- the reader side of the
+reference's input pipeline for inference (``datagen.Dataset``:
+``_parse_example_proto`` datagen.py:384-422, ``_parse_and_preprocess`` :424-476,
+GT filtering :545-575; records written by scripts/create_tfrecord.py:187-210 with
+the helpers of epos_lib/tfrecord.py).
+
+PARITY UNPINNED: TensorFlow is not installable here and the tree holds no
+``.tfrecord`` file, so this module is checked by round trips through its own
+writer only (tests/test_tfrecord.py). The formats are the public ones:
+  * TFRecord framing: u64 length | u32 masked-crc32c(length) | data |
+    u32 masked-crc32c(data), little endian;
+  * ``tf.train.Example`` protobuf: Example{1: Features{1: map<string, Feature>}},
+    Feature{1: BytesList, 2: FloatList, 3: Int64List}, each ``repeated value = 1``
+    (float / int64 lists packed or unpacked).
+
+Image decoding uses PIL (JPEG / PNG). Resizing of frames taller than
+``infer_max_height_before_crop`` (misc.py:79-93: area / bilinear with
+align_corners) is NOT reproduced -- YCB-V, LM-O and the T-LESS crops used by EPOS
+need none; such records raise.
+"""
+import io
+import struct
+
+import numpy as np
+
+# ---------------------------------------------------------------- crc32c ----
+_CRC_TABLE = None
+
+
+def _crc32c(data):
+  global _CRC_TABLE
+  if _CRC_TABLE is None:
+    tab = []
+    for i in range(256):
+      c = i
+      for _ in range(8):
+        c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+      tab.append(c)
+    _CRC_TABLE = tab
+  crc = 0xFFFFFFFF
+  tab = _CRC_TABLE
+  for b in data:
+    crc = tab[(crc ^ b) & 0xFF] ^ (crc >> 8)
+  return crc ^ 0xFFFFFFFF
+
+
+def _masked_crc(data):
+  crc = _crc32c(data)
+  return (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ------------------------------------------------------------- framing ------
+def read_records(path, verify_crc=False):
+  """Yields the raw byte string of every record of a .tfrecord file."""
+  with open(path, 'rb') as f:
+    while True:
+      head = f.read(12)
+      if not head:
+        return
+      if len(head) < 12:
+        raise IOError('truncated TFRecord header in %s' % path)
+      length, len_crc = struct.unpack('<QI', head)
+      if verify_crc and _masked_crc(head[:8]) != len_crc:
+        raise IOError('corrupt TFRecord length in %s' % path)
+      data = f.read(length)
+      tail = f.read(4)
+      if len(data) < length or len(tail) < 4:
+        raise IOError('truncated TFRecord in %s' % path)
+      if verify_crc and _masked_crc(data) != struct.unpack('<I', tail)[0]:
+        raise IOError('corrupt TFRecord data in %s' % path)
+      yield data
+
+
+def write_records(path, records):
+  with open(path, 'wb') as f:
+    for data in records:
+      head = struct.pack('<Q', len(data))
+      f.write(head + struct.pack('<I', _masked_crc(head)))
+      f.write(data + struct.pack('<I', _masked_crc(data)))
+
+
+# ------------------------------------------------------------ protobuf ------
+def _varint(buf, pos):
+  result, shift = 0, 0
+  while True:
+    b = buf[pos]
+    pos += 1
+    result |= (b & 0x7F) << shift
+    if not b & 0x80:
+      return result, pos
+    shift += 7
+
+
+def _fields(buf):
+  """Yields (field number, wire type, value) of one protobuf message."""
+  pos, n = 0, len(buf)
+  while pos < n:
+    key, pos = _varint(buf, pos)
+    num, wt = key >> 3, key & 7
+    if wt == 0:
+      val, pos = _varint(buf, pos)
+    elif wt == 1:
+      val = buf[pos:pos + 8]
+      pos += 8
+    elif wt == 2:
+      ln, pos = _varint(buf, pos)
+      val = buf[pos:pos + ln]
+      pos += ln
+    elif wt == 5:
+      val = buf[pos:pos + 4]
+      pos += 4
+    else:
+      raise ValueError('unsupported protobuf wire type %d' % wt)
+    yield num, wt, val
+
+
+def _parse_feature(buf):
+  for num, wt, val in _fields(buf):
+    if num == 1:                                   # BytesList
+      return [bytes(v) for n, _, v in _fields(val) if n == 1]
+    if num == 2:                                   # FloatList
+      out = []
+      for n, w, v in _fields(val):
+        if n != 1:
+          continue
+        if w == 2:
+          out += list(struct.unpack('<%df' % (len(v) // 4), v))
+        else:
+          out.append(struct.unpack('<f', v)[0])
+      return out
+    if num == 3:                                   # Int64List
+      out = []
+      for n, w, v in _fields(val):
+        if n != 1:
+          continue
+        if w == 2:
+          p = 0
+          while p < len(v):
+            x, p = _varint(v, p)
+            out.append(x - (1 << 64) if x >> 63 else x)
+        else:
+          out.append(v - (1 << 64) if v >> 63 else v)
+      return out
+  return []
+
+
+def parse_example(data):
+  """Serialized tf.train.Example -> {feature key: list of bytes / float / int}."""
+  feats = {}
+  for num, _, features in _fields(data):
+    if num != 1:
+      continue
+    for fnum, _, entry in _fields(features):
+      if fnum != 1:
+        continue
+      key, value = None, b''
+      for n, _, v in _fields(entry):
+        if n == 1:
+          key = bytes(v).decode('utf-8')
+        elif n == 2:
+          value = v
+      if key is not None:
+        feats[key] = _parse_feature(value)
+  return feats
+
+
+def _enc_varint(x):
+  x &= (1 << 64) - 1
+  out = bytearray()
+  while True:
+    b = x & 0x7F
+    x >>= 7
+    if x:
+      out.append(b | 0x80)
+    else:
+      out.append(b)
+      return bytes(out)
+
+
+def _enc_ld(num, payload):
+  return _enc_varint((num << 3) | 2) + _enc_varint(len(payload)) + payload
+
+
+def encode_example(features):
+  """{key: list of bytes | float | int} -> serialized tf.train.Example (what
+  tf.train.Example(...).SerializeToString() produces for the same content)."""
+  entries = b''
+  for key in sorted(features):
+    vals = features[key]
+    if not isinstance(vals, (list, tuple)):
+      vals = [vals]
+    if vals and isinstance(vals[0], (bytes, str)):
+      body = b''.join(_enc_ld(1, v.encode() if isinstance(v, str) else v)
+                      for v in vals)
+      feat = _enc_ld(1, body)
+    elif vals and isinstance(vals[0], float):
+      feat = _enc_ld(2, _enc_ld(1, struct.pack('<%df' % len(vals), *vals)))
+    else:
+      feat = _enc_ld(3, _enc_ld(1, b''.join(_enc_varint(int(v)) for v in vals)))
+    entries += _enc_ld(1, _enc_ld(1, key.encode()) + _enc_ld(2, feat))
+  return _enc_ld(1, entries)
+
+
+# ------------------------------------------------------- sample decoding ----
+def _scalar(feats, key, default):
+  v = feats.get(key)
+  return v[0] if v else default
+
+
+def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
+                  min_visib_fract=0.1):
+  """One parsed Example -> the inference sample of datagen.py:424-476,545-575:
+  dict(scene_id, im_id, image_path, image f32[crop_h, crop_w, 3], K f64[3,3],
+  gt_obj_ids list). crop_size = (width, height) as the reference consumes it
+  (datagen.py:448-449). The crop offset is 0 (the reference draws it at random
+  when the frame is larger than the crop, datagen.py:451-455)."""
+  from PIL import Image
+  im = np.asarray(Image.open(io.BytesIO(feats['image/encoded'][0])).convert('RGB'),
+                  dtype=np.float32)
+  h_orig = int(_scalar(feats, 'image/height', im.shape[0]))
+  w_orig = int(_scalar(feats, 'image/width', im.shape[1]))
+  h_new = min(max_height_before_crop, h_orig)
+  scale = np.float32(h_new) / np.float32(h_orig)
+  w_new = int(np.float32(w_orig) * scale)
+  if h_new != h_orig:
+    raise NotImplementedError(
+        'frame height %d > infer_max_height_before_crop %d: the area / bilinear '
+        'resize of misc.py:79-93 is not reproduced' % (h_orig, max_height_before_crop))
+  crop_w, crop_h = crop_size
+  if crop_h > h_new or crop_w > w_new:
+    raise ValueError('crop %dx%d larger than the frame %dx%d' % (
+        crop_w, crop_h, w_new, h_new))
+  im = im[:crop_h, :crop_w]
+  fx = np.float32(_scalar(feats, 'image/camera/fx', -1.0)) * scale
+  fy = np.float32(_scalar(feats, 'image/camera/fy', -1.0)) * scale
+  cx = np.float32(_scalar(feats, 'image/camera/cx', -1.0)) * scale
+  cy = np.float32(_scalar(feats, 'image/camera/cy', -1.0)) * scale
+  K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
+  ids = [int(x) for x in feats.get('image/object/id', [])]
+  vis = list(feats.get('image/object/visibility', [1.0] * len(ids)))
+  keep = [i for i, o in enumerate(ids)
+          if (obj_ids is None or o in obj_ids) and          # datagen.py:545-553
+          (min_visib_fract is None or vis[i] >= min_visib_fract)]   # :555-575
+  path = _scalar(feats, 'image/path', b'')
+  return {
+      'scene_id': int(_scalar(feats, 'image/scene_id', -1)),
+      'im_id': int(_scalar(feats, 'image/im_id', -1)),
+      'image_path': path.decode('utf-8') if isinstance(path, bytes) else path,
+      'image': np.ascontiguousarray(im), 'K': K,
+      'gt_obj_ids': [ids[i] for i in keep],
+  }
+
+
+def load_samples(path, crop_size, max_height_before_crop=480, obj_ids=None,
+                 min_visib_fract=0.1, verify_crc=False):
+  """Iterates the inference samples of one .tfrecord file in file order (the
+  reference keeps reading sequential at inference, datagen.py:680-683)."""
+  for rec in read_records(path, verify_crc):
+    yield decode_sample(parse_example(rec), crop_size, max_height_before_crop,
+                        obj_ids, min_visib_fract)

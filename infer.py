@@ -15,11 +15,12 @@ Same contract as the reference script:
   * poses written to <model>/infer/estimated-poses[_<infer_name>].csv in BOP'19
     format (infer.py:753-760); optional corr_*/NNNNNN_corr_OO.txt (infer.py:294-345).
 
-Input frames: the reference reads TFRecords through TensorFlow, which is not
-available here (TFRecord reading is a "next" item). Frames come
-from ``--frames <dir>`` holding ``frames.json`` (list of {scene_id, im_id, path,
-K[9], targets {obj_id: count}}) + images (.npy HxWx3 or anything PIL reads), or
-from ``--synthetic N`` seeded synthetic frames.
+Input frames: ``--infer_tfrecord_names a,b`` reads <TF_DATA_PATH>/<name>.tfrecord
+like the reference (infer.py:581-583) but without TensorFlow (epos_amd/tfrecord.py:
+TFRecord framing + tf.Example parsing + PIL decoding; frames that would need the
+reference's resize raise). Alternatively ``--frames <dir>`` holding ``frames.json``
+(list of {scene_id, im_id, path, K[9], targets {obj_id: count}}) + images (.npy
+HxWx3 or anything PIL reads), or ``--synthetic N`` seeded synthetic frames.
 
 Reference quirks kept on purpose: only the *localization* task has targets (the
 reference dereferences gt_poses=None in detection mode, infer.py:400); here
@@ -87,6 +88,7 @@ def build_parser():
   # epos_lib/common.py:60-154 (the model flags the hot path reads)
   a('--dataset', default=None)
   a('--num_frags', type=int, default=64)
+  a('--min_visib_fract', type=float, default=0.1)
   a('--corr_min_obj_conf', type=float, default=0.1)
   a('--corr_min_frag_rel_conf', type=float, default=0.5)
   a('--model_variant', default='xception_65')
@@ -155,13 +157,36 @@ def find_checkpoint(checkpoint_dir, name):
   return cands[-1] if cands else None
 
 
-def load_frames(args, num_objs, rank, world):
+def load_frames(args, num_objs, rank, world, store_obj_ids=None):
   """Returns this rank's list of (scene_id, im_id, image f32[H,W,3], K, targets)."""
   w, h = [int(x) for x in str(args.infer_crop_size).split(',')][:2] \
       if not isinstance(args.infer_crop_size, (list, tuple)) \
       else args.infer_crop_size[:2]
   frames = []
-  if args.frames:
+  if args.infer_tfrecord_names:
+    # <TF_DATA_PATH>/<name>.tfrecord for each name (infer.py:581-583,
+    # datagen.py:707-723), read without TensorFlow (epos_amd/tfrecord.py).
+    from epos_amd import tfrecord
+    names = args.infer_tfrecord_names
+    if not isinstance(names, (list, tuple)):
+      names = [n for n in str(names).split(',') if n]
+    data_path = os.environ.get('TF_DATA_PATH', '.')
+    obj_ids = store_obj_ids if store_obj_ids else None
+    all_samples = []
+    for name in names:
+      path = os.path.join(data_path, name + '.tfrecord')
+      if not os.path.exists(path):
+        raise ValueError('No input files: {}'.format(path))   # datagen.py:720-721
+      all_samples += list(tfrecord.load_samples(
+          path, (w, h), args.infer_max_height_before_crop, obj_ids,
+          args.min_visib_fract))
+    b, e = edist.shard_range(len(all_samples), rank, world)
+    for sm in all_samples[b:e]:
+      tg = {}
+      for o in sm['gt_obj_ids']:             # instance counts, infer.py:462-463
+        tg[o] = tg.get(o, 0) + 1
+      frames.append((sm['scene_id'], sm['im_id'], sm['image'], sm['K'], tg))
+  elif args.frames:
     meta = json.load(open(os.path.join(args.frames, 'frames.json')))
     b, e = edist.shard_range(len(meta), rank, world)
     for m in meta[b:e]:
@@ -186,8 +211,8 @@ def load_frames(args, num_objs, rank, world):
                      synthetic.targets(i, num_objs, 5)))
   else:
     raise ValueError(
-        'No input files: give --frames <dir> or --synthetic N (TFRecord input, '
-        'datagen.py:707-723, needs TensorFlow and is a "next" item).')
+        'No input files: give --infer_tfrecord_names, --frames <dir> or '
+        '--synthetic N.')
   return frames, h, w
 
 
@@ -305,7 +330,8 @@ def main(argv=None):
       raise ValueError('fragments.pkl / fragments.npz not found in ' + model_dir)
     store = synthetic.ModelStore(num_objs, args.num_frags, seed=0)
 
-  frames, h, w = load_frames(args, num_objs, rank, world)
+  frames, h, w = load_frames(args, num_objs, rank, world,
+                            store.dp_model['obj_ids'])
   atrous = [int(x) for x in str(args.atrous_rates).strip('[]').split(',')]
   mo = model.ModelOptions(
       model.get_outputs_to_num_channels(num_objs, args.num_frags),

@@ -79,3 +79,39 @@ def test_infer_operator_path_with_max_correspondences(tmp_path):
       env=env, capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stdout + out.stderr
   assert (tmp_path / 'toy' / 'infer' / 'estimated-poses.csv').exists()
+
+
+@pytest.mark.gpu
+def test_infer_from_tfrecord(tmp_path):
+  """--infer_tfrecord_names path: records written with the build's own encoder
+  (the reference writes them with TensorFlow, scripts/create_tfrecord.py)."""
+  import io
+  from PIL import Image
+  from epos_amd import bop_io, tfrecord
+  data = tmp_path / 'data'
+  models = tmp_path / 'models'
+  data.mkdir(); (models / 'toy').mkdir(parents=True)
+  (models / 'toy' / 'params.yml').write_text('infer_crop_size: "128,96"\n')
+  rng = np.random.RandomState(0)
+  recs = []
+  for i in range(2):
+    buf = io.BytesIO()
+    Image.fromarray(rng.randint(0, 256, (96, 128, 3)).astype(np.uint8)).save(
+        buf, format='PNG')
+    recs.append(tfrecord.encode_example({
+        'image/scene_id': [3], 'image/im_id': [i], 'image/path': [b'x.png'],
+        'image/encoded': [buf.getvalue()], 'image/height': [96],
+        'image/width': [128], 'image/channels': [3],
+        'image/camera/fx': [300.0], 'image/camera/fy': [300.0],
+        'image/camera/cx': [64.0], 'image/camera/cy': [48.0],
+        'image/object/id': [1, 2, 2], 'image/object/visibility': [0.9, 0.8, 0.7]}))
+  tfrecord.write_records(str(data / 'toy_test.tfrecord'), recs)
+  env = dict(os.environ, TF_MODELS_PATH=str(models), TF_DATA_PATH=str(data))
+  out = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'infer.py'), '--model=toy',
+       '--infer_tfrecord_names', 'toy_test', '--synthetic', '1', '--num_objs',
+       '3'], env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout + out.stderr
+  res = bop_io.load_bop_results(str(models / 'toy' / 'infer' /
+                                    'estimated-poses.csv'))
+  assert all(r['scene_id'] == 3 and r['obj_id'] in (1, 2) for r in res)

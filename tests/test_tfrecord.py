@@ -1,0 +1,91 @@
+"""TFRecord / tf.Example reader (epos_amd/tfrecord.py): framing CRCs against the
+published CRC-32C check value, protobuf round trips, sample decoding (K scaling,
+visibility / dataset filtering of datagen.py:545-575). PARITY UNPINNED vs
+TensorFlow (not installable); formats are the public ones."""
+import io
+import struct
+
+import numpy as np
+import pytest
+
+from epos_amd import tfrecord
+
+
+def test_crc32c_known_answer():
+  # RFC 3720 / Castagnoli check value for "123456789".
+  assert tfrecord._crc32c(b'123456789') == 0xE3069283
+  assert tfrecord._crc32c(b'') == 0
+
+
+def _png_bytes(arr):
+  from PIL import Image
+  buf = io.BytesIO()
+  Image.fromarray(arr).save(buf, format='PNG')
+  return buf.getvalue()
+
+
+def _example(scene_id, im_id, img, ids, vis):
+  return {
+      'image/scene_id': [scene_id], 'image/im_id': [im_id],
+      'image/path': [b'scene/rgb/000001.png'], 'image/encoded': [_png_bytes(img)],
+      'image/height': [img.shape[0]], 'image/width': [img.shape[1]],
+      'image/channels': [3],
+      'image/camera/fx': [1066.778], 'image/camera/fy': [1067.487],
+      'image/camera/cx': [312.9869], 'image/camera/cy': [241.3109],
+      'image/object/id': ids, 'image/object/visibility': [float(v) for v in vis],
+      'image/object/pose/t3': [float(900 + i) for i in range(len(ids))],
+  }
+
+
+def test_example_roundtrip_and_negative_int():
+  feats = {'a': [1, -2, 3 << 40], 'b': [0.5, -1.25], 'c': [b'xy', b''],
+           'd': [7]}
+  back = tfrecord.parse_example(tfrecord.encode_example(feats))
+  assert back['a'] == [1, -2, 3 << 40] and back['d'] == [7]
+  assert back['b'] == [0.5, -1.25] and back['c'] == [b'xy', b'']
+
+
+def test_unpacked_repeated_fields_are_accepted():
+  # FloatList / Int64List written unpacked (one tag per value) must parse too.
+  f32 = struct.pack('<f', 2.5)
+  float_list = b'\x0d' + f32 + b'\x0d' + struct.pack('<f', -1.0)   # field 1, wt 5
+  feature = tfrecord._enc_ld(2, float_list)
+  entry = tfrecord._enc_ld(1, b'k') + tfrecord._enc_ld(2, feature)
+  ex = tfrecord._enc_ld(1, tfrecord._enc_ld(1, entry))
+  assert tfrecord.parse_example(ex) == {'k': [2.5, -1.0]}
+
+
+def test_tfrecord_file_roundtrip_and_corruption(tmp_path):
+  rng = np.random.RandomState(0)
+  imgs = [rng.randint(0, 256, (480, 640, 3)).astype(np.uint8) for _ in range(2)]
+  exs = [_example(48, i + 1, imgs[i], [2, 5, 99], [0.9, 0.05, 0.8])
+         for i in range(2)]
+  path = str(tmp_path / 'ycbv_test.tfrecord')
+  tfrecord.write_records(path, [tfrecord.encode_example(e) for e in exs])
+  samples = list(tfrecord.load_samples(path, (640, 480), 480,
+                                       obj_ids=list(range(1, 22)),
+                                       verify_crc=True))
+  assert len(samples) == 2
+  s = samples[1]
+  assert (s['scene_id'], s['im_id']) == (48, 2)
+  assert s['image'].dtype == np.float32 and s['image'].shape == (480, 640, 3)
+  assert np.array_equal(s['image'], imgs[1].astype(np.float32))
+  np.testing.assert_allclose(s['K'], [[1066.778, 0, 312.9869],
+                                      [0, 1067.487, 241.3109], [0, 0, 1]],
+                             rtol=1e-6)
+  assert s['gt_obj_ids'] == [2]        # 5: visibility < 0.1, 99: not in the dataset
+  raw = bytearray(open(path, 'rb').read())
+  raw[40] ^= 0xFF
+  open(path, 'wb').write(bytes(raw))
+  with pytest.raises(IOError):
+    list(tfrecord.read_records(path, verify_crc=True))
+
+
+def test_oversized_frame_raises(tmp_path):
+  img = np.zeros((540, 720, 3), np.uint8)
+  feats = tfrecord.parse_example(tfrecord.encode_example(
+      _example(1, 1, img, [1], [1.0])))
+  with pytest.raises(NotImplementedError):
+    tfrecord.decode_sample(feats, (640, 480), 480)
+  s = tfrecord.decode_sample(feats, (720, 540), 540)
+  assert s['image'].shape == (540, 720, 3)

@@ -9,8 +9,10 @@ Same contract as the reference script:
   * env TF_DATA_PATH / TF_MODELS_PATH / BOP_PATH (config.py:9-16);
   * <TF_MODELS_PATH>/<model>/params.yml overrides flag defaults (common.py:157-177,
     list-valued crop sizes parsed from "w,h" strings);
-  * weights from <model>/train/ -- here a ``.npz`` keyed by the TF variable names
-    (latest ``*.npz`` or --checkpoint_name); fragments from <model>/fragments.pkl
+  * weights from <model>/train/ -- the TensorFlow checkpoint itself
+    (model.ckpt-N.index/.data-*, latest or --checkpoint_name, read without
+    TensorFlow by epos_amd/tf_checkpoint.py) or an ``.npz`` keyed by the TF
+    variable names; fragments from <model>/fragments.pkl
     (datagen.py:254-268) or <model>/fragments.npz;
   * poses written to <model>/infer/estimated-poses[_<infer_name>].csv in BOP'19
     format (infer.py:753-760); optional corr_*/NNNNNN_corr_OO.txt (infer.py:294-345).
@@ -315,7 +317,20 @@ def main(argv=None):
   torch.cuda.set_device(local_rank)
 
   ckpt_path = find_checkpoint(checkpoint_dir, args.checkpoint_name)
-  if ckpt_path and os.path.exists(ckpt_path):
+  tf_prefix = None
+  if args.checkpoint_name is not None and os.path.exists(
+      os.path.join(checkpoint_dir, args.checkpoint_name + '.index')):
+    tf_prefix = os.path.join(checkpoint_dir, args.checkpoint_name)
+  elif not (ckpt_path and os.path.exists(ckpt_path)):
+    from epos_amd import tf_checkpoint
+    tf_prefix = tf_checkpoint.latest_checkpoint(checkpoint_dir)  # infer.py:670-674
+  if tf_prefix is not None:
+    # A TensorFlow checkpoint (model.ckpt-N.index/.data-*), read without TF.
+    from epos_amd import tf_checkpoint
+    ckpt = tf_checkpoint.to_epos_checkpoint(
+        tf_checkpoint.load_checkpoint(tf_prefix))
+    num_objs = ckpt['logits/pred_obj_conf/biases'].shape[0] - 1
+  elif ckpt_path and os.path.exists(ckpt_path):
     ckpt = weights.load_npz(ckpt_path)
     num_objs = ckpt['logits/pred_obj_conf/biases'].shape[0] - 1
   elif args.synthetic:

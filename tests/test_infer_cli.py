@@ -115,3 +115,27 @@ def test_infer_from_tfrecord(tmp_path):
   res = bop_io.load_bop_results(str(models / 'toy' / 'infer' /
                                     'estimated-poses.csv'))
   assert all(r['scene_id'] == 3 and r['obj_id'] in (1, 2) for r in res)
+
+
+@pytest.mark.gpu
+def test_infer_restores_tf_checkpoint(tmp_path):
+  """<model>/train/model.ckpt-N.{index,data-*} is restored by variable name
+  (infer.py:670-683) through the TensorFlow-free TensorBundle reader."""
+  from epos_amd import tf_checkpoint, weights
+  models = tmp_path
+  (models / 'toy' / 'train').mkdir(parents=True)
+  (models / 'toy' / 'params.yml').write_text('infer_crop_size: "128,96"\n')
+  ckpt = weights.random_init(num_objs=3, seed=5, randomize_bn=True)
+  ckpt['global_step'] = np.asarray(7, np.int64)
+  tf_checkpoint.write_checkpoint(str(models / 'toy' / 'train' / 'model.ckpt-7'),
+                                 ckpt)
+  rng = np.random.RandomState(0)
+  np.savez(str(models / 'toy' / 'fragments.npz'), obj_ids=np.arange(1, 4),
+           frag_centers=rng.uniform(-50, 50, (3, 64, 3)),
+           frag_sizes=rng.uniform(5, 30, (3, 64)))
+  env = dict(os.environ, TF_MODELS_PATH=str(models))
+  out = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'infer.py'), '--model=toy',
+       '--synthetic', '1'], env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout + out.stderr
+  assert (models / 'toy' / 'infer' / 'estimated-poses.csv').exists()

@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                   on this host on a bounded sample (N=1, rank 0 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -33,6 +34,7 @@ if ROOT not in sys.path:
 
 from epos_amd import dist as edist          # noqa: E402
 from epos_amd import pipeline, synthetic, weights   # noqa: E402
+from epos_amd import _lib                   # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 roof
 ALGO_GFLOP_C2 = 455.0           # SURVEY.md App. A, per image
@@ -212,12 +214,16 @@ def main():
     pool.append((torch.from_numpy(imgs).to(dev), tg, idx))
   Ks = np.tile(synthetic.YCBV_K, (B, 1, 1))
   max_records = B * args.objs_per_image * 2
+  lib = _lib.load()
+  clk = torch.zeros((64, 2), dtype=torch.int64, device=dev)
+  clk_stream = None      # created after the timed region (an extra stream changes
+                         # the stream -> hardware-queue mapping of the pipelines)
 
   def finish(p):
     poses, _ = p.collect()
     return len(edist.gather_poses(poses, max_records))
 
-  def run(first, count):
+  def run(first, count, probe=False):
     """`count` steps; step i is launched on pipes[i % depth] after the step that
     used that pipeline `depth` steps earlier has been collected. Returns the
     number of poses; every step is complete (poses on the host) on return."""
@@ -229,6 +235,10 @@ def main():
       imgs, tg, idx = pool[i % n_pool]
       p.launch(imgs, Ks, tg, image_ids=idx, seed=i)
       inflight.append(p)
+      if probe:
+        _lib.check(lib.epos_clock_probe(
+            ctypes.c_void_p(clk[i % clk.shape[0]].data_ptr()), 200,
+            ctypes.c_void_p(clk_stream.cuda_stream)), 'clock_probe')
     while inflight:
       n += finish(inflight.pop(0))
     return n
@@ -273,8 +283,20 @@ def main():
           'algorithmic_gflop_per_image': round(pipe.net.flops / B / 1e9, 1),
       },
   }
+  # shader clock under the same load: a few extra steps with a spinning probe wave
+  # on a side stream (the fp32 MFMA roof is 64 FLOP/clk/SIMD x this clock)
+  clk_stream = torch.cuda.Stream(device=dev)
+  run(args.warmup + args.steps, min(10, args.steps), probe=True)
+  torch.cuda.synchronize()
+  clk_h = clk.cpu().numpy()
+  clk_h = clk_h[clk_h[:, 1] > 0]
+  core_mhz = float((clk_h[:, 0] / clk_h[:, 1]).mean() * 100.0) if len(clk_h) else None
   if rank == 0 and not args.no_roofline:
     roof, _ = gemm_roofline(pipe, max(2, min(args.steps, 5)))
+    if core_mhz:
+      # sampled in extra steps after the timed region; peak stays the 2.4 GHz figure
+      roof['core_clock_mhz_under_load'] = round(core_mhz, 0)
+      roof['peak_at_measured_clock'] = round(64 * 1024 * core_mhz * 1e6 / 1e12, 1)
     roof['end_to_end_tflops'] = round(value / world * pipe.net.flops / B / 1e12, 2)
     gemm_gflop = roof['gflop_per_image']
     if args.sparse_heads:     # flops actually executed, not the dense plan's

@@ -93,6 +93,7 @@ SYMBOLS = {
     'epos_abi_version': (ctypes.c_int, []),
     'epos_last_error': (ctypes.c_char_p, []),
     'epos_device_count': (ctypes.c_int, []),
+    'epos_clock_probe': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'epos_pack_pointwise_weights': (ctypes.c_int64,
                                     [vp, ctypes.c_int, ctypes.c_int, vp]),
     'epos_pointwise_conv_f32': (ctypes.c_int,

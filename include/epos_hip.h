@@ -39,6 +39,11 @@ int epos_abi_version(void);
 const char* epos_last_error(void);
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int epos_device_count(void);
+/* Measurement aid (bench.py): a one-wave kernel on `stream` that spins for
+ * `microseconds` and writes {shader-clock cycles, 100 MHz ticks} to the DEVICE
+ * buffer out2[2] -- cycles / ticks * 100 = the core clock in MHz while the
+ * surrounding work runs (the fp32 MFMA roof scales with it). */
+int epos_clock_probe(int64_t* out2, int microseconds, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Network layers (replace the TF1.12 ops that model.py / net_xception.py lower

@@ -6,6 +6,8 @@ import numpy as np, torch
 from epos_amd import _lib
 lib = _lib.load()
 USE_WS = os.environ.get('BENCH_WS', '0') == '1'
+RELU_IN = int(os.environ.get('BENCH_RELU_IN', '0'))
+CHECK = os.environ.get('BENCH_CHECK', '1') == '1'
 WS = torch.zeros(int(lib.epos_pointwise_workspace_bytes()), dtype=torch.uint8, device='cuda')
 def p(t): return ctypes.c_void_p(t.data_ptr())
 shapes = [(4800,728,728,1),(4800,728,728,0),(4800,1024,728,0),(4800,1536,1024,0),(4800,2048,1536,0),(4800,256,2048,0),(4800,256,1280,0),
@@ -16,13 +18,20 @@ for (m,n,k,res) in shapes:
   total = lib.epos_pack_pointwise_weights(None,k,n,None); dst=np.empty(total,np.float32)
   lib.epos_pack_pointwise_weights(w.ctypes.data_as(ctypes.c_void_p),k,n,dst.ctypes.data_as(ctypes.c_void_p))
   Wp = torch.from_numpy(dst).cuda(); b = torch.zeros((n+127)//128*128,device='cuda')
-  a = _lib.PointwiseArgs(A=p(A),lda=k,Wp=p(Wp),bias=p(b),R=p(R) if res else None,ldr=n,C=p(C),ldc=n,M=m,N=n,K=k,relu=0,relu_in=1,sub=1)
+  a = _lib.PointwiseArgs(A=p(A),lda=k,Wp=p(Wp),bias=p(b),R=p(R) if res else None,ldr=n,C=p(C),ldc=n,M=m,N=n,K=k,relu=0,relu_in=RELU_IN,sub=1)
   call = (lambda: lib.epos_pointwise_conv_grouped_ws_f32(ctypes.byref(a), 1, p(WS), None)) if USE_WS else (lambda: lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
   for _ in range(3): call()
   torch.cuda.synchronize()
+  err = ''
+  if CHECK:
+    ref = (torch.relu(A) if RELU_IN else A).double() @ torch.from_numpy(w).cuda().double()
+    if res: ref = ref + R.double()
+    d = (C.double() - ref).abs().max().item() / ref.abs().max().item()
+    err = '  relerr %.1e%s' % (d, '' if d < 1e-5 else '  <-- MISMATCH')
   e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
-  it=20; e0.record()
+  for _ in range(int(os.environ.get('BENCH_WARM', '300'))): call()   # let the core clock ramp (2.06 -> 2.4 GHz)
+  it=50; e0.record()
   for _ in range(it): call()
   e1.record(); torch.cuda.synchronize()
   us = e0.elapsed_time(e1)/it*1e3
-  print('M=%6d N=%5d K=%5d res=%d  %8.1f us  %6.1f TF' % (m,n,k,res,us,2*m*n*k/us/1e6))
+  print('M=%6d N=%5d K=%5d res=%d  %8.1f us  %6.1f TF%s' % (m,n,k,res,us,2*m*n*k/us/1e6,err))

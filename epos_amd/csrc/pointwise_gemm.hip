@@ -1376,13 +1376,16 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_sk_f32(SkArgs a_) {
     ++tr_nseg;
 #endif
     if (u == u_end) break;
-    // stores and loads of the epilogue are drained before the counted DMA
-    // waits are relied on again (vmcnt does not order stores against loads). The
-    // builtin (not asm) so that hipcc's own wait insertion knows nothing is
-    // pending when the unit loop is re-entered -- otherwise it puts a vmcnt(0)
-    // in front of the first register reuse INSIDE the loop, draining the ring.
+    // The epilogue's stores are NOT drained: loads (LDS-DMA included) return in
+    // order among themselves, so "at most 6 outstanding" still implies that the
+    // pieces of unit u+1 have landed (if one of them were pending, the 6 younger
+    // pieces of u+2 would be too => more than 6). Stores in flight can only make
+    // the counted wait longer, never shorter. Every compiler-visible load of the
+    // epilogue is consumed inside it, so hipcc has nothing pending either.
+#ifdef EPOS_SK_DRAIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+#endif
     zero_acc();
     decode_compute(u);
   }

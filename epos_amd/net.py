@@ -639,12 +639,14 @@ class EposNet(object):
         W.PRED_FRAG_LOC: self.logits[W.PRED_FRAG_LOC].view(B, h, w, O, F, 3),
     }
 
-  def time_ops(self, iters=3):
-    """Per-launch HIP-event timing of the plan (diagnostics)."""
+  def time_ops(self, iters=3, warm=0):
+    """Per-launch HIP-event timing of the plan (diagnostics). `warm` extra
+    untimed launches per op let the core clock ramp (2.06 -> 2.4 GHz)."""
     out = []
     s = self._stream()
     for name, fn in self.ops:
-      fn(s)
+      for _ in range(1 + warm):
+        fn(s)
       torch.cuda.synchronize(self.dev)
       e0 = torch.cuda.Event(enable_timing=True)
       e1 = torch.cuda.Event(enable_timing=True)

@@ -19,7 +19,7 @@ net = model.get_net(ckpt, args.batch, 480, 640, O, F)
 img = np.stack([synthetic.image(i, 480, 640) for i in range(args.batch)])
 out = net.forward(torch.from_numpy(img).cuda())
 torch.cuda.synchronize()
-rows = net.time_ops(iters=5)
+rows = net.time_ops(iters=30, warm=150)
 tot = sum(r[1] for r in rows)
 agg = {}
 for name, ms, fl in rows:

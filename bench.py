@@ -13,7 +13,7 @@ pose records on the host at the end of the step. Weights are random-init with th
 reference's initialisers (no network access for the released checkpoints).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  "roofline":     fp32-MFMA roofline of the dominant kernel (pointwise_gemm_f32),
+  "roofline":     fp32-MFMA roofline of the dominant kernel (pointwise_gemm_dma_f32),
                   measured with HIP events around every launch of it,
   "cpu_baseline": the CPU oracle (torch-CPU net + numpy corresp + C RANSAC) timed
                   on this host on a bounded sample (N=1, rank 0 only).
@@ -113,7 +113,7 @@ def cpu_baseline(ckpt, store, args, frames):
 
 
 def gemm_roofline(pipe, steps):
-  """HIP-event timing of every pointwise_gemm_f32 launch of the plan (events on
+  """HIP-event timing of every pointwise-GEMM launch of the plan (events on
   the stream the kernels are launched on), averaged over `steps` passes."""
   net = pipe.net
   s = net._stream()
@@ -159,7 +159,7 @@ def gemm_roofline(pipe, steps):
       'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
       'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
       'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,
-      'kernel': 'pointwise_gemm_f32',
+      'kernel': 'pointwise_gemm_dma_f32',
       'launches_per_image': launches // steps // net.B,
       'avg_launch_us': round(total_ms * 1e3 / launches, 2),
       'gflop_per_image': round(flops / steps / net.B / 1e9, 1),

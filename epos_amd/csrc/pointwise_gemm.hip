@@ -92,10 +92,28 @@ __device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
                                              int n0w, int lane) {
   const int l31 = lane & 31, h = lane >> 5;
   const int M = p.M, N = p.N;
+  constexpr int C4 = TN * 8;                 // float4 per staged row
+  constexpr int RPI = 64 / C4;               // rows per wave instruction
+  constexpr int NI = TM * 32 / RPI;
+  const int c4 = lane % C4, r0 = lane / C4;
+  const int n = n0w + c4 * 4;
+  // The residual rows are requested first, unconditionally and from clamped
+  // addresses, so that all of them are in flight together (a load under the
+  // store predicate would be waited for on the spot, one row at a time).
+  float4 rv[HAS_RES ? NI : 1];
+  if (HAS_RES) {
+    const int ncl = n < N ? n : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int m = m0w + r0 + i * RPI;
+      m = m < M ? m : M - 1;
+      rv[i] = *reinterpret_cast<const float4*>(p.R + static_cast<int64_t>(m) * p.ldr + ncl);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0w + j * 32 + l31;
-    const float bias = p.bias ? p.bias[n < N ? n : N - 1] : 0.f;
+    const int nb = n0w + j * 32 + l31;
+    const float bias = p.bias ? p.bias[nb < N ? nb : N - 1] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -105,25 +123,18 @@ __device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
   }
   // same wave wrote and reads: only the LDS counter has to drain
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  constexpr int C4 = TN * 8;                 // float4 per staged row
-  constexpr int RPI = 64 / C4;               // rows per wave instruction
-  const int c4 = lane % C4, r0 = lane / C4;
-  const int n = n0w + c4 * 4;
   const bool relu = p.relu != 0;
 #pragma unroll
-  for (int i = 0; i < TM * 32 / RPI; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int row = r0 + i * RPI;
     const int m = m0w + row;
     float4 v = *reinterpret_cast<const float4*>(ws + row * EP_ROW + c4 * 4);
-    if (m < M && n < N) {
-      if (HAS_RES) {
-        const float4 rv = *reinterpret_cast<const float4*>(
-            p.R + static_cast<int64_t>(m) * p.ldr + n);
-        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-      }
-      if (relu) v = relu4(v);
-      *reinterpret_cast<float4*>(p.C + static_cast<int64_t>(m) * p.ldc + n) = v;
+    if (HAS_RES) {
+      v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
     }
+    if (relu) v = relu4(v);
+    if (m < M && n < N)
+      *reinterpret_cast<float4*>(p.C + static_cast<int64_t>(m) * p.ldc + n) = v;
   }
 }
 

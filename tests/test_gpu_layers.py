@@ -66,6 +66,70 @@ def test_pointwise_gemm(lib, m, k, n, relu, relu_in, res):
   assert (out[:, :3] == -7.0).all() and (out[:, 3 + n:] == -7.0).all()
 
 
+@pytest.mark.parametrize('k', [32, 40, 64, 92, 96, 128, 132, 160, 224, 736])
+@pytest.mark.parametrize('m,n,aligned,res', [(64, 128, 1, 0), (130, 200, 1, 1),
+                                             (257, 132, 0, 1), (1000, 96, 1, 0)])
+def test_pointwise_gemm_dma_ring(lib, k, m, n, aligned, res):
+  """LDS-DMA kernel (the default for N > 64): every prologue / steady / tail path
+  of the three-stage ring (1..23 K tiles, partial last K tile with and without
+  whole k-groups missing), ragged M and N tiles, the float4 epilogue (16-byte
+  aligned rows) and the scalar one, residual + ReLU. A is followed by NaNs so that
+  reading past K inside the last K tile would poison the result."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(k * 7 + m + n)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  bias = rng.standard_normal(n).astype(np.float32)
+  r = rng.standard_normal((m, n)).astype(np.float32)
+  npad = (n + 127) // 128 * 128
+  bpad = np.zeros(npad, np.float32); bpad[:n] = bias
+  lda = k + 36                                 # columns k.. of every row are NaN
+  abuf = np.full((m, lda), np.nan, np.float32); abuf[:, :k] = a
+  A, Wp, Bd, R = (torch.from_numpy(abuf).cuda(), _pack(lib, w),
+                  torch.from_numpy(bpad).cuda(), torch.from_numpy(r).cuda())
+  ldc = n + (4 if aligned else 5)
+  off = 4 if aligned else 3
+  C = torch.full((m, ldc), -7.0, device='cuda')
+  args = _lib.PointwiseArgs(A=_p(A), lda=lda, Wp=_p(Wp), bias=_p(Bd),
+                            R=_p(R) if res else None, ldr=n, C=_p(C, off), ldc=ldc,
+                            M=m, N=n, K=k, relu=res, relu_in=0, sub=1)
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  torch.cuda.synchronize()
+  out = C.cpu().numpy()
+  ref = a.astype(np.float64) @ w.astype(np.float64) + bias
+  if res:
+    ref = np.maximum(ref + r, 0)
+  np.testing.assert_allclose(out[:, off:off + n], ref, rtol=1e-4, atol=1e-4)
+  assert (out[:, :off] == -7.0).all() and (out[:, off + n:] == -7.0).all()
+
+
+def test_pointwise_gemm_dma_grouped_and_strided(lib):
+  """One grid for three problems of different shapes (as the heads / ASPP groups)
+  plus a stride-2 row gather (shortcut convs), all through the LDS-DMA kernel."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(11)
+  b, hi, wi, cin = 2, 13, 18, 72
+  ho, wo = (hi + 1) // 2, (wi + 1) // 2
+  x = rng.standard_normal((b, hi, wi, cin)).astype(np.float32)
+  X = torch.from_numpy(x).cuda()
+  outs, refs, arr = [], [], (_lib.PointwiseArgs * 3)()
+  keep = []
+  for i, (n, sub) in enumerate([(136, 2), (80, 2), (260, 2)]):
+    w = (rng.standard_normal((cin, n)) / np.sqrt(cin)).astype(np.float32)
+    Wp = _pack(lib, w)
+    C = torch.zeros(b * ho * wo, n, device='cuda')
+    keep += [Wp, C]
+    arr[i] = _lib.PointwiseArgs(A=_p(X), lda=cin, Wp=_p(Wp), bias=None, R=None, ldr=0,
+                                C=_p(C), ldc=n, M=b * ho * wo, N=n, K=cin, relu=0,
+                                relu_in=0, sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi)
+    outs.append(C)
+    refs.append(x[:, ::2, ::2, :].reshape(-1, cin).astype(np.float64) @ w)
+  _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
+  torch.cuda.synchronize()
+  for C, ref in zip(outs, refs):
+    np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
 def test_pointwise_gemm_layout_is_not_transposed(lib):
   """A = I with an ASYMMETRIC W must reproduce W (catches row/col swaps)."""
   from epos_amd import _lib
@@ -246,7 +310,8 @@ def test_softmax_and_argmax(lib, g):
 
 @pytest.mark.parametrize('m,k,n,res', [(4800, 728, 728, 1), (4800, 2048, 256, 0),
                                        (19200, 256, 1344, 0), (700, 736, 300, 0),
-                                       (5000, 64, 128, 0), (64, 4096, 128, 1)])
+                                       (5000, 64, 128, 0), (64, 4096, 128, 1),
+                                       (3000, 40, 136, 1), (9000, 100, 260, 0)])
 def test_stream_k_gemm_matches_reference(lib, m, k, n, res, monkeypatch):
   """Persistent stream-K kernel (opt-in in round 1) through its explicit entry
   point: shapes with many / few units per worker, more workers than units, split

@@ -3,6 +3,8 @@
 // stem convs, global average pool, bilinear resize (align_corners), grouped
 // softmax and argmax. All accesses are float4 along the channel axis (the
 // contiguous axis of NHWC), 16 B per lane, so a wave moves 1 KiB per instruction.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace epos {
@@ -362,15 +364,29 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
   const int c4n = a->C / 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->stride == 1 && a->Hi == a->Ho && a->Wi == a->Wo) {
-    constexpr int L = 4;
+    static const int L = [] {              // EPOS_DW_L=2|4|8: run length (tuning)
+      const char* e = getenv("EPOS_DW_L");
+      return e ? atoi(e) : 4;
+    }();
+    static const int threads = [] {        // EPOS_DW_THREADS=64|128|256
+      const char* e = getenv("EPOS_DW_THREADS");
+      return e ? atoi(e) : 256;
+    }();
     const int nres = a->rate < a->Wo ? a->rate : a->Wo;
     const int per_res = static_cast<int>(ceil_div(a->Wo, a->rate));
     const int nchunk = static_cast<int>(ceil_div(per_res, L));
     const int64_t total =
         static_cast<int64_t>(a->B) * a->Ho * nres * nchunk * c4n;
     if (total == 0) return EPOS_OK;
-    hipLaunchKernelGGL(depthwise3x3_s1_kernel<L>, dim3(blocks_for(total, 256)),
-                       dim3(256), 0, st, *a, c4n, nres, nchunk, total);
+    if (L == 2)
+      hipLaunchKernelGGL(depthwise3x3_s1_kernel<2>, dim3(blocks_for(total, threads)),
+                         dim3(threads), 0, st, *a, c4n, nres, nchunk, total);
+    else if (L == 8)
+      hipLaunchKernelGGL(depthwise3x3_s1_kernel<8>, dim3(blocks_for(total, threads)),
+                         dim3(threads), 0, st, *a, c4n, nres, nchunk, total);
+    else
+      hipLaunchKernelGGL(depthwise3x3_s1_kernel<4>, dim3(blocks_for(total, threads)),
+                         dim3(threads), 0, st, *a, c4n, nres, nchunk, total);
     return launch_status("depthwise3x3_s1_kernel");
   }
   const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * c4n;

@@ -1,0 +1,119 @@
+// Shared pieces of the pointwise-GEMM kernels (pointwise_gemm.hip: register-staged
+// kernels + the C entry points; pointwise_gemm_dma.hip: the LDS-DMA kernels).
+// Everything here has internal linkage: each translation unit gets its own copy.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace epos {
+
+// Launchers defined in pointwise_gemm_dma.hip (the default data path for every GEMM
+// without a pre-activation ReLU, and the opt-in persistent stream-K variant).
+int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s);
+int launch_grouped_sk(const EposPointwiseArgs* args, int count, void* workspace,
+                      hipStream_t s);
+int64_t sk_workspace_bytes();
+
+namespace {
+
+constexpr int BN = 128;
+constexpr int BK = 32;
+constexpr int LDS_A_ROW = BK + 4;                  // floats
+constexpr int LDS_B_TILE = (BK / 4) * BN * 4;      // floats per buffer
+constexpr int THREADS = 256;
+constexpr int MAX_GROUP = 8;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GroupedArgs {
+  EposPointwiseArgs p[MAX_GROUP];
+  int tile_start[MAX_GROUP + 1];   // prefix sum of tiles per problem
+  int tiles_n[MAX_GROUP];
+  int npad[MAX_GROUP];
+  int count;
+};
+
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f),
+                     fmaxf(v.w, 0.f));
+}
+
+// ---------------------------------------------------------------------------
+// Vectorised epilogue. The MFMA accumulator layout gives a lane ONE output column
+// and 16 rows, i.e. 4-byte stores that touch 128 B per row -- store-ISSUE bound
+// (a 14 MB layer output took ~9 us). The wave instead transposes its tile through
+// its own LDS region (bias added on the way in) and then streams it out row-major
+// as float4: 16 B per lane, the residual is fetched the same way, ReLU last.
+// Falls back to the scalar path when rows are not 16-byte aligned (e.g. the
+// 22-channel object head).
+// ---------------------------------------------------------------------------
+constexpr int EP_ROW = 68;     // floats per staged row (64 + 4: 16 B aligned, no conflicts)
+
+__device__ __forceinline__ bool vec_epilogue_ok(const EposPointwiseArgs& p, bool has_res) {
+  bool ok = (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.C) & 15) == 0;
+  if (has_res)
+    ok = ok && (p.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(p.R) & 15) == 0;
+  return ok;
+}
+
+// acc: TM x TN accumulator tiles of this wave (row-tile major); the wave tile is
+// (TM*32) rows x (TN*32) columns at (m0w, n0w); `ws` = TM*32*EP_ROW floats of LDS
+// owned by this wave.
+template <int TM, int TN, bool HAS_RES>
+__device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
+                                             const EposPointwiseArgs& p, int m0w,
+                                             int n0w, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = p.M, N = p.N;
+  constexpr int C4 = TN * 8;                 // float4 per staged row
+  constexpr int RPI = 64 / C4;               // rows per wave instruction
+  constexpr int NI = TM * 32 / RPI;
+  const int c4 = lane % C4, r0 = lane / C4;
+  const int n = n0w + c4 * 4;
+  // The residual rows are requested first, unconditionally and from clamped
+  // addresses, so that all of them are in flight together (a load under the
+  // store predicate would be waited for on the spot, one row at a time).
+  float4 rv[HAS_RES ? NI : 1];
+  if (HAS_RES) {
+    const int ncl = n < N ? n : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int m = m0w + r0 + i * RPI;
+      m = m < M ? m : M - 1;
+      rv[i] = *reinterpret_cast<const float4*>(p.R + static_cast<int64_t>(m) * p.ldr + ncl);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = n0w + j * 32 + l31;
+    const float bias = p.bias ? p.bias[nb < N ? nb : N - 1] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ws[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EP_ROW + j * 32 + l31] =
+            acc[i * TN + j][r] + bias;
+  }
+  // same wave wrote and reads: only the LDS counter has to drain
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const bool relu = p.relu != 0;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = r0 + i * RPI;
+    const int m = m0w + row;
+    float4 v = *reinterpret_cast<const float4*>(ws + row * EP_ROW + c4 * 4);
+    if (HAS_RES) {
+      v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+    }
+    if (relu) v = relu4(v);
+    if (m < M && n < N)
+      *reinterpret_cast<float4*>(p.C + static_cast<int64_t>(m) * p.ldc + n) = v;
+  }
+}
+
+}  // namespace
+}  // namespace epos

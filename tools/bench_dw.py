@@ -1,0 +1,30 @@
+#!/usr/bin/env python
+"""Micro-benchmark of epos_depthwise3x3_f32 on the network's shapes (warm clocks),
+next to a plain device copy of the same tensor (the streaming floor at that size).
+EPOS_DW_L / EPOS_DW_THREADS select kernel variants."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from epos_amd import _lib
+lib = _lib.load()
+def p(t): return ctypes.c_void_p(t.data_ptr())
+shapes = [(60, 80, 728, 2), (60, 80, 1024, 2), (60, 80, 1536, 4), (60, 80, 2048, 12), (120, 160, 256, 1),
+          (120, 160, 304, 1), (240, 320, 64, 1), (240, 320, 128, 1), (60, 80, 256, 1)]
+def timeit(fn, warm=200, it=100):
+  for _ in range(warm): fn()
+  torch.cuda.synchronize()
+  e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(it): fn()
+  e1.record(); torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / it * 1e3
+for (h, w, c, rate) in shapes:
+  X = torch.randn(1, h, w, c, device='cuda'); Y = torch.empty_like(X)
+  w9 = torch.randn(9, c, device='cuda'); b = torch.randn(c, device='cuda')
+  a = _lib.DepthwiseArgs(X=p(X), ldx=c, w9c=p(w9), bias=p(b), Y=p(Y), ldy=c, B=1, Hi=h, Wi=w,
+                         Ho=h, Wo=w, C=c, stride=1, rate=rate, relu_in=1, relu_out=0)
+  us = timeit(lambda: lib.epos_depthwise3x3_f32(ctypes.byref(a), None))
+  cp = timeit(lambda: Y.copy_(X))
+  mb = 2 * X.numel() * 4 / 1e6
+  print('%3dx%3dx%4d rate %2d  dw %6.1f us (%5.2f TB/s)   copy %6.1f us (%5.2f TB/s)' % (
+      h, w, c, rate, us, mb / us / 1e6 * 1e6 / 1e6, cp, mb / cp))

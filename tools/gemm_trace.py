@@ -12,10 +12,11 @@ from epos_amd import _lib, build
 defs = os.environ.get('TRACE_DEFS', '').split()      # e.g. -DEPOS_ABL_NOBAR (ablations)
 tag = ''.join(d.replace('-D', '_') for d in defs)
 path = os.path.join(build.LIB_DIR, 'libepos_hip_trace%s.so' % tag)
-src = os.path.join(build.CSRC, 'pointwise_gemm.hip')
+src = os.path.join(build.CSRC, "pointwise_gemm_dma.hip")
 if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
   subprocess.check_call([build.HIPCC] + build.FLAGS + ['-DEPOS_GEMM_TRACE'] + defs +
-                        ['-o', path, src, os.path.join(build.CSRC, 'runtime.hip')])
+                        ['-o', path, src, os.path.join(build.CSRC, 'pointwise_gemm.hip'),
+                         os.path.join(build.CSRC, 'runtime.hip')])
 print('defs:', defs)
 lib = ctypes.CDLL(path)
 lib.epos_pack_pointwise_weights.restype = ctypes.c_int64

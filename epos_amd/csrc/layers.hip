@@ -66,46 +66,158 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
 // weight vectors are loaded once per run and an output costs 3(L+2)/L input
 // loads instead of 9 (+9 weights). Loads are unconditional from clamped
 // addresses (zero padding is a select) so no load sits under a branch.
-template <int L>
+//
+// XCD-aware partition. Workgroup i runs on XCD i % 8, and each XCD has a private
+// 4 MB L2. With a flat id -> (pixel, channel) map every XCD touches the whole
+// input (each input row is needed by three output rows that land on different
+// XCDs): the tensor streams through all eight L2s from the Infinity Cache, about
+// three times in total (PMC: FETCH_SIZE / WRITE_SIZE = 3.4, 12.6 us for the 14 MB
+// middle-flow tensor against 4.4 us for a plain copy). A depthwise conv never
+// mixes channels, so
+//   mode 0 (C >= 256): XCD x owns the channel slice [x*c4n/8, (x+1)*c4n/8) of
+//           EVERY pixel -- its share of the input (1/8) stays in its L2 and no
+//           byte is fetched by two XCDs;
+//   mode 1 (narrow tensors: a slice would be less than a cache line): XCD x owns
+//           a band of rows; only the 2*rate halo rows of a band are fetched twice.
+//
+// The kernel is VALU-issue bound, not bandwidth bound (the first version spent ~900
+// vector instructions per wave: 64-bit index arithmetic with runtime divisions, four
+// selects per loaded float4 for the zero padding, two v_max per ReLU'd component), so:
+// divisions by launch constants use precomputed multipliers, ReLU is one v_med3 per
+// component and a compile-time option, and a wave whose lanes all lie in the interior
+// of the image (no tap outside) takes a path without any clamp or select.
+struct FastDiv {                 // n / d for any 32-bit n (Granlund-Montgomery)
+  unsigned mul, sh1, sh2, d;
+};
+struct DwPartition {
+  int mode;        // 0: channel slices, 1: row bands
+  int runs;        // mode 0: runs of the whole launch = B*Ho*nres*nchunk
+  int rows;        // mode 1: B*Ho
+  FastDiv dwc[2];  // mode 0: slice widths floor(c4n/8) and floor(c4n/8)+1
+  FastDiv dc4n, dchunk, dres, dho;
+};
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  const unsigned t = __umulhi(f.mul, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+// One v_max per component: fmaxf() costs two under IEEE mode (a canonicalising
+// v_max v,v,v first), and hipcc folds fmed3(v, 0, inf) back into the same pair.
+__device__ __forceinline__ float relu_1op(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float4 relu4_1op(float4 v) {
+  return make_float4(relu_1op(v.x), relu_1op(v.y), relu_1op(v.z), relu_1op(v.w));
+}
+
+template <int L, bool RELU_IN, bool RELU_OUT>
 __global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(EposDepthwiseArgs p,
                                                               int c4n, int nres,
                                                               int nchunk,
-                                                              int64_t total) {
-  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (id >= total) return;
-  const int c = static_cast<int>(id % c4n) * 4;
-  int64_t rest = id / c4n;
-  const int chunk = static_cast<int>(rest % nchunk); rest /= nchunk;
-  const int res = static_cast<int>(rest % nres); rest /= nres;
-  const int y = static_cast<int>(rest % p.Ho);
-  const int b = static_cast<int>(rest / p.Ho);
+                                                              DwPartition part) {
+  const int xcd = blockIdx.x & 7;
+  const unsigned local = (blockIdx.x >> 3) * blockDim.x + threadIdx.x;
+  int c, chunk, res, y, b;
+  bool live = true;
+  if (part.mode == 0) {
+    const int c_lo = xcd * c4n / 8, wc = (xcd + 1) * c4n / 8 - c_lo;
+    live = wc != 0 && local < static_cast<unsigned>(part.runs) * wc;
+    const FastDiv& dw = wc == static_cast<int>(part.dwc[0].d) ? part.dwc[0] : part.dwc[1];
+    unsigned rest = fdiv(local, dw);
+    c = (c_lo + static_cast<int>(local - rest * wc)) * 4;
+    unsigned q = fdiv(rest, part.dchunk);
+    chunk = static_cast<int>(rest - q * nchunk); rest = q;
+    q = fdiv(rest, part.dres);
+    res = static_cast<int>(rest - q * nres); rest = q;
+    q = fdiv(rest, part.dho);
+    y = static_cast<int>(rest - q * p.Ho);
+    b = static_cast<int>(q);
+  } else {
+    const int r_lo = static_cast<int>(static_cast<int64_t>(xcd) * part.rows / 8);
+    const int nrow = static_cast<int>(static_cast<int64_t>(xcd + 1) * part.rows / 8) - r_lo;
+    live = local < static_cast<unsigned>(nrow) * nres * nchunk * c4n;
+    unsigned rest = fdiv(local, part.dc4n);
+    c = static_cast<int>(local - rest * c4n) * 4;
+    unsigned q = fdiv(rest, part.dchunk);
+    chunk = static_cast<int>(rest - q * nchunk); rest = q;
+    q = fdiv(rest, part.dres);
+    res = static_cast<int>(rest - q * nres); rest = q;
+    const unsigned row = r_lo + rest;
+    q = fdiv(row, part.dho);
+    y = static_cast<int>(row - q * p.Ho);
+    b = static_cast<int>(q);
+  }
   const int r = p.rate;
   const int x0 = res + chunk * L * r;
-  if (x0 >= p.Wo) return;
+  live = live && x0 < p.Wo;
+  if (!live) return;
   float4 w[9];
+#ifdef EPOS_DW_ABL_NOW
+#pragma unroll
+  for (int i = 0; i < 9; ++i) w[i] = make_float4(0.1f * i, 0.2f, 0.3f, 0.4f);
+  const float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
 #pragma unroll
   for (int i = 0; i < 9; ++i) w[i] = ld4(p.w9c + i * p.C + c);
   const float4 bias = ld4(p.bias + c);
+#endif
+  // 32-bit element offsets from one per-thread base (the host checks the range)
   const float* xb = p.X + static_cast<int64_t>(b) * p.Hi * p.Wi * p.ldx + c;
-  const float* rowp[3];
+  float* yb = p.Y + ((static_cast<int64_t>(b) * p.Ho + y) * p.Wo) * p.ldy + c;
+  const int ldx = static_cast<int>(p.ldx), ldy = static_cast<int>(p.ldy);
+  const int rowpitch = p.Wi * ldx;
+  // every tap of every output of this run inside the image?
+  const bool interior = y - r >= 0 && y + r < p.Hi && x0 - r >= 0 && x0 + L * r < p.Wi;
+  float4 col[L + 2][3];
+  if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
+    // ---- interior wave: no clamp, no select -----------------------------------
+    const unsigned o00 = (y - r) * rowpitch + (x0 - r) * ldx;
+    const unsigned rstep = r * rowpitch, cstep = r * ldx;
+#pragma unroll
+    for (int i = 0; i < L + 2; ++i)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) col[i][ky] = ld4(xb + (o00 + ky * rstep + i * cstep));
+    if (RELU_IN) {
+#pragma unroll
+      for (int i = 0; i < L + 2; ++i)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) col[i][ky] = relu4_1op(col[i][ky]);
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      float4 acc = bias;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        acc = fma4(col[j][ky], w[ky * 3 + 0], acc);
+        acc = fma4(col[j + 1][ky], w[ky * 3 + 1], acc);
+        acc = fma4(col[j + 2][ky], w[ky * 3 + 2], acc);
+      }
+      if (RELU_OUT) acc = relu4_1op(acc);
+      st4(yb + static_cast<unsigned>((x0 + j * r) * ldy), acc);
+    }
+    return;
+  }
+  // ---- border wave: clamped addresses, zero padding by select ------------------
+  unsigned rowoff[3];
   bool rowok[3];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int yi = y + (ky - 1) * r;
     rowok[ky] = yi >= 0 && yi < p.Hi;
-    rowp[ky] = xb + static_cast<int64_t>(rowok[ky] ? yi : 0) * p.Wi * p.ldx;
+    rowoff[ky] = (rowok[ky] ? yi : 0) * rowpitch;
   }
-  // All (L + 2) x 3 input vectors of the run are requested up front (independent,
-  // unconditional, clamped loads => one memory round trip per thread), then the
-  // window slides over registers.
-  float4 col[L + 2][3];
 #pragma unroll
   for (int i = 0; i < L + 2; ++i) {
     const int xi = x0 + (i - 1) * r;
     const bool xok = xi >= 0 && xi < p.Wi;
-    const int64_t off = static_cast<int64_t>(xok ? xi : 0) * p.ldx;
+    const unsigned off = (xok ? xi : 0) * ldx;
+#ifdef EPOS_DW_ABL_ONEROW
+    col[i][1] = ld4(xb + (rowoff[1] + off)); col[i][0] = col[i][1]; col[i][2] = col[i][1];
+#else
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) col[i][ky] = ld4(rowp[ky] + off);
+    for (int ky = 0; ky < 3; ++ky) col[i][ky] = ld4(xb + (rowoff[ky] + off));
+#endif
   }
 #pragma unroll
   for (int i = 0; i < L + 2; ++i) {
@@ -115,10 +227,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(EposDepthwiseArgs 
     for (int ky = 0; ky < 3; ++ky) {
       float4 v = col[i][ky];
       if (!(xok && rowok[ky])) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      col[i][ky] = p.relu_in ? relu4(v) : v;
+      col[i][ky] = RELU_IN ? relu4_1op(v) : v;
     }
   }
-  float* yb = p.Y + ((static_cast<int64_t>(b) * p.Ho + y) * p.Wo) * p.ldy + c;
 #pragma unroll
   for (int j = 0; j < L; ++j) {
     const int x = x0 + j * r;
@@ -129,8 +240,8 @@ __global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(EposDepthwiseArgs 
       acc = fma4(col[j + 1][ky], w[ky * 3 + 1], acc);
       acc = fma4(col[j + 2][ky], w[ky * 3 + 2], acc);
     }
-    if (p.relu_out) acc = relu4(acc);
-    if (x < p.Wo) st4(yb + static_cast<int64_t>(x) * p.ldy, acc);
+    if (RELU_OUT) acc = relu4_1op(acc);
+    if (x < p.Wo) st4(yb + static_cast<unsigned>(x * ldy), acc);
   }
 }
 
@@ -364,29 +475,64 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
   const int c4n = a->C / 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->stride == 1 && a->Hi == a->Ho && a->Wi == a->Wo) {
-    static const int L = [] {              // EPOS_DW_L=2|4|8: run length (tuning)
-      const char* e = getenv("EPOS_DW_L");
-      return e ? atoi(e) : 4;
-    }();
-    static const int threads = [] {        // EPOS_DW_THREADS=64|128|256
+    constexpr int L = 4;
+    static const int threads = [] {        // EPOS_DW_THREADS=64|128|256 (tuning)
       const char* e = getenv("EPOS_DW_THREADS");
       return e ? atoi(e) : 256;
     }();
     const int nres = a->rate < a->Wo ? a->rate : a->Wo;
     const int per_res = static_cast<int>(ceil_div(a->Wo, a->rate));
     const int nchunk = static_cast<int>(ceil_div(per_res, L));
-    const int64_t total =
-        static_cast<int64_t>(a->B) * a->Ho * nres * nchunk * c4n;
-    if (total == 0) return EPOS_OK;
-    if (L == 2)
-      hipLaunchKernelGGL(depthwise3x3_s1_kernel<2>, dim3(blocks_for(total, threads)),
-                         dim3(threads), 0, st, *a, c4n, nres, nchunk, total);
-    else if (L == 8)
-      hipLaunchKernelGGL(depthwise3x3_s1_kernel<8>, dim3(blocks_for(total, threads)),
-                         dim3(threads), 0, st, *a, c4n, nres, nchunk, total);
+    const int64_t runs = static_cast<int64_t>(a->B) * a->Ho * nres * nchunk;
+    if (runs == 0) return EPOS_OK;
+    EPOS_REQUIRE(runs * c4n < (1LL << 31) &&
+                 static_cast<int64_t>(a->Hi) * a->Wi * a->ldx < (1LL << 29) &&
+                 static_cast<int64_t>(a->Ho) * a->Wo * a->ldy < (1LL << 29),
+                 "tensor too large for 32-bit offsets within one image");
+    static const int force_mode = [] {     // EPOS_DW_MODE=0|1 (tuning)
+      const char* e = getenv("EPOS_DW_MODE");
+      return e ? atoi(e) : -1;
+    }();
+    auto fast_div = [](unsigned d) {
+      FastDiv f; f.d = d;
+      unsigned l = 0;
+      while ((1ull << l) < d) ++l;
+      f.mul = static_cast<unsigned>(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+      f.sh1 = l > 0 ? 1 : 0;
+      f.sh2 = l > 0 ? l - 1 : 0;
+      return f;
+    };
+    DwPartition part;
+    // channel slices when a slice is at least one 128-byte line wide and aligned
+    // (or wide enough that the two ragged lines per pixel do not matter)
+    part.mode = (c4n >= 128 || (c4n >= 64 && c4n % 8 == 0)) ? 0 : 1;
+    if (force_mode >= 0) part.mode = force_mode;
+    if (c4n < 8) part.mode = 1;
+    part.runs = static_cast<int>(runs);
+    part.rows = a->B * a->Ho;
+    part.dwc[0] = fast_div(c4n / 8 > 0 ? c4n / 8 : 1);
+    part.dwc[1] = fast_div(c4n / 8 + 1);
+    part.dc4n = fast_div(c4n);
+    part.dchunk = fast_div(nchunk);
+    part.dres = fast_div(nres);
+    part.dho = fast_div(a->Ho);
+    int64_t per_xcd;                        // items of the busiest XCD
+    if (part.mode == 0) per_xcd = runs * ceil_div(c4n, 8);
+    else per_xcd = ceil_div(part.rows, 8) * nres * nchunk * c4n;
+    const unsigned grid = 8 * blocks_for(per_xcd, threads);
+    const int v = (a->relu_in ? 2 : 0) | (a->relu_out ? 1 : 0);
+    if (v == 0)
+      hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, false, false>), dim3(grid), dim3(threads),
+                         0, st, *a, c4n, nres, nchunk, part);
+    else if (v == 1)
+      hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, false, true>), dim3(grid), dim3(threads),
+                         0, st, *a, c4n, nres, nchunk, part);
+    else if (v == 2)
+      hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, true, false>), dim3(grid), dim3(threads),
+                         0, st, *a, c4n, nres, nchunk, part);
     else
-      hipLaunchKernelGGL(depthwise3x3_s1_kernel<4>, dim3(blocks_for(total, threads)),
-                         dim3(threads), 0, st, *a, c4n, nres, nchunk, total);
+      hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, true, true>), dim3(grid), dim3(threads),
+                         0, st, *a, c4n, nres, nchunk, part);
     return launch_status("depthwise3x3_s1_kernel");
   }
   const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * c4n;

@@ -325,22 +325,31 @@ class EposNet(object):
     for bscope, depths, skip, act, units, stride, url in blocks:
       for u in range(units):
         scope = '%s/%s/unit_%d/xception_module' % (net, bscope, u + 1)
+        # the decoder taps sep-conv 2 of entry_flow/block2 BEFORE any activation
+        linear = (1,) if bscope == 'entry_flow/block2' else ()
         if current_stride == target:
           x, h, w, c, taps = self._xception_module(
-              scope, x, h, w, c, depths, skip, act, 1, rate, url)
+              scope, x, h, w, c, depths, skip, act, 1, rate, url, linear)
           rate *= stride
         else:
           x, h, w, c, taps = self._xception_module(
-              scope, x, h, w, c, depths, skip, act, stride, 1, url)
+              scope, x, h, w, c, depths, skip, act, stride, 1, url, linear)
           current_stride *= stride
         if bscope == 'entry_flow/block2':
           low_level = (taps[1], taps[1].shape[1], taps[1].shape[2], depths[1])
     return x, h, w, c, low_level
 
   def _xception_module(self, scope, x, hi, wi, cin, depths, skip, act_in_sep,
-                       stride, rate, unit_rates):
+                       stride, rate, unit_rates, linear_taps=()):
     """net_xception.py:197-323 as 3 x (depthwise launch + GEMM launch); the skip
-    connection is the residual input of the third GEMM's epilogue."""
+    connection is the residual input of the third GEMM's epilogue.
+
+    In the pre-activation form (ReLU -> depthwise -> pointwise, :272-276) the outputs
+    of sep-convs 1 and 2 are read by the next ReLU only, so that ReLU is applied by
+    the producing GEMM's epilogue (same values, bit for bit) instead of on every
+    tap the depthwise kernel loads -- except for `linear_taps`, which the decoder
+    reads before the activation (feature.py:29-73 'entry_flow/block2/unit_1/
+    xception_module/separable_conv2_pointwise')."""
     eps = XCEPTION_BN_EPS
     ho = hi if stride == 1 else (hi - 1) // 2 + 1
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
@@ -355,12 +364,14 @@ class EposNet(object):
                       sub=stride, ho=ho, wo=wo, hi=hi, wi=wi, group=grp)
     r, rh, rw, rc = x, hi, wi, cin
     taps = {}
+    r_is_relu = False           # r already holds ReLU(previous sep-conv output)
     for i in range(3):
       sc = '%s/separable_conv%d' % (scope, i + 1)
       s_i = stride if i == 2 else 1
       d, dh, dw_ = self._depthwise(
           sc + '_depthwise', r, rc, rh, rw, rc, s_i, rate * unit_rates[i],
-          sc + '_depthwise', eps, relu_in=not act_in_sep, relu_out=act_in_sep)
+          sc + '_depthwise', eps, relu_in=(not act_in_sep) and not r_is_relu,
+          relu_out=act_in_sep)
       w_kn, scl, bi = self._conv_params(sc + '_pointwise', eps)
       y = self._empty(self.B, dh, dw_, depths[i])
       res, ldr = None, 0
@@ -368,9 +379,11 @@ class EposNet(object):
         res, ldr = shortcut, depths[2]
       elif i == 2 and skip == 'sum':
         res, ldr = x, cin
+      fold_next_relu = (not act_in_sep) and i < 2 and i not in linear_taps
       self._pointwise(sc + '_pointwise', d, 0, rc, self.B * dh * dw_, rc, w_kn,
-                      scl, bi, y, 0, depths[i], relu=act_in_sep, res=res,
-                      ldr=ldr, group=grp if i == 0 else None)
+                      scl, bi, y, 0, depths[i], relu=act_in_sep or fold_next_relu,
+                      res=res, ldr=ldr, group=grp if i == 0 else None)
+      r_is_relu = fold_next_relu
       if i == 0:
         self._flush_group(grp)
       taps[i] = y

@@ -6,6 +6,13 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from epos_amd import _lib
+defs = os.environ.get('DW_DEFS', '').split()         # ablation builds of layers.hip
+if defs:
+  import subprocess
+  from epos_amd import build
+  path = os.path.join(build.LIB_DIR, 'libepos_hip_dw%s.so' % ''.join(d.replace('-D', '_') for d in defs))
+  subprocess.check_call([build.HIPCC] + build.FLAGS + defs + ['-o', path] + build.sources())
+  _lib.lib_path = lambda: path
 lib = _lib.load()
 def p(t): return ctypes.c_void_p(t.data_ptr())
 shapes = [(60, 80, 728, 2), (60, 80, 1024, 2), (60, 80, 1536, 4), (60, 80, 2048, 12), (120, 160, 256, 1),

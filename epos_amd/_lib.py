@@ -47,6 +47,17 @@ class DepthwiseArgs(ctypes.Structure):
   ]
 
 
+class Conv3x3Args(ctypes.Structure):
+  _fields_ = [
+      ('X', vp), ('ldx', ctypes.c_int64),
+      ('Wp', vp), ('bias', vp),
+      ('Y', vp), ('ldy', ctypes.c_int64),
+      ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
+      ('Cin', ctypes.c_int32), ('Cout', ctypes.c_int32),
+      ('relu', ctypes.c_int32),
+  ]
+
+
 class Im2colArgs(ctypes.Structure):
   _fields_ = [
       ('X', vp), ('ldx', ctypes.c_int64),
@@ -105,6 +116,7 @@ SYMBOLS = {
         ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp, vp]),
     'epos_pointwise_conv_grouped_ws_f32': (ctypes.c_int, [
         ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp, vp]),
+    'epos_conv3x3_f32': (ctypes.c_int, [ctypes.POINTER(Conv3x3Args), ctypes.c_void_p]),
     'epos_depthwise3x3_f32': (ctypes.c_int,
                               [ctypes.POINTER(DepthwiseArgs), vp]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),

@@ -12,7 +12,10 @@ namespace epos {
 
 // Launchers defined in pointwise_gemm_dma.hip (the default data path for every GEMM
 // without a pre-activation ReLU, and the opt-in persistent stream-K variant).
-int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s);
+// conv_cin != nullptr: implicit 3x3 'SAME' conv, problem i has conv_cin[i] input channels
+// (K = 9 * conv_cin[i], A = the NHWC input, Hi/Wi = its height/width).
+int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s,
+                       const int* conv_cin = nullptr);
 int launch_grouped_sk(const EposPointwiseArgs* args, int count, void* workspace,
                       hipStream_t s);
 int64_t sk_workspace_bytes();
@@ -33,6 +36,7 @@ struct GroupedArgs {
   int tile_start[MAX_GROUP + 1];   // prefix sum of tiles per problem
   int tiles_n[MAX_GROUP];
   int npad[MAX_GROUP];
+  int conv_cin[MAX_GROUP];         // LDS-DMA kernel, implicit 3x3 conv: input channels
   int count;
 };
 

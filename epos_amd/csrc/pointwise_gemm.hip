@@ -651,17 +651,25 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
                        s, args[0], npad);
     return launch_status("pointwise_gemv_f32");
   }
-  // Tile-height heuristic (EPOS_GEMM_TILE_M=64|128 overrides it for tuning):
-  // 128-row tiles only when they alone give every CU >= 2 workgroups; otherwise
-  // 64-row tiles double the number of co-resident workgroups.
+  // LDS-DMA kernel: the default whenever no pre-activation ReLU has to be applied to
+  // A on the way into LDS (measured with warm clocks: 8-30 % faster than the
+  // register-staged kernels on every shape of the network; it picks 128 x 64 tiles
+  // itself when every problem has N <= 64). EPOS_GEMM_DMA=0 disables it for A/B runs.
+  static const int use_dma = [] {
+    const char* e = getenv("EPOS_GEMM_DMA");
+    return e ? atoi(e) : -1;
+  }();
+  if (args[0].relu_in == 0 && use_dma != 0)
+    return launch_grouped_dma(args, count, s);
+  // Register-staged kernels (pre-activation ReLU on the way into LDS):
+  // EPOS_GEMM_TILE_M=64|128 and EPOS_GEMM_WP=0|1 override the choices for tuning.
+  // 128-row tiles only when they alone give every CU >= 2 workgroups; the
+  // barrier-free kernel tiles N in steps of 64, so it takes the groups whose
+  // problems all have N <= 64.
   static const int forced = [] {
     const char* e = getenv("EPOS_GEMM_TILE_M");
     return e ? atoi(e) : 0;
   }();
-  // Kernel choice (EPOS_GEMM_WP=0|1 forces one for tuning): the two kernels tie
-  // on wide outputs; the barrier-free one tiles N in steps of 64 (and skips an
-  // all-padding 32-column half), so it wins whenever every problem of the group
-  // has N <= 64 (stem convs, the 48-channel decoder projection, the object head).
   static const int use_wp = [] {
     const char* e = getenv("EPOS_GEMM_WP");
     return e ? atoi(e) : -1;
@@ -671,18 +679,28 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
   if (use_wp == 1 || (use_wp < 0 && max_n <= 64))
     return launch_grouped_wp(args, count, s);
   const bool big = forced ? forced == 128 : tiles128 >= 512;
-  // LDS-DMA kernel: the default whenever no pre-activation ReLU has to be applied to
-  // A on the way into LDS (measured with warm clocks: 8-30 % faster than the
-  // register-staged kernels on every shape of the network, 64-row tiles included
-  // where the 128-row tile used to win). EPOS_GEMM_DMA=0 disables it for A/B runs.
-  static const int use_dma = [] {
-    const char* e = getenv("EPOS_GEMM_DMA");
-    return e ? atoi(e) : -1;
-  }();
-  if (args[0].relu_in == 0 && use_dma != 0)
-    return launch_grouped_dma(args, count, s);
   if (big) return launch_grouped<128>(args, count, s);
   return launch_grouped<64>(args, count, s);
+}
+
+extern "C" int epos_conv3x3_f32(const EposConv3x3Args* a, void* stream) {
+  using namespace epos;
+  EPOS_REQUIRE(a && a->X && a->Wp && a->Y, "null pointer");
+  EPOS_REQUIRE(a->Cin > 0 && a->Cin % BK == 0, "Cin must be a multiple of 32");
+  EPOS_REQUIRE(a->ldx % 4 == 0 && a->ldx >= a->Cin, "ldx: multiple of 4, >= Cin");
+  EPOS_REQUIRE((reinterpret_cast<uintptr_t>(a->X) & 15) == 0, "X must be 16-byte aligned");
+  EPOS_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, "empty problem");
+  EPOS_REQUIRE(static_cast<int64_t>(a->B) * a->H * a->W < (1LL << 31), "too many pixels");
+  EposPointwiseArgs p = {};
+  p.A = a->X; p.lda = a->ldx;
+  p.Wp = a->Wp; p.bias = a->bias;
+  p.R = nullptr; p.ldr = 0;
+  p.C = a->Y; p.ldc = a->ldy;
+  p.M = a->B * a->H * a->W; p.N = a->Cout; p.K = 9 * a->Cin;
+  p.relu = a->relu; p.relu_in = 0; p.sub = 1;
+  p.Ho = a->H; p.Wo = a->W; p.Hi = a->H; p.Wi = a->W;
+  const int cin = a->Cin;
+  return launch_grouped_dma(&p, 1, static_cast<hipStream_t>(stream), &cin);
 }
 
 extern "C" int epos_pointwise_conv_f32(const EposPointwiseArgs* a, void* stream) {

@@ -73,14 +73,29 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const float* sbase,
       : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
 }
 
-template <bool HAS_RES>
+// LAYOUT 0: 64 x 128 tile, waves 2 x 2.   LAYOUT 1: 128 x 64 tile, waves 4 x 1 (every
+// problem of the launch has N <= 64: a 128-wide tile would waste half of its MFMAs).
+// The per-wave tile (32 x 64), the six DMA pieces per wave and K tile and the 24 KB
+// stage are the same in both.
+// CONV: implicit GEMM of a dense 3x3 stride-1 'SAME' conv with Cin % 32 == 0
+// (conv1_2, net_xception.py:462-463): K tile kt is channel block kt % (Cin/32) of
+// tap kt / (Cin/32), i.e. the A rows are the input pixels shifted by the tap -- the
+// im2col matrix only ever exists as LDS tiles. Taps outside the image come from a
+// zero block (a per-lane source select, as for the partial last K tile).
+template <bool HAS_RES, int LAYOUT, bool CONV>
 __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga_) {
+  constexpr int BM_ = LAYOUT == 0 ? 64 : 128;
+  constexpr int BN_ = LAYOUT == 0 ? 128 : 64;
+  constexpr int NA = BM_ / 32;               // A pieces per wave and K tile
+  constexpr int NW = BN_ / 32;               // W pieces per wave and K tile
+  constexpr int B_BYTES = (BK / 4) * BN_ * 16;
+  static_assert(NA + NW == 6 && B_BYTES + BM_ * BK * 4 == DMA_STAGE_BYTES, "stage");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = LAYOUT == 0 ? wave >> 1 : wave, wn = LAYOUT == 0 ? wave & 1 : 0;
   const int l31 = lane & 31, h = lane >> 5;
   EPOS_TRACE(0);
 #ifdef EPOS_GEMM_TRACE
@@ -113,25 +128,32 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
   const int npad = gp->npad[pi];
   const int tile_n = bid % tiles_n;
   const int tile_m = bid / tiles_n;
-  const int m0 = tile_m * 64, n0 = tile_n * BN;
+  const int m0 = tile_m * BM_, n0 = tile_n * BN_;
   const int M = p.M, N = p.N, K = p.K;
   const int nk = (K + BK - 1) / BK;
+  const int cblocks = CONV ? gp->conv_cin[pi] / BK : 1;   // channel blocks per tap
 
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
 
-  // ---- A pieces: piece = wave*2 + i covers rows 8*piece .. +7, lane -> (row, slot)
-  const float* asrc[2];
-  int achunk[2];
-  unsigned a_dst[2];
+  // ---- A pieces: piece = wave*NA + i covers rows 8*piece .. +7, lane -> (row, slot)
+  const float* asrc[NA];
+  int achunk[NA];
+  int apy[CONV ? NA : 1], apx[CONV ? NA : 1];     // CONV: pixel of the lane's row
+  unsigned a_dst[NA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = 8 * (wave * 2 + i) + (lane >> 3);
+  for (int i = 0; i < NA; ++i) {
+    const int r = 8 * (wave * NA + i) + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     int m = m0 + r;
     m = m < M ? m : M - 1;
     int64_t row = m;
-    if (p.sub > 1) {
+    if (CONV) {
+      const int hw = p.Hi * p.Wi;
+      const int rem = m - (m / hw) * hw;
+      apy[i] = rem / p.Wi;
+      apx[i] = rem - apy[i] * p.Wi;
+    } else if (p.sub > 1) {
       const int hw = p.Ho * p.Wo;
       const int b = m / hw, rem = m - b * hw;
       const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
@@ -139,30 +161,41 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
     }
     asrc[i] = p.A + row * p.lda + c * 4;
     achunk[i] = c * 4;
-    a_dst[i] = lds0 + DMA_B_BYTES + (wave_u * 2 + i) * 1024;
+    a_dst[i] = lds0 + B_BYTES + (wave_u * NA + i) * 1024;
   }
-  // ---- W pieces: piece = wave*4 + i -> k-group q = piece >> 1, column half
-  unsigned wvoff[4], w_dst[4];
+  // ---- W pieces: 1 KiB = 64 columns of one k-group; LDS image [8][BN_][4]
+  unsigned wvoff[NW], w_dst[NW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i, q = piece >> 1, half = piece & 1;
+  for (int i = 0; i < NW; ++i) {
+    const int piece = wave * NW + i;
+    const int q = LAYOUT == 0 ? piece >> 1 : piece, half = LAYOUT == 0 ? piece & 1 : 0;
     wvoff[i] = static_cast<unsigned>((q * npad + half * 64 + lane) * 16);
-    w_dst[i] = lds0 + (wave_u * 4 + i) * 1024;
+    w_dst[i] = lds0 + (wave_u * NW + i) * 1024;
   }
   const float* wsb = p.Wp + static_cast<int64_t>(n0) * 4;       // uniform
   const int64_t wstep_tile = static_cast<int64_t>(8) * npad * 4;
 
-  // One LDS-DMA piece of tile kt (pieces 0-1: A rows, 2-5: W k-group halves).
+  // One LDS-DMA piece of tile kt (pieces 0..NA-1: A rows, NA..5: W k-groups).
   auto issue_piece = [&](int kt, int stage, auto piece_tag, auto tail_tag) {
     constexpr int PIECE = decltype(piece_tag)::value;
     constexpr bool TAIL = decltype(tail_tag)::value;
     const unsigned so = static_cast<unsigned>(stage) * DMA_STAGE_BYTES;
-    if constexpr (PIECE < 2) {
-      const float* src = asrc[PIECE] + kt * BK;
-      if (TAIL) src = (kt * BK + achunk[PIECE] < K) ? src : g_zero_chunk;
+    if constexpr (PIECE < NA) {
+      const float* src;
+      if constexpr (CONV) {
+        const int tap = kt / cblocks, cb = kt - tap * cblocks;       // uniform
+        const int ky = tap / 3, dy = ky - 1, dx = tap - ky * 3 - 1;
+        const bool ok = static_cast<unsigned>(apy[PIECE] + dy) < static_cast<unsigned>(p.Hi) &&
+                        static_cast<unsigned>(apx[PIECE] + dx) < static_cast<unsigned>(p.Wi);
+        src = asrc[PIECE] + ((dy * p.Wi + dx) * p.lda + cb * BK);
+        src = ok ? src : g_zero_chunk;
+      } else {
+        src = asrc[PIECE] + kt * BK;
+        if (TAIL) src = (kt * BK + achunk[PIECE] < K) ? src : g_zero_chunk;
+      }
       glds16_v(src, a_dst[PIECE] + so);
     } else {
-      glds16_s(wvoff[PIECE - 2], wsb + kt * wstep_tile, w_dst[PIECE - 2] + so);
+      glds16_s(wvoff[PIECE - NA], wsb + kt * wstep_tile, w_dst[PIECE - NA] + so);
     }
   };
   auto issue = [&](int kt, int stage, auto tail_tag) {
@@ -180,16 +213,16 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
     const int sw = (l31 >> 1) & 7;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      a_off[g] = DMA_B_BYTES / 4 + (wm * 32 + l31) * BK + (((2 * g + h) ^ sw) << 2);
+      a_off[g] = B_BYTES / 4 + (wm * 32 + l31) * BK + (((2 * g + h) ^ sw) << 2);
   }
-  const int b_off = (h * BN + wn * 64 + l31) * 4;
+  const int b_off = (h * BN_ + wn * 64 + l31) * 4;
   float4 fa, fb[2];
   auto read_frags = [&](int stage, auto g_tag) {
     constexpr int g = decltype(g_tag)::value;
     const float* s = smem + stage * (DMA_STAGE_BYTES / 4);
     fa = *reinterpret_cast<const float4*>(s + a_off[g]);
-    fb[0] = *reinterpret_cast<const float4*>(s + b_off + g * 2 * BN * 4);
-    fb[1] = *reinterpret_cast<const float4*>(s + b_off + g * 2 * BN * 4 + 32 * 4);
+    fb[0] = *reinterpret_cast<const float4*>(s + b_off + g * 2 * BN_ * 4);
+    fb[1] = *reinterpret_cast<const float4*>(s + b_off + g * 2 * BN_ * 4 + 32 * 4);
   };
 
   f32x16 acc[2];
@@ -837,18 +870,18 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_sk_f32(SkArgs a_) {
 #endif
 }
 
-template <bool HAS_RES>
+template <bool HAS_RES, int LAYOUT, bool CONV>
 int launch_dma_t(const GroupedArgs& g, int total, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(pointwise_gemm_dma_f32<HAS_RES>),
+        reinterpret_cast<const void*>(pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV>),
         hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
     attr_set = true;
   }
   // 72 KB per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL((pointwise_gemm_dma_f32<HAS_RES>), dim3(total), dim3(THREADS),
-                     DMA_LDS_BYTES, s, g);
+  hipLaunchKernelGGL((pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV>), dim3(total),
+                     dim3(THREADS), DMA_LDS_BYTES, s, g);
   return launch_status("pointwise_gemm_dma_f32");
 }
 
@@ -871,20 +904,38 @@ int launch_sk_t(const SkArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s) {
+int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s,
+                       const int* conv_cin) {
   GroupedArgs g;
   g.count = count;
+  int max_n = 0;
+  for (int i = 0; i < count; ++i) max_n = args[i].N > max_n ? args[i].N : max_n;
+  const bool narrow = max_n <= 64;             // 128 x 64 tiles (LAYOUT 1)
+  const int bm = narrow ? 128 : 64, bn = narrow ? 64 : BN;
   int total = 0;
   for (int i = 0; i < count; ++i) {
     g.p[i] = args[i];
     g.npad[i] = static_cast<int>(round_up(args[i].N, BN));
-    g.tiles_n[i] = g.npad[i] / BN;
+    g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, bn));
+    g.conv_cin[i] = conv_cin ? conv_cin[i] : 0;
     g.tile_start[i] = total;
-    total += static_cast<int>(ceil_div(args[i].M, 64)) * g.tiles_n[i];
+    total += static_cast<int>(ceil_div(args[i].M, bm)) * g.tiles_n[i];
   }
   for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
-  return args[0].R != nullptr ? launch_dma_t<true>(g, total, s)
-                              : launch_dma_t<false>(g, total, s);
+  const bool res = args[0].R != nullptr;
+  if (conv_cin) {
+    if (res) {
+      set_error("launch_grouped_dma: implicit conv with a residual is not instantiated");
+      return EPOS_E_INVALID;
+    }
+    return narrow ? launch_dma_t<false, 1, true>(g, total, s)
+                  : launch_dma_t<false, 0, true>(g, total, s);
+  }
+  if (narrow)
+    return res ? launch_dma_t<true, 1, false>(g, total, s)
+               : launch_dma_t<false, 1, false>(g, total, s);
+  return res ? launch_dma_t<true, 0, false>(g, total, s)
+             : launch_dma_t<false, 0, false>(g, total, s);
 }
 
 int launch_grouped_sk(const EposPointwiseArgs* args, int count, void* workspace,

@@ -14,7 +14,8 @@ Fusion groups:
   * pointwise 1x1 (+BN, +residual add, +ReLU) is one fp32-MFMA GEMM launch that
     can read/write channel slices of the ASPP / decoder concat buffers, so no
     concat copy exists;
-  * the two dense 3x3 stem convs are im2col + the same GEMM.
+  * dense 3x3 stem convs: stride 1 with Cin % 32 == 0 (conv1_2) is an implicit GEMM
+    inside the LDS-DMA kernel; the 3-channel stride-2 conv1_1 is im2col + the same GEMM.
 torch is used for device memory and streams only.
 """
 import ctypes
@@ -192,6 +193,21 @@ class EposNet(object):
     ho = hi if stride == 1 else (hi - 1) // 2 + 1
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     k = 9 * cin
+    if stride == 1 and rate == 1 and cin % 32 == 0 and not preprocess:
+      # implicit GEMM: the LDS-DMA kernel gathers the shifted input pixels itself
+      w_kn, scale, bias = self._conv_params(scope, eps)
+      wp, bp, kpad = self._pack_pointwise(w_kn, scale, bias)
+      cout = w_kn.shape[1]
+      y = self._empty(self.B, ho, wo, cout)
+      cargs = _lib.Conv3x3Args(X=_ptr(x), ldx=cin, Wp=_ptr(wp), bias=_ptr(bp),
+                               Y=_ptr(y), ldy=cout, B=self.B, H=hi, W=wi, Cin=cin,
+                               Cout=cout, relu=1)
+      lib = self.lib
+
+      def run_conv(stream, cargs=cargs):
+        _lib.check(lib.epos_conv3x3_f32(ctypes.byref(cargs), stream), name)
+      self._add(name, run_conv, 2 * self.B * ho * wo * cout * k, 'gemm')
+      return y, ho, wo, cout
     ldcol = (k + 3) // 4 * 4
     m = self.B * ho * wo
     col = self._empty(m, ldcol)

@@ -167,6 +167,35 @@ def test_pointwise_stride2_shortcut(lib):
   np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('b,h,w,cin,cout', [(2, 12, 16, 32, 64), (1, 9, 21, 64, 40),
+                                            (2, 7, 5, 32, 136), (1, 30, 44, 96, 64)])
+def test_conv3x3_implicit_gemm(lib, b, h, w, cin, cout):
+  """Dense 3x3 'SAME' conv as an implicit GEMM in the LDS-DMA kernel (taps gathered
+  by the DMA, zero block outside the image) vs conv2d_same of the oracle
+  (external/slim/nets/resnet_utils.py:77-122): both tile layouts (Cout <= 64 and
+  > 64), one and several channel blocks per tap, ragged M tiles."""
+  from epos_amd import _lib
+  from oracle import net_ref
+  rng = np.random.RandomState(b * h + cin)
+  x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+  wgt = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+  bias = rng.standard_normal(cout).astype(np.float32)
+  ref = net_ref.conv2d_raw(torch.from_numpy(x).permute(0, 3, 1, 2), wgt, 1, 1,
+                           'SAME').permute(0, 2, 3, 1).numpy() + bias
+  ref = np.maximum(ref, 0)
+  X = torch.from_numpy(x).cuda()
+  Wp = _pack(lib, wgt.reshape(9 * cin, cout))
+  npad = (cout + 127) // 128 * 128
+  bpad = np.zeros(npad, np.float32); bpad[:cout] = bias
+  Bd = torch.from_numpy(bpad).cuda()
+  Y = torch.full((b, h, w, cout), -3.0, device='cuda')
+  args = _lib.Conv3x3Args(X=_p(X), ldx=cin, Wp=_p(Wp), bias=_p(Bd), Y=_p(Y), ldy=cout,
+                          B=b, H=h, W=w, Cin=cin, Cout=cout, relu=1)
+  _lib.check(lib.epos_conv3x3_f32(ctypes.byref(args), None))
+  torch.cuda.synchronize()
+  np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize('hi,wi,c,stride,rate', [
     (17, 23, 32, 1, 1), (16, 24, 64, 2, 1), (15, 21, 8, 2, 1), (20, 28, 16, 1, 2),
     (60, 80, 8, 1, 12), (30, 40, 8, 1, 36), (9, 9, 12, 1, 4)])

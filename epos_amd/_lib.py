@@ -54,6 +54,7 @@ class Conv3x3Args(ctypes.Structure):
       ('Y', vp), ('ldy', ctypes.c_int64),
       ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
       ('Cin', ctypes.c_int32), ('Cout', ctypes.c_int32),
+      ('stride', ctypes.c_int32), ('rate', ctypes.c_int32),
       ('relu', ctypes.c_int32),
   ]
 

@@ -12,10 +12,11 @@ namespace epos {
 
 // Launchers defined in pointwise_gemm_dma.hip (the default data path for every GEMM
 // without a pre-activation ReLU, and the opt-in persistent stream-K variant).
-// conv_cin != nullptr: implicit 3x3 'SAME' conv, problem i has conv_cin[i] input channels
-// (K = 9 * conv_cin[i], A = the NHWC input, Hi/Wi = its height/width).
+// conv_cin != nullptr: implicit 3x3 conv, problem i has conv_cin[i] input channels and
+// dilation conv_rate[i] (K = 9 * conv_cin[i], A = the NHWC input of Hi x Wi pixels,
+// `sub` = stride, M = B * Ho * Wo output pixels).
 int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s,
-                       const int* conv_cin = nullptr);
+                       const int* conv_cin = nullptr, const int* conv_rate = nullptr);
 int launch_grouped_sk(const EposPointwiseArgs* args, int count, void* workspace,
                       hipStream_t s);
 int64_t sk_workspace_bytes();
@@ -37,6 +38,7 @@ struct GroupedArgs {
   int tiles_n[MAX_GROUP];
   int npad[MAX_GROUP];
   int conv_cin[MAX_GROUP];         // LDS-DMA kernel, implicit 3x3 conv: input channels
+  int conv_rate[MAX_GROUP];        //   and dilation
   int count;
 };
 

@@ -690,17 +690,19 @@ extern "C" int epos_conv3x3_f32(const EposConv3x3Args* a, void* stream) {
   EPOS_REQUIRE(a->ldx % 4 == 0 && a->ldx >= a->Cin, "ldx: multiple of 4, >= Cin");
   EPOS_REQUIRE((reinterpret_cast<uintptr_t>(a->X) & 15) == 0, "X must be 16-byte aligned");
   EPOS_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cout > 0, "empty problem");
+  EPOS_REQUIRE((a->stride == 1 || a->stride == 2) && a->rate >= 1, "stride 1|2, rate >= 1");
+  const int ho = (a->H - 1) / a->stride + 1, wo = (a->W - 1) / a->stride + 1;
   EPOS_REQUIRE(static_cast<int64_t>(a->B) * a->H * a->W < (1LL << 31), "too many pixels");
   EposPointwiseArgs p = {};
   p.A = a->X; p.lda = a->ldx;
   p.Wp = a->Wp; p.bias = a->bias;
   p.R = nullptr; p.ldr = 0;
   p.C = a->Y; p.ldc = a->ldy;
-  p.M = a->B * a->H * a->W; p.N = a->Cout; p.K = 9 * a->Cin;
-  p.relu = a->relu; p.relu_in = 0; p.sub = 1;
-  p.Ho = a->H; p.Wo = a->W; p.Hi = a->H; p.Wi = a->W;
-  const int cin = a->Cin;
-  return launch_grouped_dma(&p, 1, static_cast<hipStream_t>(stream), &cin);
+  p.M = a->B * ho * wo; p.N = a->Cout; p.K = 9 * a->Cin;
+  p.relu = a->relu; p.relu_in = 0; p.sub = a->stride;
+  p.Ho = ho; p.Wo = wo; p.Hi = a->H; p.Wi = a->W;
+  const int cin = a->Cin, rate = a->rate;
+  return launch_grouped_dma(&p, 1, static_cast<hipStream_t>(stream), &cin, &rate);
 }
 
 extern "C" int epos_pointwise_conv_f32(const EposPointwiseArgs* a, void* stream) {

@@ -77,11 +77,14 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const float* sbase,
 // problem of the launch has N <= 64: a 128-wide tile would waste half of its MFMAs).
 // The per-wave tile (32 x 64), the six DMA pieces per wave and K tile and the 24 KB
 // stage are the same in both.
-// CONV: implicit GEMM of a dense 3x3 stride-1 'SAME' conv with Cin % 32 == 0
-// (conv1_2, net_xception.py:462-463): K tile kt is channel block kt % (Cin/32) of
-// tap kt / (Cin/32), i.e. the A rows are the input pixels shifted by the tap -- the
-// im2col matrix only ever exists as LDS tiles. Taps outside the image come from a
-// zero block (a per-lane source select, as for the partial last K tile).
+// CONV: implicit GEMM of a dense 3x3 conv with Cin % 32 == 0 (conv2d_same,
+// external/slim/nets/resnet_utils.py:77-122: stride 1 = 'SAME' with dilation `rate`,
+// stride 2 = explicit pad `rate` + VALID; conv1_2 net_xception.py:462-463, the root and
+// bottleneck 3x3 convs of net_resnet_v1_beta.py): K tile kt is channel block
+// kt % (Cin/32) of tap kt / (Cin/32), i.e. the A rows are the input pixels
+// (y*stride + dy*rate, x*stride + dx*rate) -- the im2col matrix only ever exists as
+// LDS tiles. Taps outside the image come from a zero block (a per-lane source
+// select, as for the partial last K tile).
 template <bool HAS_RES, int LAYOUT, bool CONV>
 __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga_) {
   constexpr int BM_ = LAYOUT == 0 ? 64 : 128;
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
   const int M = p.M, N = p.N, K = p.K;
   const int nk = (K + BK - 1) / BK;
   const int cblocks = CONV ? gp->conv_cin[pi] / BK : 1;   // channel blocks per tap
+  const int crate = CONV ? gp->conv_rate[pi] : 1;
 
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
@@ -148,11 +152,13 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
     int m = m0 + r;
     m = m < M ? m : M - 1;
     int64_t row = m;
-    if (CONV) {
-      const int hw = p.Hi * p.Wi;
-      const int rem = m - (m / hw) * hw;
-      apy[i] = rem / p.Wi;
-      apx[i] = rem - apy[i] * p.Wi;
+    if (CONV) {                      // centre tap of output pixel m
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      apy[i] = yo * p.sub;
+      apx[i] = xo * p.sub;
+      row = (static_cast<int64_t>(b) * p.Hi + apy[i]) * p.Wi + apx[i];
     } else if (p.sub > 1) {
       const int hw = p.Ho * p.Wo;
       const int b = m / hw, rem = m - b * hw;
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
       const float* src;
       if constexpr (CONV) {
         const int tap = kt / cblocks, cb = kt - tap * cblocks;       // uniform
-        const int ky = tap / 3, dy = ky - 1, dx = tap - ky * 3 - 1;
+        const int ky = tap / 3, dy = (ky - 1) * crate, dx = (tap - ky * 3 - 1) * crate;
         const bool ok = static_cast<unsigned>(apy[PIECE] + dy) < static_cast<unsigned>(p.Hi) &&
                         static_cast<unsigned>(apx[PIECE] + dx) < static_cast<unsigned>(p.Wi);
         src = asrc[PIECE] + ((dy * p.Wi + dx) * p.lda + cb * BK);
@@ -905,7 +911,7 @@ int launch_sk_t(const SkArgs& a, hipStream_t s) {
 }  // namespace
 
 int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s,
-                       const int* conv_cin) {
+                       const int* conv_cin, const int* conv_rate) {
   GroupedArgs g;
   g.count = count;
   int max_n = 0;
@@ -918,6 +924,7 @@ int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s,
     g.npad[i] = static_cast<int>(round_up(args[i].N, BN));
     g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, bn));
     g.conv_cin[i] = conv_cin ? conv_cin[i] : 0;
+    g.conv_rate[i] = conv_rate ? conv_rate[i] : 1;
     g.tile_start[i] = total;
     total += static_cast<int>(ceil_div(args[i].M, bm)) * g.tiles_n[i];
   }

@@ -193,7 +193,7 @@ class EposNet(object):
     ho = hi if stride == 1 else (hi - 1) // 2 + 1
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     k = 9 * cin
-    if stride == 1 and rate == 1 and cin % 32 == 0 and not preprocess:
+    if cin % 32 == 0 and not preprocess:
       # implicit GEMM: the LDS-DMA kernel gathers the shifted input pixels itself
       w_kn, scale, bias = self._conv_params(scope, eps)
       wp, bp, kpad = self._pack_pointwise(w_kn, scale, bias)
@@ -201,7 +201,7 @@ class EposNet(object):
       y = self._empty(self.B, ho, wo, cout)
       cargs = _lib.Conv3x3Args(X=_ptr(x), ldx=cin, Wp=_ptr(wp), bias=_ptr(bp),
                                Y=_ptr(y), ldy=cout, B=self.B, H=hi, W=wi, Cin=cin,
-                               Cout=cout, relu=1)
+                               Cout=cout, stride=stride, rate=rate, relu=1)
       lib = self.lib
 
       def run_conv(stream, cargs=cargs):

@@ -102,19 +102,23 @@ int epos_pointwise_conv_grouped_sk_f32(const EposPointwiseArgs* args, int count,
 int epos_pointwise_conv_grouped_ws_f32(const EposPointwiseArgs* args, int count,
                                        void* workspace, void* stream);
 
-/* Dense 3x3 conv, stride 1, 'SAME' (zero pad 1) + folded BatchNorm (+ ReLU) as an
- * IMPLICIT GEMM: the im2col matrix only exists as LDS tiles filled by LDS-DMA from the
- * shifted input pixels. Replaces resnet_utils.conv2d_same(stride=1) at
- * net_xception.py:462-463 (conv1_2) and the stride-1 root convs of
- * net_resnet_v1_beta.py:96-112. X [device]: [B, H, W] pixels, rows of ldx floats, Cin
- * channels used (Cin % 32 == 0); Wp [device]: epos_pack_pointwise_weights of the
- * [9*Cin][Cout] matrix whose row (ky*3+kx)*Cin + c is TF's HWIO w[ky][kx][c][:]; bias
- * [device]: round_up(Cout,128) floats or NULL; Y [device]: [B, H, W] rows of ldy floats. */
+/* Dense 3x3 conv + folded BatchNorm (+ ReLU) as an IMPLICIT GEMM: the im2col matrix
+ * only exists as LDS tiles filled by LDS-DMA from the shifted input pixels. Semantics =
+ * resnet_utils.conv2d_same (external/slim/nets/resnet_utils.py:77-122): stride 1 ->
+ * 'SAME' with dilation `rate` (zero pad = rate); stride 2 -> zero pad `rate` on every
+ * side + VALID. Output (y, x) reads input (y*stride + (ky-1)*rate, x*stride + (kx-1)*rate).
+ * Replaces conv1_2 (net_xception.py:462-463) and the stride-1 root convs and the
+ * bottleneck 3x3 convs of net_resnet_v1_beta.py:38-112. X [device]: [B, H, W] pixels,
+ * rows of ldx floats, Cin channels used (Cin % 32 == 0); Wp [device]:
+ * epos_pack_pointwise_weights of the [9*Cin][Cout] matrix whose row (ky*3+kx)*Cin + c is
+ * TF's HWIO w[ky][kx][c][:]; bias [device]: round_up(Cout,128) floats or NULL; Y
+ * [device]: [B, Ho, Wo] rows of ldy floats, Ho = (H-1)/stride + 1. */
 typedef struct EposConv3x3Args {
   const float* X; int64_t ldx;
   const float* Wp; const float* bias;
   float* Y; int64_t ldy;
   int32_t B, H, W, Cin, Cout;
+  int32_t stride, rate;
   int32_t relu;
 } EposConv3x3Args;
 int epos_conv3x3_f32(const EposConv3x3Args* args, void* stream);

@@ -167,9 +167,11 @@ def test_pointwise_stride2_shortcut(lib):
   np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('b,h,w,cin,cout', [(2, 12, 16, 32, 64), (1, 9, 21, 64, 40),
-                                            (2, 7, 5, 32, 136), (1, 30, 44, 96, 64)])
-def test_conv3x3_implicit_gemm(lib, b, h, w, cin, cout):
+@pytest.mark.parametrize('b,h,w,cin,cout,stride,rate', [
+    (2, 12, 16, 32, 64, 1, 1), (1, 9, 21, 64, 40, 1, 1), (2, 7, 5, 32, 136, 1, 1),
+    (1, 30, 44, 96, 64, 1, 1), (2, 15, 21, 64, 72, 2, 1), (1, 16, 24, 32, 64, 2, 1),
+    (1, 20, 28, 64, 130, 1, 2), (2, 13, 17, 32, 48, 1, 4)])
+def test_conv3x3_implicit_gemm(lib, b, h, w, cin, cout, stride, rate):
   """Dense 3x3 'SAME' conv as an implicit GEMM in the LDS-DMA kernel (taps gathered
   by the DMA, zero block outside the image) vs conv2d_same of the oracle
   (external/slim/nets/resnet_utils.py:77-122): both tile layouts (Cout <= 64 and
@@ -180,17 +182,22 @@ def test_conv3x3_implicit_gemm(lib, b, h, w, cin, cout):
   x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
   wgt = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
   bias = rng.standard_normal(cout).astype(np.float32)
-  ref = net_ref.conv2d_raw(torch.from_numpy(x).permute(0, 3, 1, 2), wgt, 1, 1,
-                           'SAME').permute(0, 2, 3, 1).numpy() + bias
-  ref = np.maximum(ref, 0)
+  xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+  if stride == 1:
+    ref = net_ref.conv2d_raw(xt, wgt, 1, rate, 'SAME')
+  else:                               # conv2d_same: explicit pad + VALID
+    ref = net_ref.conv2d_raw(net_ref.fixed_padding(xt, 3, rate), wgt, stride, rate, 'VALID')
+  ref = np.maximum(ref.permute(0, 2, 3, 1).numpy() + bias, 0)
+  ho, wo = ref.shape[1], ref.shape[2]
   X = torch.from_numpy(x).cuda()
   Wp = _pack(lib, wgt.reshape(9 * cin, cout))
   npad = (cout + 127) // 128 * 128
   bpad = np.zeros(npad, np.float32); bpad[:cout] = bias
   Bd = torch.from_numpy(bpad).cuda()
-  Y = torch.full((b, h, w, cout), -3.0, device='cuda')
+  Y = torch.full((b, ho, wo, cout), -3.0, device='cuda')
   args = _lib.Conv3x3Args(X=_p(X), ldx=cin, Wp=_p(Wp), bias=_p(Bd), Y=_p(Y), ldy=cout,
-                          B=b, H=h, W=w, Cin=cin, Cout=cout, relu=1)
+                          B=b, H=h, W=w, Cin=cin, Cout=cout, stride=stride, rate=rate,
+                          relu=1)
   _lib.check(lib.epos_conv3x3_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)

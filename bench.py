@@ -51,6 +51,10 @@ def parse_args():
   ap.add_argument('--num-objs', type=int, default=21)
   ap.add_argument('--num-frags', type=int, default=64)
   ap.add_argument('--objs-per-image', type=int, default=5)
+  ap.add_argument('--model-variant', default='xception_65',
+                  choices=['xception_65', 'resnet_v1_101_beta'],
+                  help='backbone (the headline workload C2 is xception_65; '
+                       'resnet_v1_101_beta with --num-objs 15 --batch-per-gpu 8 is C5)')
   ap.add_argument('--no-calibrate', action='store_true',
                   help='keep the raw random-init logits layers (every confidence '
                        'then stays below tau_a and corr/RANSAC get no work)')
@@ -184,13 +188,16 @@ def main():
   # layers (identity BN lets them decay to 1e-3, which both starves the heads and
   # flatters the clocks), and the logits layers are calibrated on one frame so
   # that the correspondence / RANSAC stages see YCB-V-like amounts of work.
-  ckpt = weights.random_init(num_objs=args.num_objs, num_frags=args.num_frags,
-                             seed=0, randomize_bn=True)
+  ckpt = weights.random_init(args.model_variant, num_objs=args.num_objs,
+                             num_frags=args.num_frags, seed=0, randomize_bn=True)
+  from epos_amd import model
+  mo = model.ModelOptions(
+      model.get_outputs_to_num_channels(args.num_objs, args.num_frags),
+      model_variant=args.model_variant)
   store = synthetic.ModelStore(args.num_objs, args.num_frags, seed=0)
   if not args.no_calibrate:
-    from epos_amd import model
     net0 = model.get_net(ckpt, 1, args.height, args.width, args.num_objs,
-                         args.num_frags, device=dev)
+                         args.num_frags, mo, device=dev)
     net0.forward(torch.from_numpy(
         synthetic.image(0, args.height, args.width)[None]).to(dev))
     torch.cuda.synchronize()
@@ -201,7 +208,8 @@ def main():
   pipes = [pipeline.EposPipeline(
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
       capacity=1 << 21, max_instances=1, device=dev,
-      use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads)
+      use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads,
+      model_options=mo)
            for j in range(depth)]
   pipe = pipes[0]
   # Synthetic frames, resident in HBM before the timed region.
@@ -264,7 +272,7 @@ def main():
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
       'config': {
-          'workload': 'C2: synthetic 640x480 RGB, xception_65 random-init '
+          'workload': 'C2: synthetic 640x480 RGB, %s random-init ' % args.model_variant +
                       '(reference initialisers, randomised BN statistics, logits '
                       'layers %s), %d objects x %d fragments, %d target '
                       'objects/image, batch %d per GPU, dense heads + corr + '

@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
 // divisions by launch constants use precomputed multipliers, ReLU is one v_med3 per
 // component and a compile-time option, and a wave whose lanes all lie in the interior
 // of the image (no tap outside) takes a path without any clamp or select.
+#ifndef EPOS_DW_MIN_BLOCKS
+#define EPOS_DW_MIN_BLOCKS 4     // <= 128 VGPRs: see DESIGN.md (co-residency with GEMM waves)
+#endif
 struct FastDiv {                 // n / d for any 32-bit n (Granlund-Montgomery)
   unsigned mul, sh1, sh2, d;
 };
@@ -112,7 +115,7 @@ __device__ __forceinline__ float4 relu4_1op(float4 v) {
 }
 
 template <int L, bool RELU_IN, bool RELU_OUT>
-__global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(EposDepthwiseArgs p,
+__global__ __launch_bounds__(256, EPOS_DW_MIN_BLOCKS) void depthwise3x3_s1_kernel(EposDepthwiseArgs p,
                                                               int c4n, int nres,
                                                               int nchunk,
                                                               DwPartition part) {

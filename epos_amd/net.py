@@ -40,6 +40,17 @@ def scale_dimension(dim, scale):
   return int((float(dim) - 1.0) * scale + 1.0)
 
 
+_CAPTURE_STREAMS = {}
+
+
+def _capture_stream(dev):
+  """One shared side stream per device for graph capture from the default stream."""
+  key = str(dev)
+  if key not in _CAPTURE_STREAMS:
+    _CAPTURE_STREAMS[key] = torch.cuda.Stream(dev)
+  return _CAPTURE_STREAMS[key]
+
+
 class EposNet(object):
   """Static-shape forward plan. ``forward(images)`` returns the logits buffers;
   ``predict(images)`` the reference's prediction dict (model.py:629-687)."""
@@ -629,7 +640,12 @@ class EposNet(object):
   def capture_graph(self, sparse=False):
     """Captures the plan (dense, or the sparse-mode trunk) into one hipGraph."""
     torch.cuda.synchronize(self.dev)
-    side = torch.cuda.Stream(self.dev)
+    # Capture on the caller's stream when it is not the default one (the pipeline's
+    # own stream): every extra HIP stream shifts the stream -> hardware-queue mapping
+    # (4 queues), and two pipelines sharing a queue serialise against each other.
+    side = torch.cuda.current_stream(self.dev)
+    if side == torch.cuda.default_stream(self.dev):
+      side = _capture_stream(self.dev)
     with torch.cuda.stream(side):
       self.run_plan(sparse=sparse)         # warm-up outside capture
     torch.cuda.synchronize(self.dev)

@@ -288,7 +288,15 @@ __global__ __launch_bounds__(1024) void global_avg_pool_kernel(
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
     const float* xb = X + static_cast<int64_t>(b) * HW * ldx + c;
-    for (int r = phase; r < HW; r += 64) {
+    int r = phase;
+    for (; r + 7 * 64 < HW; r += 8 * 64) {        // eight rows in flight per thread
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4(xb + static_cast<int64_t>(r + u * 64) * ldx);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; r < HW; r += 64) {
       const float4 v = ld4(xb + static_cast<int64_t>(r) * ldx);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }

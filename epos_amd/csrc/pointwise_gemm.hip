@@ -482,11 +482,15 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_wp_f32(GroupedArgs ga_
 }
 // ---------------------------------------------------------------------------
 // M <= 8 rows (the image-pooling branch, model.py:223-224, M = batch): a GEMV.
-// Block = 64 output channels x 4 K-slices; fixed-order LDS reduction.
+// Block = 64 output channels x 16 K-slices (1024 threads); every thread keeps eight
+// independent loads in flight (the first version, 4 slices and one dependent load
+// per iteration, took 62 us for this 1 MFLOP); fixed-order LDS reduction.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pointwise_gemv_f32(EposPointwiseArgs p,
-                                                          int npad) {
-  __shared__ float part[4][64];
+constexpr int GEMV_SLICES = 16;
+
+__global__ __launch_bounds__(64 * GEMV_SLICES) void pointwise_gemv_f32(EposPointwiseArgs p,
+                                                                       int npad) {
+  __shared__ float part[GEMV_SLICES][64];
   const int t = threadIdx.x;
   const int n = blockIdx.x * 64 + (t & 63);
   const int ks = t >> 6;
@@ -494,7 +498,25 @@ __global__ __launch_bounds__(256) void pointwise_gemv_f32(EposPointwiseArgs p,
   const float* a = p.A + static_cast<int64_t>(m) * p.lda;
   const int kq = p.K / 4;
   float acc = 0.f;
-  for (int q = ks; q < kq; q += 4) {
+  int q = ks;
+  for (; q + 7 * GEMV_SLICES < kq; q += 8 * GEMV_SLICES) {
+    float4 av[8], wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      av[u] = *reinterpret_cast<const float4*>(a + (q + u * GEMV_SLICES) * 4);
+      wv[u] = *reinterpret_cast<const float4*>(
+          p.Wp + (static_cast<int64_t>(q + u * GEMV_SLICES) * npad + n) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (p.relu_in) av[u] = relu4(av[u]);
+      acc = fmaf(av[u].x, wv[u].x, acc);
+      acc = fmaf(av[u].y, wv[u].y, acc);
+      acc = fmaf(av[u].z, wv[u].z, acc);
+      acc = fmaf(av[u].w, wv[u].w, acc);
+    }
+  }
+  for (; q < kq; q += GEMV_SLICES) {
     float4 av = *reinterpret_cast<const float4*>(a + q * 4);
     if (p.relu_in) av = relu4(av);
     const float4 wv = *reinterpret_cast<const float4*>(
@@ -507,7 +529,9 @@ __global__ __launch_bounds__(256) void pointwise_gemv_f32(EposPointwiseArgs p,
   part[ks][t & 63] = acc;
   __syncthreads();
   if (ks == 0 && n < p.N) {
-    float v = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+    float v = part[0][t];
+#pragma unroll
+    for (int i = 1; i < GEMV_SLICES; ++i) v += part[i][t];
     if (p.bias) v += p.bias[n];
     if (p.R) v += p.R[static_cast<int64_t>(m) * p.ldr + n];
     if (p.relu) v = fmaxf(v, 0.f);
@@ -647,8 +671,8 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
   }
   if (count == 1 && args[0].M <= 8 && args[0].sub == 1) {
     const int npad = static_cast<int>(round_up(args[0].N, BN));
-    hipLaunchKernelGGL(pointwise_gemv_f32, dim3(npad / 64, args[0].M), dim3(256), 0,
-                       s, args[0], npad);
+    hipLaunchKernelGGL(pointwise_gemv_f32, dim3(npad / 64, args[0].M),
+                       dim3(64 * GEMV_SLICES), 0, s, args[0], npad);
     return launch_status("pointwise_gemv_f32");
   }
   // LDS-DMA kernel: the default whenever no pre-activation ReLU has to be applied to

@@ -284,28 +284,47 @@ __device__ __forceinline__ bool reproj(const double* pose, const double* K,
   Xc[1] = pose[3] * xyz[0] + pose[4] * xyz[1] + pose[5] * xyz[2] + pose[10];
   Xc[2] = pose[6] * xyz[0] + pose[7] * xyz[1] + pose[8] * xyz[2] + pose[11];
   if (!(Xc[2] > 0.0)) return true;
-  const double px = (K[0] * Xc[0] + K[1] * Xc[1]) / Xc[2] + K[2];
-  const double py = (K[4] * Xc[1]) / Xc[2] + K[5];
+  const double iz = 1.0 / Xc[2];               // the only division per point
+  const double px = (K[0] * Xc[0] + K[1] * Xc[1]) * iz + K[2];
+  const double py = (K[4] * Xc[1]) * iz + K[5];
   r[0] = px - xy[0];
   r[1] = py - xy[1];
   *e2 = r[0] * r[0] + r[1] * r[1];
   return false;
 }
 
-// MSAC score + inlier count of `pose` over idx[0..m) (wave-wide; result uniform)
-__device__ double score_pose(const double* pose, const double* K, const double* xy,
-                             const double* xyz, const int32_t* idx, int64_t m,
-                             double thr2, int lane, int* count) {
-  double acc = 0.0;
-  int cnt = 0;
+// MSAC scores + inlier counts of `ns` (<= 4) poses over idx[0..m) in ONE pass over
+// the correspondences (wave-wide; results uniform). Each pose's sum keeps the
+// canonical order: 64 strided per-lane partials, then the xor butterfly.
+__device__ void score_poses(const double* poses, int ns, const double* K,
+                            const double* xy, const double* xyz, const int32_t* idx,
+                            int64_t m, double thr2, int lane, double* score,
+                            int* count) {
+  const double inv_thr2 = 1.0 / thr2;
+  double acc[MAX_SOL] = {0.0, 0.0, 0.0, 0.0};
+  int cnt[MAX_SOL] = {0, 0, 0, 0};
   for (int64_t i = lane; i < m; i += 64) {
     const int32_t p = idx[i];
-    double e2, Xc[3], r[2];
-    if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
-    if (e2 < thr2) { acc += 1.0 - e2 / thr2; ++cnt; }
+    const double x2[2] = {xy[2 * p], xy[2 * p + 1]};
+    const double x3[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
+#pragma unroll
+    for (int q = 0; q < MAX_SOL; ++q) {
+      if (q < ns) {                                        // wave-uniform
+        double e2, Xc[3], r[2];
+        if (!reproj(poses + 12 * q, K, x2, x3, &e2, Xc, r) && e2 < thr2) {
+          acc[q] += 1.0 - e2 * inv_thr2;
+          ++cnt[q];
+        }
+      }
+    }
   }
-  *count = butterfly_sum_i(cnt);
-  return butterfly_sum(acc);
+#pragma unroll
+  for (int q = 0; q < MAX_SOL; ++q) {
+    if (q < ns) {
+      count[q] = butterfly_sum_i(cnt[q]);
+      score[q] = butterfly_sum(acc[q]);
+    }
+  }
 }
 
 __device__ void bearing(const double* K, const double* xy, double* f) {
@@ -388,12 +407,17 @@ __global__ __launch_bounds__(256) void ransac_hypotheses(
       const double thr2 = prm.threshold * prm.threshold;
       double* hp = w.hyp_pose + (static_cast<int64_t>(s) * prm.max_iters + it) * MAX_SOL * 12;
       int32_t* hc = w.hyp_count + (static_cast<int64_t>(s) * prm.max_iters + it) * MAX_SOL;
-      for (int q = 0; q < ns; ++q) {
-        int cnt;
-        const double sc = score_pose(sols + 12 * q, K, xy, xyz, active, n_active,
-                                     thr2, lane, &cnt);
-        if (lane == 0) { hs[q] = sc; hc[q] = cnt; }
-        if (lane < 12) hp[q * 12 + lane] = sols[12 * q + lane];
+      double sc[MAX_SOL];
+      int cnt[MAX_SOL];
+      score_poses(sols, ns, K, xy, xyz, active, n_active, thr2, lane, sc, cnt);
+#pragma unroll
+      for (int q = 0; q < MAX_SOL; ++q) {
+        if (q < ns) {
+          if (lane == 0) { hs[q] = sc[q]; hc[q] = cnt[q]; }
+#pragma unroll
+          for (int e = 0; e < 12; ++e)
+            if (lane == e) hp[q * 12 + e] = sols[12 * q + e];
+        }
       }
     }
   }
@@ -438,13 +462,47 @@ __device__ int solve6(const double* H /*[36]*/, const double* g, double* x) {
   return 0;
 }
 
-__device__ int gn_step(const double* pose, const double* K, const double* xy,
-                       const double* xyz, const int32_t* idx, int64_t m,
-                       double thr2, int lane, double* next) {
+// ---- workgroup-wide (256 threads) sums of the local optimisation -------------------
+// Canonical order: 256 strided partials (thread t takes items t, t+256, ...), the xor
+// butterfly inside each wave, then (w0 + w1) + (w2 + w3) through LDS. Every thread gets
+// the same value, so the control flow that depends on it stays workgroup-uniform.
+__device__ __forceinline__ double block_combine(double wave_sum, double* s_red, int t) {
+  if ((t & 63) == 0) s_red[t >> 6] = wave_sum;
+  __syncthreads();
+  const double r = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  __syncthreads();
+  return r;
+}
+
+__device__ double score_pose_block(const double* pose, const double* K, const double* xy,
+                                   const double* xyz, const int32_t* idx, int64_t m,
+                                   double thr2, int t, double* s_red, int* s_cnt,
+                                   int* count) {
+  const double inv_thr2 = 1.0 / thr2;
+  double acc = 0.0;
+  int cnt = 0;
+  for (int64_t i = t; i < m; i += 256) {
+    const int32_t p = idx[i];
+    double e2, Xc[3], r[2];
+    if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
+    if (e2 < thr2) { acc += 1.0 - e2 * inv_thr2; ++cnt; }
+  }
+  cnt = butterfly_sum_i(cnt);
+  if ((t & 63) == 0) s_cnt[t >> 6] = cnt;
+  const double sc = block_combine(butterfly_sum(acc), s_red, t);   // two barriers inside
+  *count = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  __syncthreads();
+  return sc;
+}
+
+__device__ int gn_step_block(const double* pose, const double* K, const double* xy,
+                             const double* xyz, const int32_t* idx, int64_t m,
+                             double thr2, int t, double* s_red27 /*[4][27]*/,
+                             double* next) {
   double acc[27];
 #pragma unroll
   for (int v = 0; v < 27; ++v) acc[v] = 0.0;
-  for (int64_t i = lane; i < m; i += 64) {
+  for (int64_t i = t; i < m; i += 256) {
     const int32_t p = idx[i];
     double e2, Xc[3], r[2];
     if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
@@ -471,7 +529,15 @@ __device__ int gn_step(const double* pose, const double* K, const double* xy,
     for (int a = 0; a < 6; ++a) { acc[v] += J0[a] * r[0] + J1[a] * r[1]; ++v; }
   }
 #pragma unroll
-  for (int v = 0; v < 27; ++v) acc[v] = butterfly_sum(acc[v]);
+  for (int v = 0; v < 27; ++v) {
+    const double ws = butterfly_sum(acc[v]);
+    if ((t & 63) == 0) s_red27[(t >> 6) * 27 + v] = ws;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < 27; ++v)
+    acc[v] = (s_red27[v] + s_red27[27 + v]) + (s_red27[54 + v] + s_red27[81 + v]);
+  __syncthreads();
   double H[36], g[6], x[6];
   int v = 0;
   for (int a = 0; a < 6; ++a)
@@ -537,13 +603,16 @@ __global__ __launch_bounds__(256) void ransac_select_refine(
     }
     __syncthreads();
   }
-  if (t >= 64) return;                                     // wave 0 continues
-  const int lane = t;
+  __shared__ double s_red[4];
+  __shared__ double s_red27[4 * 27];
+  __shared__ int s_cnt[4];
+  __shared__ int s_inl[4], s_new[4];
+  const int lane = t & 63, wave = t >> 6;
   double best_score = s_score[0];
   const int bi = s_index[0];
-  if (!(best_score > 0.0)) { if (lane == 0) w.done[s] = 1; return; }
+  if (!(best_score > 0.0)) { if (t == 0) w.done[s] = 1; return; }       // uniform
   int best_count = w.hyp_count[static_cast<int64_t>(s) * nh + bi];
-  if (best_count < 3) { if (lane == 0) w.done[s] = 1; return; }
+  if (best_count < 3) { if (t == 0) w.done[s] = 1; return; }
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
   int32_t* labels = labels_all + base;
@@ -552,25 +621,27 @@ __global__ __launch_bounds__(256) void ransac_select_refine(
   const double thr2 = prm.threshold * prm.threshold;
   double pose[12];
   for (int i = 0; i < 12; ++i) pose[i] = w.hyp_pose[(static_cast<int64_t>(s) * nh + bi) * 12 + i];
-  // ---- local optimisation ----
+  // ---- local optimisation: the whole workgroup sums, every thread steps ----
   orthonormalize(pose);
-  best_score = score_pose(pose, K, xy, xyz, active, n_active, thr2, lane, &best_count);
+  best_score = score_pose_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red, s_cnt,
+                                &best_count);
   for (int li = 0; li < prm.lo_iters; ++li) {
     double cand[12];
-    if (gn_step(pose, K, xy, xyz, active, n_active, thr2, lane, cand)) break;
+    if (gn_step_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red27, cand)) break;
     int cnt;
-    const double sc = score_pose(cand, K, xy, xyz, active, n_active, thr2, lane, &cnt);
+    const double sc = score_pose_block(cand, K, xy, xyz, active, n_active, thr2, t, s_red,
+                                       s_cnt, &cnt);
     if (!(sc > best_score)) break;
     best_score = sc; best_count = cnt;
     for (int i = 0; i < 12; ++i) pose[i] = cand[i];
   }
-  if (best_count < prm.min_point_number) { if (lane == 0) w.done[s] = 1; return; }
-  // ---- inliers over ALL correspondences of the slot -> bitset ----
+  if (best_count < prm.min_point_number) { if (t == 0) w.done[s] = 1; return; }
+  // ---- inliers over ALL correspondences of the slot -> bitset (chunk c: wave c % 4) --
   const int64_t words = (n + 63) / 64;
   const int64_t wbase = base / 64 + s;
   uint64_t* cur = w.inl_bits + static_cast<int64_t>(k) * w.words_total + wbase;
   int n_inl = 0, n_new = 0;
-  for (int64_t c = 0; c < words; ++c) {
+  for (int64_t c = wave; c < words; c += 4) {
     const int64_t i = c * 64 + lane;
     bool inl = false, fresh = false;
     if (i < n) {
@@ -583,6 +654,12 @@ __global__ __launch_bounds__(256) void ransac_select_refine(
     n_new += __popcll(__ballot(fresh));
     if (lane == 0) cur[c] = bits;
   }
+  if (lane == 0) { s_inl[wave] = n_inl; s_new[wave] = n_new; }
+  __threadfence_block();
+  __syncthreads();
+  if (t >= 64) return;                                     // wave 0 finishes the round
+  n_inl = s_inl[0] + s_inl[1] + s_inl[2] + s_inl[3];
+  n_new = s_new[0] + s_new[1] + s_new[2] + s_new[3];
   __threadfence_block();
   bool ok = n_inl > 0;
   for (int j = 0; j < k && ok; ++j) {

@@ -29,11 +29,17 @@
  * The graph-cut spatial-coherence labelling of GC-RANSAC and PEARL's joint
  * relabelling are NOT restated (their parameters are accepted and ignored).
  *
- * All sums over correspondences use one canonical order so that the wavefront-
- * parallel HIP kernel can reproduce them bit for bit: 64 strided partial sums
- * (partial l takes items l, l+64, ...) combined by a 6-level xor butterfly.
- * Only + - * / sqrt are used (correctly rounded on both sides); build with
- * -ffp-contract=off.
+ * All sums over correspondences use canonical orders so that the wavefront-
+ * parallel HIP kernels can reproduce them bit for bit:
+ *   - hypothesis scoring (one wavefront per hypothesis): 64 strided partial sums
+ *     (partial l takes items l, l+64, ...) combined by a 6-level xor butterfly;
+ *   - local optimisation (one 256-thread workgroup per object): 256 strided
+ *     partial sums (partial q takes items q, q+256, ...), a 6-level xor butterfly
+ *     inside each group of 64 and then (g0 + g1) + (g2 + g3).
+ * The projection uses ONE reciprocal per point (iz = 1/Z, then multiplications) and
+ * the MSAC term is 1 - e2 * (1/thr2): a division costs the GPU about ten fp64
+ * instructions. Only + - * / sqrt are used (correctly rounded on both sides);
+ * build with -ffp-contract=off.
  */
 #include <math.h>
 #include <stdint.h>
@@ -321,33 +327,53 @@ static int reproj(const double* pose, const double* K, const double* xy,
   Xc[1] = R[3] * xyz[0] + R[4] * xyz[1] + R[5] * xyz[2] + t[1];
   Xc[2] = R[6] * xyz[0] + R[7] * xyz[1] + R[8] * xyz[2] + t[2];
   if (!(Xc[2] > 0.0)) return 1;
-  const double px = (K[0] * Xc[0] + K[1] * Xc[1]) / Xc[2] + K[2];
-  const double py = (K[4] * Xc[1]) / Xc[2] + K[5];
+  const double iz = 1.0 / Xc[2];
+  const double px = (K[0] * Xc[0] + K[1] * Xc[1]) * iz + K[2];
+  const double py = (K[4] * Xc[1]) * iz + K[5];
   r[0] = px - xy[0];
   r[1] = py - xy[1];
   *e2 = r[0] * r[0] + r[1] * r[1];
   return 0;
 }
 
-/* MSAC score and inlier count of a pose over the index list idx[0..m) */
-static double score_pose(const double* pose, const double* K, const double* xy,
-                         const double* xyz, const int32_t* idx, int64_t m,
-                         double thr2, int32_t* count) {
-  double part[64];
+/* 256 partials: butterfly inside each group of 64, then (g0 + g1) + (g2 + g3) */
+static void tree256(double* part, int stride, int nvals) {
+  for (int g = 0; g < 4; ++g) tree64(part + (size_t)g * 64 * stride, stride, nvals);
+  for (int v = 0; v < nvals; ++v)
+    part[v] = (part[v] + part[64 * stride + v]) + (part[128 * stride + v] + part[192 * stride + v]);
+}
+
+/* MSAC score and inlier count of a pose over the index list idx[0..m);
+ * P = 64 (hypothesis scoring) or 256 (local optimisation) strided partials */
+static double score_pose_p(const double* pose, const double* K, const double* xy,
+                           const double* xyz, const int32_t* idx, int64_t m,
+                           double thr2, int32_t* count, int P) {
+  double part[256];
+  const double inv_thr2 = 1.0 / thr2;
   int32_t cnt = 0;
-  for (int l = 0; l < 64; ++l) {
+  for (int l = 0; l < P; ++l) {
     double acc = 0.0;
-    for (int64_t i = l; i < m; i += 64) {
+    for (int64_t i = l; i < m; i += P) {
       const int32_t p = idx[i];
       double e2, Xc[3], r[2];
       if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
-      if (e2 < thr2) { acc += 1.0 - e2 / thr2; ++cnt; }
+      if (e2 < thr2) { acc += 1.0 - e2 * inv_thr2; ++cnt; }
     }
     part[l] = acc;
   }
-  tree64(part, 1, 1);
+  if (P == 64) tree64(part, 1, 1); else tree256(part, 1, 1);
   *count = cnt;
   return part[0];
+}
+static double score_pose(const double* pose, const double* K, const double* xy,
+                         const double* xyz, const int32_t* idx, int64_t m,
+                         double thr2, int32_t* count) {
+  return score_pose_p(pose, K, xy, xyz, idx, m, thr2, count, 64);
+}
+static double score_pose256(const double* pose, const double* K, const double* xy,
+                            const double* xyz, const int32_t* idx, int64_t m,
+                            double thr2, int32_t* count) {
+  return score_pose_p(pose, K, xy, xyz, idx, m, thr2, count, 256);
 }
 
 /* ------------------------------------------------- local optimisation -- */
@@ -389,11 +415,11 @@ static int gn_step(const double* pose, const double* K, const double* xy,
                    const double* xyz, const int32_t* idx, int64_t m, double thr2,
                    double* next) {
   /* 27 accumulated quantities: 21 upper-triangular H entries + 6 of g */
-  static double part[64 * 27];
-  for (int l = 0; l < 64; ++l) {
+  static double part[256 * 27];
+  for (int l = 0; l < 256; ++l) {
     double acc[27];
     for (int v = 0; v < 27; ++v) acc[v] = 0.0;
-    for (int64_t i = l; i < m; i += 64) {
+    for (int64_t i = l; i < m; i += 256) {
       const int32_t p = idx[i];
       double e2, Xc[3], r[2];
       if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
@@ -420,7 +446,7 @@ static int gn_step(const double* pose, const double* K, const double* xy,
     }
     for (int v = 0; v < 27; ++v) part[l * 27 + v] = acc[v];
   }
-  tree64(part, 27, 27);
+  tree256(part, 27, 27);
   double H[6][6], g[6], x[6];
   int v = 0;
   for (int a = 0; a < 6; ++a)
@@ -512,14 +538,14 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
     orthonormalize(best_pose);
     {
       int32_t cnt;
-      best_score = score_pose(best_pose, K, xy, xyz, active, n_active, thr2, &cnt);
+      best_score = score_pose256(best_pose, K, xy, xyz, active, n_active, thr2, &cnt);
       best_count = cnt;
     }
     for (int li = 0; li < prm->lo_iters; ++li) {
       double cand[12];
       if (gn_step(best_pose, K, xy, xyz, active, n_active, thr2, cand)) break;
       int32_t cnt;
-      const double sc = score_pose(cand, K, xy, xyz, active, n_active, thr2, &cnt);
+      const double sc = score_pose256(cand, K, xy, xyz, active, n_active, thr2, &cnt);
       if (!(sc > best_score)) break;
       best_score = sc; best_count = cnt;
       memcpy(best_pose, cand, sizeof(cand));

@@ -90,3 +90,43 @@ def test_sparse_heads_equal_dense_on_target_objects():
       assert torch.equal(dl[im, :, obj - 1], sl[im, :, obj - 1])
   assert torch.equal(dense.net.logits['pred_obj_conf'],
                      sparse.net.logits['pred_obj_conf'])
+
+
+def test_concurrent_pipelines_are_deterministic():
+  """Four plans in flight on four HIP streams (what bench.py does): the LDS-DMA
+  rings, counted waits and grouped launches of one plan must not be disturbed by
+  the kernels of the others. Every plan processes the same frames in every round;
+  head tensors and poses have to repeat bit for bit, round after round, and agree
+  between the plans (same weights, same input)."""
+  from epos_amd import pipeline, weights
+  O, F, B, H, W_ = 4, 64, 1, 192, 256
+  ckpt = weights.random_init(num_objs=O, seed=9, randomize_bn=True, logits_std=0.6)
+  store = Store(O, F)
+  depth = 4
+  pipes = [pipeline.EposPipeline(ckpt, B, H, W_, O, F, store, capacity=1 << 19,
+                                 instance=j) for j in range(depth)]
+  rng = np.random.RandomState(3)
+  frames = [torch.from_numpy(rng.randint(0, 256, (B, H, W_, 3)).astype('f')).cuda()
+            for _ in range(3)]
+  Ks = np.tile(np.array([[400., 0, 128], [0, 400., 96], [0, 0, 1]]), (B, 1, 1))
+  targets = [{1: 1, 2: 1, 4: 1}]
+  ref = {}
+  for rnd in range(6):
+    for f, img in enumerate(frames):
+      for p in pipes:                          # all four in flight on the same frame
+        p.launch(img, Ks, targets, seed=11)
+      outs = []
+      for p in pipes:
+        poses, _ = p.collect()
+        logits = p.net.logits['pred_frag_loc'].clone()
+        outs.append((poses, logits))
+      for poses, logits in outs:
+        key = f
+        if key not in ref:
+          ref[key] = (poses, logits.cpu())
+        rp, rl = ref[key]
+        assert torch.equal(logits.cpu(), rl)
+        assert len(poses) == len(rp)
+        for a, b in zip(poses, rp):
+          assert a['obj_id'] == b['obj_id'] and a['score'] == b['score']
+          assert np.array_equal(a['R'], b['R']) and np.array_equal(a['t'], b['t'])

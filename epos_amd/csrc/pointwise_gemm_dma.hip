@@ -85,7 +85,7 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const float* sbase,
 // (y*stride + dy*rate, x*stride + dx*rate) -- the im2col matrix only ever exists as
 // LDS tiles. Taps outside the image come from a zero block (a per-lane source
 // select, as for the partial last K tile).
-template <bool HAS_RES, int LAYOUT, bool CONV>
+template <bool HAS_RES, int LAYOUT, bool CONV, bool SINGLE>
 __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga_) {
   constexpr int BM_ = LAYOUT == 0 ? 64 : 128;
   constexpr int BN_ = LAYOUT == 0 ? 128 : 64;
@@ -121,11 +121,16 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
     const int q = total >> 3, r = total & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   }
+  // SINGLE (one problem per launch, the common case): every argument is read from a
+  // fixed kernarg offset, i.e. all scalar loads go out together right at the start;
+  // the grouped form needs the tile_start search first (a second dependent round trip).
   int pi = 0;
+  if (!SINGLE) {
 #pragma unroll
-  for (int i = 1; i < MAX_GROUP; ++i)
-    if (i < gp->count && bid >= gp->tile_start[i]) pi = i;
-  bid -= gp->tile_start[pi];
+    for (int i = 1; i < MAX_GROUP; ++i)
+      if (i < gp->count && bid >= gp->tile_start[i]) pi = i;
+    bid -= gp->tile_start[pi];
+  }
   const EposPointwiseArgs p = gp->p[pi];
   const int tiles_n = gp->tiles_n[pi];
   const int npad = gp->npad[pi];
@@ -160,6 +165,9 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
       apx[i] = xo * p.sub;
       row = (static_cast<int64_t>(b) * p.Hi + apy[i]) * p.Wi + apx[i];
     } else if (p.sub > 1) {
+      // (rare: the stride-2 shortcut convs) keep this a real branch -- if-converted,
+      // its two integer divisions per piece sit on every launch's critical path
+      asm volatile("" ::: "memory");
       const int hw = p.Ho * p.Wo;
       const int b = m / hw, rem = m - b * hw;
       const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
@@ -238,12 +246,19 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   // ---- prologue: tiles 0 and 1 in flight, tile 0 landed + visible -----------
+#ifdef EPOS_GEMM_TRACE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // finer prologue split (first 512 WGs)
+  if (t == 0 && blockIdx.x < 512) g_trace_units[blockIdx.x * 32] = wall_clock64();
+#endif
   if (nk == 1) {
     issue(0, 0, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     issue(0, 0, std::false_type{});
     if (nk == 2) issue(1, 1, std::true_type{}); else issue(1, 1, std::false_type{});
+#ifdef EPOS_GEMM_TRACE
+    if (t == 0 && blockIdx.x < 512) g_trace_units[blockIdx.x * 32 + 1] = wall_clock64();
+#endif
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
@@ -876,19 +891,24 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_sk_f32(SkArgs a_) {
 #endif
 }
 
-template <bool HAS_RES, int LAYOUT, bool CONV>
-int launch_dma_t(const GroupedArgs& g, int total, hipStream_t s) {
+template <bool HAS_RES, int LAYOUT, bool CONV, bool SINGLE>
+int launch_dma_tt(const GroupedArgs& g, int total, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV>),
+        reinterpret_cast<const void*>(pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV, SINGLE>),
         hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES);
     attr_set = true;
   }
   // 72 KB per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL((pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV>), dim3(total),
+  hipLaunchKernelGGL((pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV, SINGLE>), dim3(total),
                      dim3(THREADS), DMA_LDS_BYTES, s, g);
   return launch_status("pointwise_gemm_dma_f32");
+}
+template <bool HAS_RES, int LAYOUT, bool CONV>
+int launch_dma_t(const GroupedArgs& g, int total, hipStream_t s) {
+  return g.count == 1 ? launch_dma_tt<HAS_RES, LAYOUT, CONV, true>(g, total, s)
+                      : launch_dma_tt<HAS_RES, LAYOUT, CONV, false>(g, total, s);
 }
 
 constexpr int SK_WORKERS = 512;             // two workgroups per CU on 256 CUs

@@ -20,6 +20,7 @@ for s in range(nstream_max):
                          relu=0, relu_in=0, sub=1)
   bufs.append((A, C, Wp, b, a))
 streams = [torch.cuda.Stream() for _ in range(nstream_max)]
+clk = torch.zeros((8, 2), dtype=torch.int64, device='cuda'); cs = torch.cuda.Stream()
 N = 600
 for ns in (1, 2, 3):
   for rep in range(2):
@@ -30,7 +31,10 @@ for ns in (1, 2, 3):
     for i in range(N):
       j = i % ns
       lib.epos_pointwise_conv_f32(ctypes.byref(bufs[j][4]), ctypes.c_void_p(streams[j].cuda_stream))
+      if rep == 1 and i in (N // 2, N // 2 + 100):      # sample the core clock mid-run
+        lib.epos_clock_probe(ctypes.c_void_p(clk[i // 100 % 8].data_ptr()), 300, ctypes.c_void_p(cs.cuda_stream))
     for s in streams[:ns]: torch.cuda.current_stream().wait_stream(s)
     e1.record(); torch.cuda.synchronize()
   us = e0.elapsed_time(e1) / N * 1e3
-  print('M=%d N=%d K=%d  %d stream(s): %.1f us per launch  %.1f TFLOP/s aggregate' % (m, n, k, ns, us, 2 * m * n * k / us / 1e6))
+  ch = clk.cpu().numpy(); ch = ch[ch[:, 1] > 0]; mhz = float((ch[:, 0] / ch[:, 1]).mean() * 100) if len(ch) else 0; clk.zero_()
+  print('M=%d N=%d K=%d  %d stream(s): %.1f us per launch  %.1f TFLOP/s aggregate  core clock %.0f MHz (roof at that clock %.1f)' % (m, n, k, ns, us, 2 * m * n * k / us / 1e6, mhz, 65.536 * mhz / 1e3))

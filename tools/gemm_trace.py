@@ -56,3 +56,13 @@ print('distinct CUs %d; workgroups per CU histogram %s' % (len(keys), dict(zip(*
 per = dict(zip(keys, counts)); co = np.array([per[x] for x in cu_key])
 for c in sorted(set(co)):
   print('  CUs with %d WG: k-loop mean %.2f us, end mean %.2f us' % (c, loop[co == c].mean(), end[co == c].mean()))
+
+try:
+  lib.epos_debug_read_trace_units
+  ub = np.zeros(512 * 32, np.uint64)
+  lib.epos_debug_read_trace_units(ub.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(ub.nbytes))
+  ub = ub.reshape(512, 32).astype(np.int64)[:min(nwg, 512)]
+  k0 = min(nwg, 512)
+  st('pro:args', us(ub[:, 0] - tr[:k0, 0])); st('pro:issue', us(ub[:, 1] - ub[:, 0])); st('pro:wait', us(tr[:k0, 1] - ub[:, 1]))
+except AttributeError:
+  pass

@@ -88,3 +88,45 @@ def test_c5_lmo_like_resnet_batch8():
                                 max_instances=1, model_options=mo)
   p1 = pipe1.net.forward(torch.from_numpy(imgs[3:4]).cuda())
   assert torch.equal(p1['pred_obj_conf'][0], pred['pred_obj_conf'][3])
+
+
+def test_c2_full_size_network_and_pipeline():
+  """BASELINE config C2 at its full size (640x480, 21 objects x 64 fragments, 5
+  target objects): every head tensor of the HIP network against the torch-CPU
+  oracle (fp32, rtol = atol = 3e-4: 65 layers of differently ordered fp32 sums), the
+  softmax property sum == 1, and the poses of the device pipeline against the
+  oracle chain (numpy correspondences + C RANSAC) run on the HIP heads."""
+  from epos_amd import model, pipeline, synthetic, weights
+  from oracle import net_ref
+  O, F, H, W_ = 21, 64, 480, 640
+  ckpt = weights.random_init(num_objs=O, seed=0, randomize_bn=True)
+  store = synthetic.ModelStore(O, F, seed=0)
+  img = synthetic.image(7, H, W_)[None]
+  net0 = model.get_net(ckpt, 1, H, W_, O, F)
+  net0.forward(torch.from_numpy(img).cuda())
+  torch.cuda.synchronize()
+  assert (net0.out_h, net0.out_w) == (120, 160)
+  synthetic.calibrate_logits(ckpt, net0.decoder_out[0].cpu().numpy())
+  model._NETS.clear()
+  pipe = pipeline.EposPipeline(ckpt, 1, H, W_, O, F, store, capacity=1 << 21,
+                               max_instances=1)
+  targets = [synthetic.targets(7, O, 5)]
+  Ks = synthetic.YCBV_K[None]
+  poses, _ = pipe.process_batch(torch.from_numpy(img).cuda(), Ks, targets, seed=3)
+  pred = {k: v.cpu().numpy() for k, v in pipe.net.forward().items()}
+  ref = net_ref.predict(img, ckpt, num_objs=O, num_frags=F)
+  for k in ['pred_obj_conf', 'pred_frag_conf', 'pred_frag_loc']:
+    assert pred[k].shape == ref[k].shape, k
+    np.testing.assert_allclose(pred[k], ref[k], rtol=3e-4, atol=3e-4, err_msg=k)
+  np.testing.assert_allclose(pred['pred_obj_conf'].sum(-1), 1.0, atol=1e-5)
+  np.testing.assert_allclose(pred['pred_frag_conf'].sum(-1), 1.0, atol=1e-5)
+  conf = np.sort(ref['pred_obj_conf'], axis=-1)
+  clear = (conf[..., -1] - conf[..., -2]) > 1e-3
+  assert np.array_equal(pred['pred_obj_label'][clear], ref['pred_obj_label'][clear])
+  slots, wants = pipe.make_slots(targets)
+  exp = _oracle_chain(pipe, store, pred, slots, wants, Ks, 3)
+  assert len(poses) == len(exp) and len(poses) >= 3
+  for p, (im, obj_id, rp, rs) in zip(poses, exp):
+    assert p['obj_id'] == obj_id
+    np.testing.assert_allclose(np.hstack([p['R'], p['t']]), rp, atol=1e-9)
+    np.testing.assert_allclose(p['score'], rs, rtol=1e-12)

@@ -186,8 +186,11 @@ def main():
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X (no CPU fallback); the CPU oracle '
                      'is only timed beside the GPU path.')
-  torch.cuda.set_device(local_rank)
-  dev = 'cuda:%d' % local_rank
+  # EPOS_FORCE_DEVICE=0 maps every rank onto one GPU (functional test of the
+  # multi-rank flow on a one-GPU box, together with EPOS_DIST_BACKEND=gloo)
+  dev_index = int(os.environ.get('EPOS_FORCE_DEVICE', local_rank))
+  torch.cuda.set_device(dev_index)
+  dev = 'cuda:%d' % dev_index
   B = args.batch_per_gpu
   # Random-init weights with the reference's initialisers; BatchNorm statistics
   # are randomised so that activations keep an O(0.1..1) scale through the 65

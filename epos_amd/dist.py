@@ -26,7 +26,10 @@ def init_from_env(backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
-      backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+      # EPOS_DIST_BACKEND=gloo: exercise the multi-rank flow where RCCL cannot run
+      # (e.g. two ranks sharing the single GPU of a test box)
+      backend = os.environ.get('EPOS_DIST_BACKEND') or (
+          'nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
       torch.cuda.set_device(local_rank)
       dist.init_process_group(backend, rank=rank, world_size=world,

@@ -130,3 +130,34 @@ def test_concurrent_pipelines_are_deterministic():
         for a, b in zip(poses, rp):
           assert a['obj_id'] == b['obj_id'] and a['score'] == b['score']
           assert np.array_equal(a['R'], b['R']) and np.array_equal(a['t'], b['t'])
+
+
+def test_bench_multi_rank_flow_on_one_gpu():
+  """bench.py under torchrun with two ranks mapped onto the one GPU of the test box
+  (EPOS_FORCE_DEVICE=0) and gloo for the pose-record all_gather / barriers
+  (EPOS_DIST_BACKEND=gloo: RCCL refuses two ranks on one device): the N > 1 code path
+  -- rank-local plans, per-step gather, max-over-ranks timing, rank-0 JSON line --
+  end to end on real kernels."""
+  import json
+  import os
+  import socket
+  import subprocess
+  import sys
+  with socket.socket() as sck:
+    sck.bind(('127.0.0.1', 0))
+    port = sck.getsockname()[1]
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, EPOS_DIST_BACKEND='gloo', EPOS_FORCE_DEVICE='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+         str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6',
+         '--warmup', '2', '--no-cpu-baseline', '--no-roofline']
+  out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True,
+                       timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+  assert len(lines) == 1                      # rank 0 only
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak'
+  assert d['config']['global_batch'] == 2 and d['value'] > 0
+  assert d['config']['poses_per_step'] > 0

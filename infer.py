@@ -148,6 +148,26 @@ def load_fragments(model_dir, num_frags):
   return store
 
 
+def fragment_from_bop_models(model_dir, args, dev):
+  """datagen.py:238-296: no fragments.pkl yet -> load the object models of the
+  dataset (<BOP_PATH>/<dataset>/models[_<type>]/obj_XXXXXX.ply; 'reconst' for T-LESS,
+  'dense' for ITODD, 'eval' for TUD-L, the original ones otherwise), fragment them by
+  furthest-point sampling on the GPU, save fragments.pkl next to params.yml."""
+  from epos_amd import fragment, ply
+  dataset = args.dataset
+  bop = os.environ.get('BOP_PATH')
+  if not dataset or not bop or dataset not in ply.BOP_OBJ_IDS:
+    return None
+  mtype = {'tless': 'reconst', 'itodd': 'dense', 'tudl': 'eval'}.get(dataset)
+  if not os.path.exists(ply.model_path(bop, dataset, ply.BOP_OBJ_IDS[dataset][0], mtype)):
+    return None
+  models = ply.load_models(bop, dataset, mtype)
+  centers, sizes = fragment.fragment_models(
+      {o: m['pts'] for o, m in models.items()}, args.num_frags, device=dev)
+  fragment.save_fragments(os.path.join(model_dir, 'fragments.pkl'), centers, sizes)
+  return load_fragments(model_dir, args.num_frags)
+
+
 def find_checkpoint(checkpoint_dir, name):
   if name is not None:
     path = os.path.join(checkpoint_dir, name)
@@ -340,9 +360,12 @@ def main(argv=None):
   else:
     raise ValueError('No checkpoint (.npz) found in {}'.format(checkpoint_dir))
   store = load_fragments(model_dir, args.num_frags)
+  if store is None and not args.synthetic:
+    store = fragment_from_bop_models(model_dir, args, dev)
   if store is None:
     if not args.synthetic:
-      raise ValueError('fragments.pkl / fragments.npz not found in ' + model_dir)
+      raise ValueError('fragments.pkl / fragments.npz not found in ' + model_dir +
+                       ' and no BOP models under $BOP_PATH/<dataset>/models*')
     store = synthetic.ModelStore(num_objs, args.num_frags, seed=0)
 
   frames, h, w = load_frames(args, num_objs, rank, world,

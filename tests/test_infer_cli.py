@@ -139,3 +139,42 @@ def test_infer_restores_tf_checkpoint(tmp_path):
        '--synthetic', '1'], env=env, capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stdout + out.stderr
   assert (models / 'toy' / 'infer' / 'estimated-poses.csv').exists()
+
+
+@pytest.mark.gpu
+def test_fragments_from_bop_ply_models(tmp_path, monkeypatch):
+  """No fragments.pkl: infer.py loads <BOP_PATH>/<dataset>/models*/obj_XXXXXX.ply
+  (epos_amd/ply.py), fragments the vertices on the GPU and caches fragments.pkl
+  (datagen.py:238-296). Centres / sizes must equal the numpy oracle's FPS + size rule
+  on the same vertices, and the model-type rule ('eval' models for TUD-L) is honoured."""
+  import argparse
+  import infer
+  from epos_amd import ply
+  from oracle import fragment_ref
+  bop = tmp_path / 'bop'
+  rng = np.random.RandomState(4)
+  pts = {}
+  for o in ply.BOP_OBJ_IDS['tudl']:
+    os.makedirs(os.path.dirname(ply.model_path(str(bop), 'tudl', o, 'eval')),
+                exist_ok=True)
+    v = rng.uniform(-60, 60, (500 + 37 * o, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True) / (30.0 + 10 * o)
+    pts[o] = v.astype(np.float64)
+    ply.save_ply(ply.model_path(str(bop), 'tudl', o, 'eval'), v,
+                 faces=rng.randint(0, len(v), (50, 3)))
+  monkeypatch.setenv('BOP_PATH', str(bop))
+  model_dir = tmp_path / 'm'
+  model_dir.mkdir()
+  args = argparse.Namespace(dataset='tudl', num_frags=64)
+  store = infer.fragment_from_bop_models(str(model_dir), args, 'cuda:0')
+  assert (model_dir / 'fragments.pkl').exists()
+  assert store.dp_model['obj_ids'] == [1, 2, 3]
+  for o in store.dp_model['obj_ids']:
+    centers, ids = fragment_ref.fragmentation_fps(pts[o], 64)
+    np.testing.assert_array_equal(store.frag_centers[o], centers)
+    sizes = [max((pts[o][ids == f].max(0) - pts[o][ids == f].min(0)).max(), 5.0)
+             for f in range(64)]
+    np.testing.assert_array_equal(store.frag_sizes[o], sizes)
+  # a dataset without model files falls through (the caller then raises)
+  args.dataset = 'ycbv'
+  assert infer.fragment_from_bop_models(str(model_dir), args, 'cuda:0') is None

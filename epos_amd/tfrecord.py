@@ -13,10 +13,11 @@ writer only (tests/test_tfrecord.py). The formats are the public ones:
     Feature{1: BytesList, 2: FloatList, 3: Int64List}, each ``repeated value = 1``
     (float / int64 lists packed or unpacked).
 
-Image decoding uses PIL (JPEG / PNG). Resizing of frames taller than
-``infer_max_height_before_crop`` (misc.py:79-93: area / bilinear with
-align_corners) is NOT reproduced -- YCB-V, LM-O and the T-LESS crops used by EPOS
-need none; such records raise.
+Image decoding uses PIL (JPEG / PNG). Frames taller than
+``infer_max_height_before_crop`` are shrunk as misc.py:79-93 does, with a numpy
+restatement of ``tf.image.resize_area(align_corners=True)`` (box filter over
+[y*s, (y+1)*s), s = (in-1)/(out-1), source indices clamped to the image) -- also
+unpinned; YCB-V, LM-O and the T-LESS crops used by EPOS need no resize.
 """
 import io
 import struct
@@ -201,6 +202,47 @@ def encode_example(features):
   return _enc_ld(1, entries)
 
 
+# ------------------------------------------------------------- resizing -----
+def _area_weights(n_in, n_out):
+  """[n_out, n_in] float32 weights of TensorFlow's ResizeArea kernel with
+  align_corners=True: output i averages the input interval [i*s, (i+1)*s),
+  s = (n_in - 1) / (n_out - 1), partial cells weighted by their overlap, source
+  indices beyond the image clamped to the last pixel."""
+  scale = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+  w = np.zeros((n_out, n_in), np.float32)
+  inv = np.float32(1.0) / scale if scale > 0 else np.float32(1.0)
+  for i in range(n_out):
+    lo, hi = np.float32(i) * scale, np.float32(i + 1) * scale
+    if scale == 0:
+      w[i, 0] = 1.0
+      continue
+    j = int(np.floor(lo))
+    while j < int(np.ceil(hi)):
+      if j < lo:
+        part = np.float32(j + 1) - lo
+      elif j + 1 > hi:
+        part = hi - np.float32(j)
+      else:
+        part = np.float32(1.0)
+      w[i, min(max(j, 0), n_in - 1)] += part * inv
+      j += 1
+  return w
+
+
+def resize_area(im, out_h, out_w):
+  """misc.resize_image_tf's shrinking branch (misc.py:86-89) on an [H,W,C] float
+  image."""
+  im = np.asarray(im, np.float32)
+  if im.shape[0] == out_h and im.shape[1] == out_w:
+    return im
+  wy = _area_weights(im.shape[0], out_h)
+  wx = _area_weights(im.shape[1], out_w)
+  h, w, c = im.shape
+  rows = (wy @ im.reshape(h, w * c)).reshape(out_h, w, c)          # rows first
+  return np.ascontiguousarray(
+      np.tensordot(rows, wx, axes=([1], [1])).transpose(0, 2, 1), np.float32)
+
+
 # ------------------------------------------------------- sample decoding ----
 def _scalar(feats, key, default):
   v = feats.get(key)
@@ -222,10 +264,8 @@ def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
   h_new = min(max_height_before_crop, h_orig)
   scale = np.float32(h_new) / np.float32(h_orig)
   w_new = int(np.float32(w_orig) * scale)
-  if h_new != h_orig:
-    raise NotImplementedError(
-        'frame height %d > infer_max_height_before_crop %d: the area / bilinear '
-        'resize of misc.py:79-93 is not reproduced' % (h_orig, max_height_before_crop))
+  if h_new != h_orig:                      # misc.py:79-93 (shrinking: area filter)
+    im = resize_area(im, h_new, w_new)
   crop_w, crop_h = crop_size
   if crop_h > h_new or crop_w > w_new:
     raise ValueError('crop %dx%d larger than the frame %dx%d' % (

@@ -81,11 +81,50 @@ def test_tfrecord_file_roundtrip_and_corruption(tmp_path):
     list(tfrecord.read_records(path, verify_crc=True))
 
 
-def test_oversized_frame_raises(tmp_path):
-  img = np.zeros((540, 720, 3), np.uint8)
+def test_oversized_frame_is_resized_before_the_crop(tmp_path):
+  img = np.full((540, 720, 3), 77, np.uint8)
   feats = tfrecord.parse_example(tfrecord.encode_example(
       _example(1, 1, img, [1], [1.0])))
-  with pytest.raises(NotImplementedError):
-    tfrecord.decode_sample(feats, (640, 480), 480)
+  s = tfrecord.decode_sample(feats, (640, 480), 480)        # 540 -> 480 rows, 720 -> 640
+  assert s['image'].shape == (480, 640, 3)
+  np.testing.assert_allclose(s['image'], 77.0, rtol=1e-6)
   s = tfrecord.decode_sample(feats, (720, 540), 540)
   assert s['image'].shape == (540, 720, 3)
+
+
+def test_resize_area_align_corners():
+  """Shrinking branch of misc.resize_image_tf (tf.image.resize_area, align_corners):
+  hand-computed box-filter values, constants preserved, identity at equal size."""
+  from epos_amd import tfrecord
+  im = np.arange(5 * 5, dtype=np.float32).reshape(5, 5, 1)
+  out = tfrecord.resize_area(im, 3, 3)             # s = 4 / 2 = 2
+  # output row r averages input rows {2r, 2r+1}; the last one reaches past the
+  # image and repeats row 4 (clamped): same for columns
+  rows = [(im[0] + im[1]) / 2, (im[2] + im[3]) / 2, im[4]]
+  exp = np.stack([np.stack([(r[0] + r[1]) / 2, (r[2] + r[3]) / 2, r[4]]) for r in rows])
+  np.testing.assert_allclose(out, exp, rtol=1e-6)
+  const = np.full((7, 9, 3), 3.25, np.float32)
+  np.testing.assert_allclose(tfrecord.resize_area(const, 4, 5), 3.25, rtol=1e-6)
+  assert tfrecord.resize_area(im, 5, 5) is not None
+  np.testing.assert_array_equal(tfrecord.resize_area(im, 5, 5), im)
+  w = tfrecord._area_weights(11, 4)                # fractional scale 10/3
+  np.testing.assert_allclose(w.sum(1), 1.0, rtol=1e-6)
+
+
+def test_oversized_frame_is_shrunk_and_K_scaled(tmp_path):
+  from PIL import Image
+  import io
+  from epos_amd import tfrecord
+  rgb = np.random.RandomState(0).randint(0, 256, (96, 128, 3)).astype(np.uint8)
+  buf = io.BytesIO(); Image.fromarray(rgb).save(buf, format='PNG')
+  feats = {'image/encoded': [buf.getvalue()], 'image/height': [96], 'image/width': [128],
+           'image/camera/fx': [200.0], 'image/camera/fy': [210.0],
+           'image/camera/cx': [64.0], 'image/camera/cy': [48.0],
+           'image/scene_id': [1], 'image/im_id': [2], 'image/path': [b'x.png']}
+  path = str(tmp_path / 't.tfrecord')
+  tfrecord.write_records(path, [tfrecord.encode_example(feats)])
+  s = next(tfrecord.load_samples(path, (64, 48), max_height_before_crop=48))
+  assert s['image'].shape == (48, 64, 3)
+  np.testing.assert_allclose(s['K'][0, 0], 100.0)   # fx * 48/96
+  np.testing.assert_allclose(s['K'][1, 2], 24.0)
+  np.testing.assert_allclose(s['image'], tfrecord.resize_area(rgb.astype(np.float32), 48, 64))

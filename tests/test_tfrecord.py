@@ -87,7 +87,7 @@ def test_oversized_frame_is_resized_before_the_crop(tmp_path):
       _example(1, 1, img, [1], [1.0])))
   s = tfrecord.decode_sample(feats, (640, 480), 480)        # 540 -> 480 rows, 720 -> 640
   assert s['image'].shape == (480, 640, 3)
-  np.testing.assert_allclose(s['image'], 77.0, rtol=1e-6)
+  np.testing.assert_allclose(s["image"], 77.0, rtol=2e-4)   # float32 cell bounds, as TF
   s = tfrecord.decode_sample(feats, (720, 540), 540)
   assert s['image'].shape == (540, 720, 3)
 

@@ -147,6 +147,10 @@ SYMBOLS = {
         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, vp, vp,
         vp, ctypes.c_int64, ctypes.POINTER(CorrOut), vp, vp]),
     'epos_corr_slot_bases': (ctypes.c_int, [vp, ctypes.c_int, vp, vp]),
+    'epos_project_to_mesh_f64': (ctypes.c_int, [
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p]),
     'epos_fragmentation_fps': (ctypes.c_int, [
         vp, ctypes.c_int64, ctypes.c_int, vp, vp, vp, vp, vp]),
     'epos_fit_params_default': (None, [ctypes.POINTER(FitParams)]),

@@ -128,10 +128,10 @@ def establish_many_to_many(
   obj_confs [h,w,O+1], frag_confs [h,w,O,F], frag_coords [h,w,O,F,3]: numpy
   arrays (copied to HBM) or torch tensors already on the device.
   """
-  if project_to_surface:
-    raise NotImplementedError(
-        'project_to_surface (datagen.py:128-154, libigl AABB) is out of scope; '
-        'the reference default is False (infer.py:59-61).')
+  if project_to_surface and not getattr(model_store, 'models', None):
+    raise ValueError(
+        'project_to_surface needs model_store.models = {obj_id: {"pts", "faces"}} '
+        '(datagen.py:68-84; epos_amd.ply.load_models)')
   dev = torch.device(device)
 
   def to_dev(a):
@@ -166,4 +166,27 @@ def establish_many_to_many(
       continue                                     # no masked pixel: key absent (:49)
     lo, hi = int(base[s]), int(base[s + 1])
     corresp[obj_id] = {k: v[lo:hi].copy() for k, v in host.items()}
+    if project_to_surface:                         # corresp.py:87-88
+      m = model_store.models[obj_id]
+      corresp[obj_id]['coord_3d'] = project_pts_to_model(
+          ex.coord_3d[lo:hi], m['pts'], m['faces'], device=device)
   return corresp
+
+
+def project_pts_to_model(pts, verts, faces, device='cuda:0', return_faces=False):
+  """ObjectModelStore.project_pts_to_model (datagen.py:128-154): closest point of the
+  triangle mesh (verts [V,3], faces [F,3]) for every row of pts [N,3]. pts may be a
+  device tensor (f64) or a host array; returns a host float64 array."""
+  lib = _lib.load()
+  dev = torch.device(device)
+  P = torch.as_tensor(pts).to(device=dev, dtype=torch.float64).contiguous()
+  V = torch.as_tensor(np.ascontiguousarray(verts, np.float64)).to(dev)
+  Fc = torch.as_tensor(np.ascontiguousarray(faces, np.int32)).to(dev)
+  out = torch.empty_like(P)
+  fidx = torch.empty(P.shape[0], dtype=torch.int32, device=dev)
+  _lib.check(lib.epos_project_to_mesh_f64(
+      _ptr(P), P.shape[0], _ptr(V), V.shape[0], _ptr(Fc), Fc.shape[0], _ptr(out),
+      _ptr(fidx), _stream(dev)), 'epos_project_to_mesh_f64')
+  if return_faces:
+    return out.cpu().numpy(), fidx.cpu().numpy()
+  return out.cpu().numpy()

@@ -159,10 +159,112 @@ __global__ __launch_bounds__(256) void corr_fill_kernel(
   }
 }
 
+// --------------------------------------------------------------------------
+// project_to_surface (corresp.py:87-88 -> datagen.py:128-154): closest point of the
+// object's triangle mesh for every predicted 3D point. The reference asks libigl's AABB
+// tree; here one wavefront per query point sweeps ALL faces (lane = face modulo 64:
+// exact, no tree to build; ~80 fp64 operations per point-face pair) and reduces
+// (squared distance, face index) lexicographically, so ties go to the lowest face index.
+// Closest point on a triangle by the Voronoi-region tests of Ericson, "Real-Time
+// Collision Detection" 5.1.5; fp64, only + - * /, same operation order as
+// the numpy restatement the tests check it against (bit-exact).
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double dot3d(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+__device__ __forceinline__ void closest_on_triangle(const double* p, const double* a,
+                                                    const double* b, const double* c,
+                                                    double* q) {
+  double ab[3], ac[3], ap[3];
+  for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+  const double d1 = dot3d(ab, ap), d2 = dot3d(ac, ap);
+  if (d1 <= 0.0 && d2 <= 0.0) { q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; return; }
+  double bp[3];
+  for (int i = 0; i < 3; ++i) bp[i] = p[i] - b[i];
+  const double d3 = dot3d(ab, bp), d4 = dot3d(ac, bp);
+  if (d3 >= 0.0 && d4 <= d3) { q[0] = b[0]; q[1] = b[1]; q[2] = b[2]; return; }
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+    const double v = d1 / (d1 - d3);
+    for (int i = 0; i < 3; ++i) q[i] = a[i] + v * ab[i];
+    return;
+  }
+  double cp[3];
+  for (int i = 0; i < 3; ++i) cp[i] = p[i] - c[i];
+  const double d5 = dot3d(ab, cp), d6 = dot3d(ac, cp);
+  if (d6 >= 0.0 && d5 <= d6) { q[0] = c[0]; q[1] = c[1]; q[2] = c[2]; return; }
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+    const double w = d2 / (d2 - d6);
+    for (int i = 0; i < 3; ++i) q[i] = a[i] + w * ac[i];
+    return;
+  }
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+    const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for (int i = 0; i < 3; ++i) q[i] = b[i] + w * (c[i] - b[i]);
+    return;
+  }
+  const double denom = 1.0 / (va + vb + vc);
+  const double v = vb * denom, w = vc * denom;
+  for (int i = 0; i < 3; ++i) q[i] = a[i] + ab[i] * v + ac[i] * w;
+}
+
+__global__ __launch_bounds__(256) void project_to_mesh_kernel(
+    const double* __restrict__ pts, int64_t n, const double* __restrict__ verts,
+    const int32_t* __restrict__ faces, int64_t nf, double* out, int32_t* face_idx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;                               // wave-uniform
+  const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  double best = INFINITY, bq[3] = {0.0, 0.0, 0.0};
+  int64_t bf = nf;
+  for (int64_t f = lane; f < nf; f += 64) {
+    const int32_t ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+    const double a[3] = {verts[3 * ia], verts[3 * ia + 1], verts[3 * ia + 2]};
+    const double b[3] = {verts[3 * ib], verts[3 * ib + 1], verts[3 * ib + 2]};
+    const double c[3] = {verts[3 * ic], verts[3 * ic + 1], verts[3 * ic + 2]};
+    double q[3];
+    closest_on_triangle(p, a, b, c, q);
+    const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 < best) { best = d2; bf = f; bq[0] = q[0]; bq[1] = q[1]; bq[2] = q[2]; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ob = __shfl_xor(best, off, 64);
+    const int64_t of = __shfl_xor(bf, off, 64);
+    const double o0 = __shfl_xor(bq[0], off, 64), o1 = __shfl_xor(bq[1], off, 64),
+                 o2 = __shfl_xor(bq[2], off, 64);
+    if (ob < best || (ob == best && of < bf)) {
+      best = ob; bf = of; bq[0] = o0; bq[1] = o1; bq[2] = o2;
+    }
+  }
+  if (lane == 0) {
+    out[3 * i] = bq[0]; out[3 * i + 1] = bq[1]; out[3 * i + 2] = bq[2];
+    if (face_idx) face_idx[i] = static_cast<int32_t>(bf);
+  }
+}
+
 }  // namespace
 }  // namespace epos
 
 using namespace epos;
+
+extern "C" int epos_project_to_mesh_f64(const double* pts, int64_t n,
+                                        const double* verts, int64_t nv,
+                                        const int32_t* faces, int64_t nf, double* out,
+                                        int32_t* face_idx, void* stream) {
+  EPOS_REQUIRE(pts && verts && faces && out, "null pointer");
+  EPOS_REQUIRE(nv > 0 && nf > 0 && nf < (1LL << 31), "empty mesh");
+  if (n == 0) return EPOS_OK;
+  hipLaunchKernelGGL(project_to_mesh_kernel,
+                     dim3(static_cast<unsigned>(ceil_div(n, 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pts, n, verts, faces, nf, out,
+                     face_idx);
+  return launch_status("project_to_mesh_kernel");
+}
 
 extern "C" int epos_corr_count(const float* obj_confs, const float* frag_confs,
                                const EposCorrSlot* slots, int S, int B, int P,

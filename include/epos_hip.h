@@ -245,6 +245,14 @@ int epos_corr_fill(const float* obj_confs, const float* frag_confs,
 int epos_corr_slot_bases(const int32_t* totals, int S, int64_t* slot_base,
                          void* stream);
 
+/* project_to_surface (corresp.py:87-88, datagen.py:128-154: igl::AABB::squared_distance):
+ * out[i] = the point of the triangle mesh (verts [nv,3] f64, faces [nf,3] int32, all
+ * device) closest to pts[i] ([n,3] f64); face_idx [n] int32 or NULL receives the face.
+ * Exact sweep over all faces, ties -> lowest face index. */
+int epos_project_to_mesh_f64(const double* pts, int64_t n, const double* verts,
+                             int64_t nv, const int32_t* faces, int64_t nf, double* out,
+                             int32_t* face_idx, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Model preprocessing (replaces epos_lib/fragment.py:8-54, fragmentation_fps,
  * called once per object by ObjectModelStore.fragment_models, datagen.py:86-126).

@@ -277,7 +277,8 @@ def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
     corr = ecorresp.establish_many_to_many(
         pred['pred_obj_conf'][b], pred['pred_frag_conf'][b],
         pred['pred_frag_loc'][b], list(targets[b]), store, pipe.output_scale,
-        args.corr_min_obj_conf, args.corr_min_frag_rel_conf, False,
+        args.corr_min_obj_conf, args.corr_min_frag_rel_conf,
+        bool(args.project_to_surface),
         args.task_type == pipeline.LOCALIZATION, device=str(pipe.dev))
     t_corr += time.time() - tc
     tf_ = time.time()
@@ -392,10 +393,21 @@ def main(argv=None):
       max_model_number_for_optimization=args.max_model_number_for_pearl,
       use_prosac=args.use_prosac)
   # max_correspondences / use_prosac (both off by default, infer.py:95-97,115-117)
-  # re-order the correspondences by confidence on the host (infer.py:425-440), so
+  # re-order the correspondences by confidence on the host (infer.py:425-440), and
+  # project_to_surface (off by default) needs the object meshes, so
   # those runs go operator by operator (HIP network -> HIP correspondences -> host
   # sort -> HIP fitting per object) instead of through the fused device pipeline.
-  operator_path = args.max_correspondences is not None or args.use_prosac
+  operator_path = (args.max_correspondences is not None or args.use_prosac or
+                   args.project_to_surface)
+  if args.project_to_surface:
+    # infer.py:622 prepare_for_projection: the 'eval' models of the dataset
+    # (datagen.py:250-252,299-306), closest-point queries on the GPU
+    from epos_amd import ply
+    bop = os.environ.get('BOP_PATH')
+    if not (args.dataset and bop):
+      raise ValueError('--project_to_surface needs --dataset and $BOP_PATH (object models)')
+    store.models = ply.load_models(bop, args.dataset, 'eval',
+                                   obj_ids=store.dp_model['obj_ids'])
   B = args.batch
   max_inst = args.max_instances_to_fit or 4
   pipe = pipeline.EposPipeline(

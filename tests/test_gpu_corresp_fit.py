@@ -200,3 +200,69 @@ def test_fragmentation_fps_large_cloud_matches_oracle():
   seed = np.vstack([np.zeros((1, 3)), c])
   d = [np.min(np.linalg.norm(seed[:k] - seed[k], axis=1)) for k in range(1, 65)]
   assert all(d[i] >= d[i + 1] - 1e-9 for i in range(len(d) - 1))
+
+
+def _toy_mesh(rng, nv=60, nf=90):
+  verts = rng.uniform(-50, 50, (nv, 3))
+  faces = np.stack([rng.choice(nv, 3, replace=False) for _ in range(nf)]).astype(np.int32)
+  return verts, faces
+
+
+def test_project_to_surface_matches_oracle_bit_for_bit():
+  """project_to_surface (corresp.py:87-88): the HIP closest-point sweep against the
+  numpy restatement on random meshes and query points that hit every Voronoi region
+  (vertices, edges, face interiors, points on the surface, a duplicated face for the
+  tie rule)."""
+  from epos_amd import corresp as ecorresp
+  from oracle import project_ref
+  rng = np.random.RandomState(12)
+  verts, faces = _toy_mesh(rng)
+  faces = np.concatenate([faces, faces[:1]])          # duplicate: tie -> lowest index
+  pts = np.concatenate([
+      rng.uniform(-80, 80, (150, 3)),
+      verts[:10],                                          # exactly on vertices
+      (verts[faces[:10, 0]] + verts[faces[:10, 1]]) / 2,   # on edges
+      verts[faces[:10]].mean(1),                           # inside faces
+  ])
+  out, fidx = ecorresp.project_pts_to_model(pts, verts, faces, return_faces=True)
+  ref, ridx = project_ref.project_pts_to_model(pts, verts, faces)
+  assert np.array_equal(out, ref) and np.array_equal(fidx, ridx)
+  assert fidx.max() < len(faces) - 1                       # the duplicate never wins
+  # projecting a projected point is a fixed point (it lies on the mesh)
+  again = ecorresp.project_pts_to_model(out, verts, faces)
+  np.testing.assert_allclose(again, out, atol=1e-9)
+
+
+def test_establish_many_to_many_with_projection():
+  """Operator API with project_to_surface=True: coord_3d = closest mesh points of the
+  un-projected coord_3d; every other array unchanged."""
+  from epos_amd import corresp as ecorresp
+  from oracle import project_ref
+  rng = np.random.RandomState(5)
+  h, w, O, F = 12, 16, 2, 64
+  obj = rng.dirichlet(np.ones(O + 1), (h, w)).astype(np.float32)
+  frag = rng.dirichlet(np.ones(F), (h, w, O)).astype(np.float32)
+  loc = rng.standard_normal((h, w, O, F, 3)).astype(np.float32)
+
+  class Store(object):
+    pass
+  st = Store()
+  st.dp_model = {'obj_ids': [1, 2]}
+  st.frag_centers = {o: rng.uniform(-40, 40, (F, 3)) for o in (1, 2)}
+  st.frag_sizes = {o: rng.uniform(5, 20, F) for o in (1, 2)}
+  st.models = {}
+  for o in (1, 2):
+    v, f = _toy_mesh(rng, 40, 60)
+    st.models[o] = {'pts': v, 'faces': f}
+  plain = ecorresp.establish_many_to_many(obj, frag, loc, [1, 2], st, 0.25, 0.2, 0.5,
+                                          False, True)
+  proj = ecorresp.establish_many_to_many(obj, frag, loc, [1, 2], st, 0.25, 0.2, 0.5,
+                                         True, True)
+  assert set(plain) == set(proj) and len(plain) >= 1
+  for o in plain:
+    for k in plain[o]:
+      if k != 'coord_3d':
+        assert np.array_equal(plain[o][k], proj[o][k])
+    ref, _ = project_ref.project_pts_to_model(plain[o]['coord_3d'][:200],
+                                              st.models[o]['pts'], st.models[o]['faces'])
+    assert np.array_equal(proj[o]['coord_3d'][:200], ref)

@@ -68,3 +68,22 @@ def test_fragment_oracle_matches_reference_golden(name):
   assert np.array_equal(ids, z['vertex_frag_ids'])
   sizes = fragment_ref.fragment_sizes(z['vertices'], ids, int(z['num_frags']))
   assert sizes.shape == (int(z['num_frags']),) and (sizes >= 5.0).all()
+
+
+def test_project_ref_known_answers():
+  """oracle/project_ref.py (closest point on a triangle mesh) on a unit square made of
+  two triangles: interior, edge, vertex regions and the tie rule."""
+  from oracle import project_ref
+  verts = np.array([[0., 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])
+  faces = np.array([[0, 1, 2], [0, 2, 3]])
+  pts = np.array([[0.7, 0.2, 3.0],      # above the first triangle
+                  [0.2, 0.7, -2.0],     # below the second
+                  [0.5, 0.5, 1.0],      # above the shared diagonal: tie -> face 0
+                  [2.0, 0.5, 0.0],      # beyond the edge x = 1
+                  [-1.0, -1.0, 0.5],    # beyond the corner (0, 0)
+                  [0.5, 2.0, 0.0]])     # beyond the edge y = 1
+  out, idx = project_ref.project_pts_to_model(pts, verts, faces)
+  exp = np.array([[0.7, 0.2, 0], [0.2, 0.7, 0], [0.5, 0.5, 0], [1.0, 0.5, 0],
+                  [0, 0, 0], [0.5, 1.0, 0]])
+  np.testing.assert_allclose(out, exp, atol=1e-15)
+  assert list(idx) == [0, 1, 0, 0, 0, 1]

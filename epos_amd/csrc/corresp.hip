@@ -58,33 +58,45 @@ __global__ __launch_bounds__(256) void corr_mask_kernel(
   }
 }
 
-// In-place exclusive scan of two int arrays of length P per slot.
+// In-place exclusive scan of two int arrays of length P per slot: one 1024-thread
+// workgroup per slot walks the arrays in coalesced 1024-element chunks; inside a chunk
+// a wave-level inclusive scan (shuffle up) + the 16 wave totals through LDS; the running
+// carry is a register. (The first version gave every thread a private strided
+// sub-range and scanned the 1024 partial sums with 20 barriers: 41 us.)
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(v, o, 64);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(1024) void corr_scan_kernel(int32_t* px, int32_t* cnt,
                                                          int P, int32_t* totals) {
-  __shared__ int32_t sa[1024], sb[1024];
-  const int s = blockIdx.x, t = threadIdx.x;
+  __shared__ int32_t wa[16], wb[16];
+  const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int32_t* a = px + static_cast<int64_t>(s) * P;
   int32_t* b = cnt + static_cast<int64_t>(s) * P;
-  const int chunk = (P + 1023) / 1024;
-  const int lo = min(t * chunk, P), hi = min(lo + chunk, P);
-  int32_t suma = 0, sumb = 0;
-  for (int i = lo; i < hi; ++i) { suma += a[i]; sumb += b[i]; }
-  sa[t] = suma; sb[t] = sumb;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
-    int32_t va = 0, vb = 0;
-    if (t >= off) { va = sa[t - off]; vb = sb[t - off]; }
+  int32_t carry_a = 0, carry_b = 0;
+  for (int base = 0; base < P; base += 1024) {
+    const int i = base + t;
+    const int32_t va = i < P ? a[i] : 0, vb = i < P ? b[i] : 0;
+    const int32_t ia = wave_incl_scan(va, lane), ib = wave_incl_scan(vb, lane);
+    if (lane == 63) { wa[wave] = ia; wb[wave] = ib; }
     __syncthreads();
-    sa[t] += va; sb[t] += vb;
+    int32_t off_a = carry_a, off_b = carry_b, tot_a = 0, tot_b = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int32_t xa = wa[w], xb = wb[w];
+      if (w < wave) { off_a += xa; off_b += xb; }
+      tot_a += xa; tot_b += xb;
+    }
+    if (i < P) { a[i] = off_a + ia - va; b[i] = off_b + ib - vb; }   // exclusive
+    carry_a += tot_a; carry_b += tot_b;
     __syncthreads();
   }
-  int32_t ra = sa[t] - suma, rb = sb[t] - sumb;   // exclusive prefix of the chunk
-  for (int i = lo; i < hi; ++i) {
-    const int32_t va = a[i], vb = b[i];
-    a[i] = ra; b[i] = rb;
-    ra += va; rb += vb;
-  }
-  if (t == 1023) { totals[2 * s] = sa[t]; totals[2 * s + 1] = sb[t]; }
+  if (t == 0) { totals[2 * s] = carry_a; totals[2 * s + 1] = carry_b; }
 }
 
 __global__ void corr_slot_bases_kernel(const int32_t* totals, int S,

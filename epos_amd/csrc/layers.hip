@@ -377,6 +377,43 @@ __global__ __launch_bounds__(256) void softmax_groups_kernel(float* X,
   if (on) x[lane] = e / s;
 }
 
+// G == 64 (the fragment axis): a wave handles FOUR groups, 16 lanes x float4 each --
+// a quarter of the waves and fewer shuffle levels than the one-float-per-lane form. The same arithmetic (max / sum: in-lane pairs first, then the 8-4-2-1 xor
+// butterfly over the 16 lanes) is used by softmax_slots64_kernel, so dense and
+// sparse-head runs stay bit-identical.
+__device__ __forceinline__ float4 softmax64_lane16(float4 v) {
+  float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+  v.x = expf(v.x - m); v.y = expf(v.y - m); v.z = expf(v.z - m); v.w = expf(v.w - m);
+  float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+  return make_float4(v.x / s, v.y / s, v.z / s, v.w / s);
+}
+
+__global__ __launch_bounds__(256) void softmax_groups64_kernel(float* X, int64_t n_groups) {
+  const int lane = threadIdx.x & 63;
+  const int64_t g = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool on = g < n_groups;
+  float* x = X + (on ? g : 0) * 64 + (lane & 15) * 4;
+  const float4 r = softmax64_lane16(ld4(x));             // shuffles: all lanes take part
+  if (on) st4(x, r);
+}
+
+__global__ __launch_bounds__(256) void softmax_slots64_kernel(
+    float* X, const EposCorrSlot* __restrict__ slots, int P, int O) {
+  const int lane = threadIdx.x & 63;
+  const int p = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const int s = blockIdx.y;
+  const int img = slots[s].image, obj = slots[s].obj_id;
+  const bool on = p < P;
+  float* x = X + ((static_cast<int64_t>(img) * P + (on ? p : 0)) * O + (obj - 1)) * 64 +
+             (lane & 15) * 4;
+  const float4 r = softmax64_lane16(ld4(x));
+  if (on) st4(x, r);
+}
+
 // Softmax over the F fragment confidences of the given (image, object) slots only
 // (sparse-head mode): group of slot s, pixel p at X + ((img*P + p)*O + obj-1)*F.
 __global__ __launch_bounds__(256) void softmax_slots_kernel(
@@ -594,6 +631,11 @@ extern "C" int epos_softmax_groups_f32(float* X, int64_t n_groups, int G,
   EPOS_REQUIRE(X, "null pointer");
   EPOS_REQUIRE(G >= 1 && G <= 64, "G must be in [1, 64]");
   if (n_groups == 0) return EPOS_OK;
+  if (G == 64 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    hipLaunchKernelGGL(softmax_groups64_kernel, dim3(blocks_for(n_groups, 16)), dim3(256),
+                       0, static_cast<hipStream_t>(stream), X, n_groups);
+    return launch_status("softmax_groups64_kernel");
+  }
   hipLaunchKernelGGL(softmax_groups_kernel, dim3(blocks_for(n_groups, 4)),
                      dim3(256), 0, static_cast<hipStream_t>(stream), X, n_groups,
                      G);
@@ -657,6 +699,11 @@ extern "C" int epos_softmax_slots_f32(float* X, const EposCorrSlot* slots, int S
   EPOS_REQUIRE(X && slots, "null pointer");
   EPOS_REQUIRE(F >= 1 && F <= 64, "F must be in [1, 64]");
   if (S == 0 || P == 0) return EPOS_OK;
+  if (F == 64 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    hipLaunchKernelGGL(softmax_slots64_kernel, dim3(blocks_for(P, 16), S), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), X, slots, P, O);
+    return launch_status("softmax_slots64_kernel");
+  }
   hipLaunchKernelGGL(softmax_slots_kernel, dim3(blocks_for(P, 4), S), dim3(256), 0,
                      static_cast<hipStream_t>(stream), X, slots, P, O, F);
   return launch_status("softmax_slots_kernel");

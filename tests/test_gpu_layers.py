@@ -382,3 +382,15 @@ def test_stream_k_gemm_matches_reference(lib, m, k, n, res, monkeypatch):
   assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
   flags = ws.cpu().numpy()[-4096:].view(np.int32)
   assert not flags.any()              # flags self-reset, no error word
+
+
+def test_clock_probe_reports_a_plausible_core_clock(lib):
+  """epos_clock_probe: shader cycles per 100 MHz tick while a wave spins for 200 us."""
+  from epos_amd import _lib
+  out = torch.zeros(2, dtype=torch.int64, device='cuda')
+  _lib.check(lib.epos_clock_probe(_p(out), 200, None))
+  torch.cuda.synchronize()
+  cyc, ticks = [int(v) for v in out.cpu()]
+  assert 19000 <= ticks <= 40000                    # ~200 us of the 100 MHz counter
+  mhz = cyc / ticks * 100.0
+  assert 500.0 < mhz < 3000.0, mhz

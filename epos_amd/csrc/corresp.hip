@@ -25,19 +25,26 @@ __device__ __forceinline__ float wave_max64(float v) {
   return v;
 }
 
+// Pixels per wave in the mask / fill kernels: the per-pixel part uses the first
+// CORR_PPW lanes, the per-fragment part all 64. A wave walks its masked pixels one after
+// the other (each step a dependent 256-byte load), so FEWER pixels per wave = more
+// waves in flight = the latency of those steps overlaps.
+constexpr int CORR_PPW = 16;
+
 __global__ __launch_bounds__(256) void corr_mask_kernel(
     const float* __restrict__ obj_confs, const float* __restrict__ frag_confs,
     const EposCorrSlot* __restrict__ slots, int P, int O, int F, float tau_a,
     float tau_b, int32_t* px_flag, int32_t* corr_cnt, uint64_t* frag_mask) {
   const int s = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CORR_PPW;
   if (p0 >= P) return;                       // wave-uniform
   const int img = slots[s].image, obj = slots[s].obj_id;
   const int p = p0 + lane;
+  const bool mine = lane < CORR_PPW && p < P;   // this lane owns a pixel
   const int64_t pix0 = static_cast<int64_t>(img) * P;
   bool masked = false;
-  if (p < P) masked = obj_confs[(pix0 + p) * (O + 1) + obj] > tau_a;  // corresp.py:46-47
+  if (mine) masked = obj_confs[(pix0 + p) * (O + 1) + obj] > tau_a;  // corresp.py:46-47
   uint64_t todo = __ballot(masked);
   uint64_t mybits = 0;
   while (todo) {                             // wave-uniform loop over masked pixels
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(256) void corr_mask_kernel(
     const uint64_t bits = __ballot(lane < F && v > thr);   // corresp.py:64, strict >
     if (lane == j) mybits = bits;
   }
-  if (p < P) {
+  if (mine) {
     const int64_t o = static_cast<int64_t>(s) * P + p;
     px_flag[o] = masked ? 1 : 0;
     corr_cnt[o] = __popcll(mybits);
@@ -72,6 +79,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   return v;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(1024) void corr_scan_kernel(int32_t* px, int32_t* cnt,
                                                          int P, int32_t* totals) {
   __shared__ int32_t wa[16], wb[16];
@@ -79,10 +87,25 @@ __global__ __launch_bounds__(1024) void corr_scan_kernel(int32_t* px, int32_t* c
   int32_t* a = px + static_cast<int64_t>(s) * P;
   int32_t* b = cnt + static_cast<int64_t>(s) * P;
   int32_t carry_a = 0, carry_b = 0;
-  for (int base = 0; base < P; base += 1024) {
-    const int i = base + t;
-    const int32_t va = i < P ? a[i] : 0, vb = i < P ? b[i] : 0;
-    const int32_t ia = wave_incl_scan(va, lane), ib = wave_incl_scan(vb, lane);
+  for (int base = 0; base < P; base += 1024 * VEC) {
+    const int i = base + t * VEC;                // VEC consecutive elements per thread
+    int32_t va[VEC], vb[VEC];
+    if (VEC == 4 && i < P) {                     // P % 4 == 0: all four are in range
+      const int4 xa = *reinterpret_cast<const int4*>(a + i);
+      const int4 xb = *reinterpret_cast<const int4*>(b + i);
+      va[0] = xa.x; va[VEC > 1 ? 1 : 0] = xa.y; va[VEC > 2 ? 2 : 0] = xa.z; va[VEC > 3 ? 3 : 0] = xa.w;
+      vb[0] = xb.x; vb[VEC > 1 ? 1 : 0] = xb.y; vb[VEC > 2 ? 2 : 0] = xb.z; vb[VEC > 3 ? 3 : 0] = xb.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        va[e] = i + e < P ? a[i + e] : 0;
+        vb[e] = i + e < P ? b[i + e] : 0;
+      }
+    }
+    int32_t ta = 0, tb = 0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { ta += va[e]; tb += vb[e]; }
+    const int32_t ia = wave_incl_scan(ta, lane), ib = wave_incl_scan(tb, lane);
     if (lane == 63) { wa[wave] = ia; wb[wave] = ib; }
     __syncthreads();
     int32_t off_a = carry_a, off_b = carry_b, tot_a = 0, tot_b = 0;
@@ -92,7 +115,18 @@ __global__ __launch_bounds__(1024) void corr_scan_kernel(int32_t* px, int32_t* c
       if (w < wave) { off_a += xa; off_b += xb; }
       tot_a += xa; tot_b += xb;
     }
-    if (i < P) { a[i] = off_a + ia - va; b[i] = off_b + ib - vb; }   // exclusive
+    int32_t ra = off_a + ia - ta, rb = off_b + ib - tb;     // exclusive prefix of the thread
+    int32_t oa[VEC], ob[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { oa[e] = ra; ob[e] = rb; ra += va[e]; rb += vb[e]; }
+    if (VEC == 4 && i < P) {
+      *reinterpret_cast<int4*>(a + i) = make_int4(oa[0], oa[VEC > 1 ? 1 : 0], oa[VEC > 2 ? 2 : 0], oa[VEC > 3 ? 3 : 0]);
+      *reinterpret_cast<int4*>(b + i) = make_int4(ob[0], ob[VEC > 1 ? 1 : 0], ob[VEC > 2 ? 2 : 0], ob[VEC > 3 ? 3 : 0]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (i + e < P) { a[i + e] = oa[e]; b[i + e] = ob[e]; }
+    }
     carry_a += tot_a; carry_b += tot_b;
     __syncthreads();
   }
@@ -117,14 +151,14 @@ __global__ __launch_bounds__(256) void corr_fill_kernel(
     int64_t capacity, EposCorrOut out, int32_t* overflow) {
   const int s = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * CORR_PPW;
   if (p0 >= P) return;
   const int img = slots[s].image, obj = slots[s].obj_id;
   const int p = p0 + lane;
   const int64_t pix0 = static_cast<int64_t>(img) * P;
   uint64_t mbits = 0;
   int32_t pxo = 0, co = 0;
-  if (p < P) {
+  if (lane < CORR_PPW && p < P) {
     const int64_t o = static_cast<int64_t>(s) * P + p;
     mbits = frag_mask[o]; pxo = px_off[o]; co = corr_off[o];
   }
@@ -290,14 +324,19 @@ extern "C" int epos_corr_count(const float* obj_confs, const float* frag_confs,
   EPOS_REQUIRE(B > 0 && P > 0 && O > 0, "empty problem");
   if (S == 0) return EPOS_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  dim3 grid(static_cast<unsigned>(ceil_div(P, 256)), S);
+  dim3 grid(static_cast<unsigned>(ceil_div(P, 4 * CORR_PPW)), S);
   hipLaunchKernelGGL(corr_mask_kernel, grid, dim3(256), 0, st, obj_confs,
                      frag_confs, slots, P, O, F, min_obj_conf, min_frag_rel_conf,
                      px_off, corr_off, frag_mask);
   int rc = launch_status("corr_mask_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(corr_scan_kernel, dim3(S), dim3(1024), 0, st, px_off,
-                     corr_off, P, totals);
+  if (P % 4 == 0 && (reinterpret_cast<uintptr_t>(px_off) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(corr_off) & 15) == 0)
+    hipLaunchKernelGGL(corr_scan_kernel<4>, dim3(S), dim3(1024), 0, st, px_off,
+                       corr_off, P, totals);
+  else
+    hipLaunchKernelGGL(corr_scan_kernel<1>, dim3(S), dim3(1024), 0, st, px_off,
+                       corr_off, P, totals);
   return launch_status("corr_scan_kernel");
 }
 
@@ -324,7 +363,7 @@ extern "C" int epos_corr_fill(const float* obj_confs, const float* frag_confs,
   EPOS_REQUIRE(F >= 1 && F <= 64, "num_frags must be in [1, 64]");
   EPOS_REQUIRE(W > 0 && P % W == 0, "P must be a multiple of W");
   if (S == 0) return EPOS_OK;
-  dim3 grid(static_cast<unsigned>(ceil_div(P, 256)), S);
+  dim3 grid(static_cast<unsigned>(ceil_div(P, 4 * CORR_PPW)), S);
   hipLaunchKernelGGL(corr_fill_kernel, grid, dim3(256), 0,
                      static_cast<hipStream_t>(stream), obj_confs, frag_confs,
                      frag_coords, frag_centers, frag_sizes, slots, P, W, O, F,

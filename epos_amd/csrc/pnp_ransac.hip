@@ -293,6 +293,32 @@ __device__ __forceinline__ bool reproj(const double* pose, const double* K,
   return false;
 }
 
+constexpr int PF = 4;           // items fetched together per lane / thread
+
+// PF correspondences of one lane's strided partial (items i0, i0 + stride, ...): all
+// index loads first, then all point loads (unconditional, from clamped positions), so
+// that the gathers of PF items are in flight together.
+struct PointBatch {
+  double x2[PF][2], x3[PF][3];
+  bool ok[PF];
+  __device__ __forceinline__ void load(const double* xy, const double* xyz,
+                                       const int32_t* idx, int64_t i0, int stride,
+                                       int64_t m) {
+    int32_t p[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int64_t i = i0 + static_cast<int64_t>(u) * stride;
+      ok[u] = i < m;
+      p[u] = idx[ok[u] ? i : i0];
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      x2[u][0] = xy[2 * p[u]]; x2[u][1] = xy[2 * p[u] + 1];
+      x3[u][0] = xyz[3 * p[u]]; x3[u][1] = xyz[3 * p[u] + 1]; x3[u][2] = xyz[3 * p[u] + 2];
+    }
+  }
+};
+
 // MSAC scores + inlier counts of `ns` (<= 4) poses over idx[0..m) in ONE pass over
 // the correspondences (wave-wide; results uniform). Each pose's sum keeps the
 // canonical order: 64 strided per-lane partials, then the xor butterfly.
@@ -303,17 +329,23 @@ __device__ void score_poses(const double* poses, int ns, const double* K,
   const double inv_thr2 = 1.0 / thr2;
   double acc[MAX_SOL] = {0.0, 0.0, 0.0, 0.0};
   int cnt[MAX_SOL] = {0, 0, 0, 0};
-  for (int64_t i = lane; i < m; i += 64) {
-    const int32_t p = idx[i];
-    const double x2[2] = {xy[2 * p], xy[2 * p + 1]};
-    const double x3[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
+  // PF items of this lane's partial are fetched together (index -> point is a dependent
+  // gather: without this the loop is one memory round trip per item) and then consumed
+  // in the canonical order i, i + 64, ...
+  for (int64_t i0 = lane; i0 < m; i0 += 64 * PF) {
+    PointBatch pb;
+    pb.load(xy, xyz, idx, i0, 64, m);
 #pragma unroll
-    for (int q = 0; q < MAX_SOL; ++q) {
-      if (q < ns) {                                        // wave-uniform
-        double e2, Xc[3], r[2];
-        if (!reproj(poses + 12 * q, K, x2, x3, &e2, Xc, r) && e2 < thr2) {
-          acc[q] += 1.0 - e2 * inv_thr2;
-          ++cnt[q];
+    for (int u = 0; u < PF; ++u) {
+      if (!pb.ok[u]) continue;
+#pragma unroll
+      for (int q = 0; q < MAX_SOL; ++q) {
+        if (q < ns) {                                      // wave-uniform
+          double e2, Xc[3], r[2];
+          if (!reproj(poses + 12 * q, K, pb.x2[u], pb.x3[u], &e2, Xc, r) && e2 < thr2) {
+            acc[q] += 1.0 - e2 * inv_thr2;
+            ++cnt[q];
+          }
         }
       }
     }
@@ -481,11 +513,16 @@ __device__ double score_pose_block(const double* pose, const double* K, const do
   const double inv_thr2 = 1.0 / thr2;
   double acc = 0.0;
   int cnt = 0;
-  for (int64_t i = t; i < m; i += 256) {
-    const int32_t p = idx[i];
-    double e2, Xc[3], r[2];
-    if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
-    if (e2 < thr2) { acc += 1.0 - e2 * inv_thr2; ++cnt; }
+  for (int64_t i0 = t; i0 < m; i0 += 256 * PF) {
+    PointBatch pb;
+    pb.load(xy, xyz, idx, i0, 256, m);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (!pb.ok[u]) continue;
+      double e2, Xc[3], r[2];
+      if (reproj(pose, K, pb.x2[u], pb.x3[u], &e2, Xc, r)) continue;
+      if (e2 < thr2) { acc += 1.0 - e2 * inv_thr2; ++cnt; }
+    }
   }
   cnt = butterfly_sum_i(cnt);
   if ((t & 63) == 0) s_cnt[t >> 6] = cnt;
@@ -502,10 +539,14 @@ __device__ int gn_step_block(const double* pose, const double* K, const double* 
   double acc[27];
 #pragma unroll
   for (int v = 0; v < 27; ++v) acc[v] = 0.0;
-  for (int64_t i = t; i < m; i += 256) {
-    const int32_t p = idx[i];
+  for (int64_t i0 = t; i0 < m; i0 += 256 * PF) {
+    PointBatch pb;
+    pb.load(xy, xyz, idx, i0, 256, m);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+    if (!pb.ok[u]) continue;
     double e2, Xc[3], r[2];
-    if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
+    if (reproj(pose, K, pb.x2[u], pb.x3[u], &e2, Xc, r)) continue;
     if (!(e2 < thr2)) continue;
     const double iz = 1.0 / Xc[2];
     const double a0 = K[0] * iz, a1 = K[1] * iz,
@@ -527,6 +568,7 @@ __device__ int gn_step_block(const double* pose, const double* K, const double* 
       for (int b = a; b < 6; ++b) { acc[v] += J0[a] * J0[b] + J1[a] * J1[b]; ++v; }
 #pragma unroll
     for (int a = 0; a < 6; ++a) { acc[v] += J0[a] * r[0] + J1[a] * r[1]; ++v; }
+    }
   }
 #pragma unroll
   for (int v = 0; v < 27; ++v) {

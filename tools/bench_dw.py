@@ -4,7 +4,7 @@ next to a plain device copy of the same tensor (the streaming floor at that size
 EPOS_DW_L / EPOS_DW_THREADS select kernel variants."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from epos_amd import _lib
 defs = os.environ.get('DW_DEFS', '').split()         # ablation builds of layers.hip
 if defs:

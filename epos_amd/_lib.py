@@ -32,6 +32,7 @@ class PointwiseArgs(ctypes.Structure):
       ('sub', ctypes.c_int32),
       ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
       ('Hi', ctypes.c_int32), ('Wi', ctypes.c_int32),
+      ('Ws', vp),
   ]
 
 
@@ -108,6 +109,8 @@ SYMBOLS = {
     'epos_clock_probe': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'epos_pack_pointwise_weights': (ctypes.c_int64,
                                     [vp, ctypes.c_int, ctypes.c_int, vp]),
+    'epos_pack_pointwise_weights_split': (ctypes.c_int64,
+                                          [vp, ctypes.c_int, ctypes.c_int, vp]),
     'epos_pointwise_conv_f32': (ctypes.c_int,
                                 [ctypes.POINTER(PointwiseArgs), vp]),
     'epos_pointwise_conv_grouped_f32': (ctypes.c_int, [

@@ -20,6 +20,10 @@ int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s,
 int launch_grouped_sk(const EposPointwiseArgs* args, int count, void* workspace,
                       hipStream_t s);
 int64_t sk_workspace_bytes();
+// pointwise_gemm_split.hip: fp32 GEMM on the bf16 matrix pipe (exact three-way operand
+// split, six piece products); every problem carries split-packed weights (p.Ws).
+int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s);
+bool split_eligible(const EposPointwiseArgs* args, int count);
 
 namespace {
 
@@ -41,6 +45,31 @@ struct GroupedArgs {
   int conv_rate[MAX_GROUP];        //   and dilation
   int count;
 };
+
+// ---- LDS-DMA (global_load_lds_dwordx4) helpers, inline asm: hipcc neither waits for
+// these before ds_reads nor counts them, the kernels' vmcnt waits are explicit.
+// one wave-instruction: 64 lanes x 16 B -> LDS [lds_dst, lds_dst + 1024)
+__device__ __forceinline__ void glds16_v(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const uint64_t b = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b >> 32));
+  return reinterpret_cast<const float*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+__device__ __forceinline__ void glds16_s(unsigned voff, const float* sbase,
+                                         unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
 
 __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f),

@@ -675,6 +675,10 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
                        dim3(64 * GEMV_SLICES), 0, s, args[0], npad);
     return launch_status("pointwise_gemv_f32");
   }
+  // Split-operand kernel on the bf16 matrix pipe (pointwise_gemm_split.hip): fp32 in,
+  // fp32 out, error not above the fp32 MFMA's; taken whenever the caller supplied the
+  // split-packed weights. EPOS_GEMM_SPLIT=0 keeps everything on the fp32 MFMA kernels.
+  if (split_eligible(args, count)) return launch_grouped_split(args, count, s);
   // LDS-DMA kernel: the default whenever no pre-activation ReLU has to be applied to
   // A on the way into LDS (measured with warm clocks: 8-30 % faster than the
   // register-staged kernels on every shape of the network; it picks 128 x 64 tiles

@@ -50,29 +50,6 @@ constexpr int DMA_STAGE_BYTES = DMA_A_BYTES + DMA_B_BYTES;
 constexpr int DMA_STAGES = 3;
 constexpr int DMA_LDS_BYTES = DMA_STAGES * DMA_STAGE_BYTES;   // 73728
 
-// one wave-instruction: 64 lanes x 16 B -> LDS [lds_dst, lds_dst + 1024)
-__device__ __forceinline__ void glds16_v(const float* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ const float* uniform_ptr(const float* p) {
-  const uint64_t b = reinterpret_cast<uint64_t>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b));
-  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(b >> 32));
-  return reinterpret_cast<const float*>((static_cast<uint64_t>(hi) << 32) | lo);
-}
-__device__ __forceinline__ void glds16_s(unsigned voff, const float* sbase,
-                                         unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
-}
-
 // LAYOUT 0: 64 x 128 tile, waves 2 x 2.   LAYOUT 1: 128 x 64 tile, waves 4 x 1 (every
 // problem of the launch has N <= 64: a 128-wide tile would waste half of its MFMAs).
 // The per-wave tile (32 x 64), the six DMA pieces per wave and K tile and the 24 KB

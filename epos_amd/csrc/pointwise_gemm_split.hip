@@ -1,0 +1,452 @@
+// fp32 pointwise GEMM on the bf16 matrix pipe of gfx950 ("split" kernel).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate, and the GEMMs are 95 % of
+// the network's arithmetic. Here every fp32 operand is cut EXACTLY into three bf16
+// pieces -- x = hi + mid + lo, 8 + 8 + 8 significand bits, taken by truncation so that
+// both residuals are exact fp32 subtractions -- and the product a*b is assembled from
+// six piece products with v_mfma_f32_32x32x16_bf16, accumulated in fp32:
+//     a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + am*bm + al*bh)  [+ am*bl + al*bm + al*bl]
+// The three dropped terms are below 2^-23 |a*b|, i.e. below the rounding of a single
+// fp32 multiply-add; the piece products themselves are exact (8 x 8 bits) and each MFMA
+// adds 16 of them with one rounding, so the result is NOT less accurate than the fp32
+// MFMA (or an fmaf chain): measured against fp64 the rms error is equal with one
+// accumulator and ~3x smaller with the correction terms kept in their own accumulator
+// (tools/split_proto/split_acc.hip, tests/test_gpu_layers.py). Six bf16 MFMAs of 32
+// cycles replace eight fp32 MFMAs of 64 for the same 32x32x16 block: 2.67x less matrix
+// pipe time, and the bf16 MFMA does not share the VALU the way the fp32 one does.
+//
+// Weights are split and laid out in MFMA fragment order once on the host
+// (epos_pack_pointwise_weights_split); activations stay fp32 in HBM and are split in
+// registers after the fragment read (11 VALU ops per pair of values).
+//
+// Tile 128 x 128 per 256-thread workgroup (waves 2 x 2, 64 x 64 each: 4 blocks x 2
+// accumulators), K step 16 per stage, FOUR-stage LDS-DMA ring of 20 KB (A 128 rows x
+// 64 B fp32, XOR-swizzled through the per-lane source address; W 12 KB lane-linear
+// fragments) = 80 KB, two workgroups per CU. Tile kt+3 is issued while tile kt is
+// computed; one raw s_barrier per stage as in pointwise_gemm_dma_f32.
+#include <string.h>
+
+#include "pointwise_gemm.h"
+
+namespace epos {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) float g_zero_chunk_sp[4] = {0.f, 0.f, 0.f, 0.f};
+
+constexpr int SP_BM = 128, SP_BN = 128, SP_BK = 16;
+constexpr int SP_A_BYTES = SP_BM * SP_BK * 4;        // 8192
+constexpr int SP_W_BYTES = SP_BK * SP_BN * 6;        // 12288: 4 col blocks x 3 pieces x 1 KB
+constexpr int SP_STAGE = SP_A_BYTES + SP_W_BYTES;    // 20480
+constexpr int SP_NST = 4;
+constexpr int SP_LDS = SP_NST * SP_STAGE;            // 81920
+
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) {   // {b.hi, a.hi}
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+
+// eight fp32 values (k = 0..7 of one row) -> three packed bf16x8 pieces
+__device__ __forceinline__ void split8(const float4 x0, const float4 x1, u32x4& hi,
+                                       u32x4& mid, u32x4& lo) {
+  const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hb[j] = __float_as_uint(x[j]);
+    const float r1 = x[j] - __uint_as_float(hb[j] & 0xffff0000u);   // exact
+    mb[j] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(mb[j] & 0xffff0000u);     // exact, <= 8 bits
+    lb[j] = __float_as_uint(r2);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = pack_hi16(hb[2 * j], hb[2 * j + 1]);
+    mid[j] = pack_hi16(mb[2 * j], mb[2 * j + 1]);
+    lo[j] = pack_hi16(lb[2 * j], lb[2 * j + 1]);
+  }
+}
+
+__device__ __forceinline__ void mfma_bf16(const u32x4& a, const u32x4& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                              __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool HAS_RES, bool SINGLE, bool TWO_ACC>
+__global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedArgs ga_) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  (void)ga_;
+  const GroupedArgs* __restrict__ gp =
+      (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  int bid;
+  {   // workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles
+    const int total = gp->tile_start[MAX_GROUP];
+    const int raw = blockIdx.x, x = raw & 7, idx = raw >> 3;
+    const int q = total >> 3, r = total & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  int pi = 0;
+  if (!SINGLE) {
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i)
+      if (i < gp->count && bid >= gp->tile_start[i]) pi = i;
+    bid -= gp->tile_start[pi];
+  }
+  const EposPointwiseArgs p = gp->p[pi];
+  const int tiles_n = gp->tiles_n[pi];
+  const int tile_n = bid % tiles_n;
+  const int tile_m = bid / tiles_n;
+  const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
+  const int M = p.M, N = p.N, K = p.K;
+  const int nks = (K + SP_BK - 1) / SP_BK;
+
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) float*)smem));
+
+  // ---- A pieces (1 KB = 16 rows x 64 B): piece = wave*2 + i, lane -> (row, slot);
+  //      slot s of row r holds chunk s ^ ((r >> 2) & 3)
+  const float* asrc[2];
+  int achunk[2];
+  unsigned a_dst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 16 * (wave * 2 + i) + (lane >> 2);
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    int m = m0 + r;
+    m = m < M ? m : M - 1;
+    int64_t row = m;
+    if (p.sub > 1) {
+      asm volatile("" ::: "memory");        // keep the divisions off the common path
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      row = (static_cast<int64_t>(b) * p.Hi + yo * p.sub) * p.Wi + xo * p.sub;
+    }
+    asrc[i] = p.A + row * p.lda + c * 4;
+    achunk[i] = c * 4;
+    a_dst[i] = lds0 + SP_W_BYTES + (wave_u * 2 + i) * 1024;
+  }
+  // ---- W pieces: the 12 KB stage image is contiguous in the packed buffer
+  unsigned wvoff[3], w_dst[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    wvoff[i] = static_cast<unsigned>(((wave * 3 + i) * 64 + lane) * 16);
+    w_dst[i] = lds0 + (wave_u * 3 + i) * 1024;
+  }
+  const float* wsb = uniform_ptr(reinterpret_cast<const float*>(
+      static_cast<const char*>(p.Ws) + static_cast<int64_t>(tile_n) * nks * SP_W_BYTES));
+
+  auto issue_piece = [&](int kt, int stage, auto piece_tag, auto tail_tag) {
+    constexpr int PIECE = decltype(piece_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const unsigned so = static_cast<unsigned>(stage) * SP_STAGE;
+    if constexpr (PIECE < 2) {
+      const float* src = asrc[PIECE] + kt * SP_BK;
+      if (TAIL) src = (kt * SP_BK + achunk[PIECE] < K) ? src : g_zero_chunk_sp;
+      glds16_v(src, a_dst[PIECE] + so);
+    } else {
+      glds16_s(wvoff[PIECE - 2], wsb + static_cast<int64_t>(kt) * (SP_W_BYTES / 4),
+               w_dst[PIECE - 2] + so);
+    }
+  };
+  auto issue = [&](int kt, int stage) {
+    issue_piece(kt, stage, std::integral_constant<int, 0>{}, std::true_type{});
+    issue_piece(kt, stage, std::integral_constant<int, 1>{}, std::true_type{});
+    issue_piece(kt, stage, std::integral_constant<int, 2>{}, std::true_type{});
+    issue_piece(kt, stage, std::integral_constant<int, 3>{}, std::true_type{});
+    issue_piece(kt, stage, std::integral_constant<int, 4>{}, std::true_type{});
+  };
+
+  // ---- fragment addresses (float index from the stage base)
+  int a_off[2];
+  {
+    const int sw = (l31 >> 2) & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      a_off[j] = SP_W_BYTES / 4 + (wm * 64 + l31) * SP_BK + (((2 * h + j) ^ sw) << 2);
+  }
+  const int b_off = (wn * 2 * 3 * 64 + lane) * 4;      // + (cb*3 + piece) * 256 floats
+
+  float4 xa[2][2];          // raw fp32 A fragments of the NEXT stage to compute
+  u32x4 bp[2][3];           // pre-split W fragments
+  auto read_a = [&](int stage) {
+    const float* s = smem + stage * (SP_STAGE / 4);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        xa[rb][j] = *reinterpret_cast<const float4*>(s + a_off[j] + rb * 32 * SP_BK);
+  };
+  auto read_b = [&](int stage, auto cb_tag) {
+    constexpr int cb = decltype(cb_tag)::value;
+    const float* s = smem + stage * (SP_STAGE / 4);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      bp[cb][pc] = *reinterpret_cast<const u32x4*>(s + b_off + (cb * 3 + pc) * 256);
+  };
+
+  f32x16 acc[4], acc2[TWO_ACC ? 4 : 1];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  if (TWO_ACC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+  }
+
+  // ---- prologue: up to three tiles in flight, tile 0 landed + visible
+  issue(0, 0);
+  if (nks > 1) issue(1, 1);
+  if (nks > 2) issue(2, 2);
+  if (nks > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (nks > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_a(0);
+  read_b(0, std::integral_constant<int, 0>{});
+  read_b(0, std::integral_constant<int, 1>{});
+
+  // MODE 0: issue tile kt+3 (full)  1: issue tile kt+3 (the last, maybe partial)
+  //      2: kt+2 is the last tile   3: kt+1 is the last tile   4: last tile
+  auto tile = [&](int kt, int stage, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const int s3 = (stage + 3) & 3, s1 = (stage + 1) & 3;
+    u32x4 ah[2], am[2], al[2];
+#ifdef EPOS_SPLIT_ABL_NOSPLIT
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* x0 = reinterpret_cast<const float*>(&xa[rb][0]);
+        const float* x1 = reinterpret_cast<const float*>(&xa[rb][1]);
+        ah[rb][j] = __float_as_uint(x0[j]); am[rb][j] = __float_as_uint(x1[j]);
+        al[rb][j] = ah[rb][j] ^ am[rb][j];
+      }
+#else
+    split8(xa[0][0], xa[0][1], ah[0], am[0], al[0]);
+    split8(xa[1][0], xa[1][1], ah[1], am[1], al[1]);
+#endif
+    auto half = [&](auto cb_tag, auto dma_tag) {
+      constexpr int cb = decltype(cb_tag)::value;
+      constexpr bool DMA = decltype(dma_tag)::value;
+      const u32x4 bh = bp[cb][0], bm = bp[cb][1], bl = bp[cb][2];
+      f32x16* corr = TWO_ACC ? acc2 : acc;
+      auto pair = [&](const u32x4* a, const u32x4& b, f32x16* c, auto n_tag) {
+        constexpr int n = decltype(n_tag)::value;
+        mfma_bf16(a[0], b, c[0 * 2 + cb]);
+        mfma_bf16(a[1], b, c[1 * 2 + cb]);
+#ifdef EPOS_SPLIT_ABL_NODMA
+        constexpr bool kIssue = false;
+#else
+        constexpr bool kIssue = true;
+#endif
+        if constexpr (kIssue && DMA && n < 5) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(kt + 3, s3, std::integral_constant<int, n>{},
+                      std::integral_constant<bool, MODE == 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      pair(al, bh, corr, std::integral_constant<int, 0>{});
+      pair(ah, bl, corr, std::integral_constant<int, 1>{});
+      pair(am, bm, corr, std::integral_constant<int, 2>{});
+      pair(am, bh, corr, std::integral_constant<int, 3>{});
+      pair(ah, bm, corr, std::integral_constant<int, 4>{});
+      pair(ah, bh, acc, std::integral_constant<int, 5>{});
+    };
+    half(std::integral_constant<int, 0>{}, std::integral_constant<bool, (MODE <= 1)>{});
+    if constexpr (MODE != 4) {
+      // my reads of this stage are complete (fragments are in registers); my pieces
+      // of tile kt+1 have landed once at most the later tiles' pieces are outstanding
+#ifndef EPOS_SPLIT_ABL_NOBAR
+      if (MODE <= 1) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      else if (MODE == 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#endif
+#ifndef EPOS_SPLIT_ABL_NOREAD
+      read_a(s1);
+      read_b(s1, std::integral_constant<int, 0>{});
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    half(std::integral_constant<int, 1>{}, std::false_type{});
+#ifndef EPOS_SPLIT_ABL_NOREAD
+    if constexpr (MODE != 4) read_b(s1, std::integral_constant<int, 1>{});
+#endif
+  };
+  {
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
+    using M4 = std::integral_constant<int, 4>;
+    int kt = 0;
+    for (; kt + 7 < nks; kt += 4) {        // every LDS offset an immediate
+      tile(kt, 0, M0{});
+      tile(kt + 1, 1, M0{});
+      tile(kt + 2, 2, M0{});
+      tile(kt + 3, 3, M0{});
+    }
+    int stage = 0;                          // kt is a multiple of 4 here
+    for (; kt + 4 < nks; ++kt) {
+      tile(kt, stage, M0{});
+      stage = (stage + 1) & 3;
+    }
+    if (kt + 4 == nks) { tile(kt, stage, M1{}); stage = (stage + 1) & 3; ++kt; }
+    if (kt + 3 == nks) { tile(kt, stage, M2{}); stage = (stage + 1) & 3; ++kt; }
+    if (kt + 2 == nks) { tile(kt, stage, M3{}); stage = (stage + 1) & 3; ++kt; }
+    tile(kt, stage, M4{});
+  }
+  if (TWO_ACC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] += acc2[j][r];
+  }
+
+  // ---- epilogue --------------------------------------------------------------
+  if (vec_epilogue_ok(p, HAS_RES)) {
+    __syncthreads();
+    float* ws = smem + wave * 64 * EP_ROW;
+    vec_epilogue<2, 2, HAS_RES>(ws, acc, p, m0 + wm * 64, n0 + wn * 64, lane);
+    return;
+  }
+  const bool relu = p.relu != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + l31;
+      const int nc = n < N ? n : N - 1;
+      const float bias = p.bias ? p.bias[nc] : 0.f;
+      const int mb = m0 + wm * 64 + i * 32 + 4 * h;
+      float rv[16];
+      if (HAS_RES) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = mb + (r & 3) + 8 * (r >> 2);
+          m = m < M ? m : M - 1;
+          rv[r] = p.R[static_cast<int64_t>(m) * p.ldr + nc];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        float v = acc[i * 2 + j][r] + bias;
+        if (HAS_RES) v += rv[r];
+        if (relu) v = fmaxf(v, 0.f);
+        if (m < M && n < N) p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
+      }
+    }
+}
+
+template <bool HAS_RES, bool SINGLE, bool TWO_ACC>
+int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s) {
+  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, TWO_ACC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+    attr_set = true;
+  }
+  // 80 KB per workgroup: at most two per CU = two MFMA waves per SIMD
+  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), SP_LDS, s, g);
+  return launch_status("pointwise_gemm_split_f32");
+}
+
+}  // namespace
+
+// A group goes to the split kernel when every problem carries split weights and has no
+// pre-activation ReLU. The choice depends on nothing else (not on N, not on the other
+// problems of the group): a layer gives bit-identical results whether it is launched
+// alone or grouped (the sparse-head path relies on that).
+bool split_eligible(const EposPointwiseArgs* args, int count) {
+  static const int mode = [] {
+    const char* e = getenv("EPOS_GEMM_SPLIT");
+    return e ? atoi(e) : 1;
+  }();
+  if (mode == 0) return false;
+  for (int i = 0; i < count; ++i) {
+    const EposPointwiseArgs& a = args[i];
+    if (!a.Ws || a.relu_in != 0 || a.M <= 8 || (a.K & 3) != 0 || (a.lda & 3) != 0 ||
+        (reinterpret_cast<uintptr_t>(a.A) & 15) != 0)
+      return false;
+  }
+  return true;
+}
+
+int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s) {
+  static const int two_acc = [] {
+    const char* e = getenv("EPOS_GEMM_SPLIT_ACC");
+    return e ? atoi(e) : 2;
+  }();
+  GroupedArgs g = {};
+  g.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    g.p[i] = args[i];
+    g.tile_start[i] = total;
+    g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, SP_BN));
+    g.npad[i] = g.tiles_n[i] * SP_BN;
+    total += static_cast<int>(ceil_div(args[i].M, SP_BM)) * g.tiles_n[i];
+  }
+  for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  const bool res = args[0].R != nullptr;
+  const bool single = count == 1;
+  if (two_acc == 2) {
+    if (res) return single ? launch_split_tt<true, true, true>(g, total, s)
+                           : launch_split_tt<true, false, true>(g, total, s);
+    return single ? launch_split_tt<false, true, true>(g, total, s)
+                  : launch_split_tt<false, false, true>(g, total, s);
+  }
+  if (res) return single ? launch_split_tt<true, true, false>(g, total, s)
+                         : launch_split_tt<true, false, false>(g, total, s);
+  return single ? launch_split_tt<false, true, false>(g, total, s)
+                : launch_split_tt<false, false, false>(g, total, s);
+}
+
+}  // namespace epos
+
+extern "C" int64_t epos_pack_pointwise_weights_split(const float* w_kn, int K, int N,
+                                                     void* dst) {
+  using namespace epos;
+  const int64_t tiles_n = ceil_div(N, SP_BN), nks = ceil_div(K, SP_BK);
+  const int64_t total = tiles_n * nks * SP_W_BYTES;
+  if (!dst) return total;
+  uint16_t* out = static_cast<uint16_t*>(dst);
+  for (int64_t tn = 0; tn < tiles_n; ++tn)
+    for (int64_t ks = 0; ks < nks; ++ks)
+      for (int cbw = 0; cbw < 4; ++cbw)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int j = 0; j < 8; ++j) {
+            const int64_t col = tn * SP_BN + cbw * 32 + (ln & 31);
+            const int64_t k = ks * SP_BK + (ln >> 5) * 8 + j;
+            const float w = (k < K && col < N) ? w_kn[k * static_cast<int64_t>(N) + col] : 0.f;
+            uint32_t hb, mb, lb;
+            memcpy(&hb, &w, 4);
+            float hf; const uint32_t hm = hb & 0xffff0000u; memcpy(&hf, &hm, 4);
+            const float r1 = w - hf;
+            memcpy(&mb, &r1, 4);
+            float mf; const uint32_t mm = mb & 0xffff0000u; memcpy(&mf, &mm, 4);
+            const float r2 = r1 - mf;
+            memcpy(&lb, &r2, 4);
+            const uint16_t piece[3] = {static_cast<uint16_t>(hb >> 16),
+                                       static_cast<uint16_t>(mb >> 16),
+                                       static_cast<uint16_t>(lb >> 16)};
+            for (int pc = 0; pc < 3; ++pc)
+              out[((((tn * nks + ks) * 4 + cbw) * 3 + pc) * 64 + ln) * 8 + j] = piece[pc];
+          }
+  return total;
+}

@@ -116,6 +116,22 @@ class EposNet(object):
     b[:n] = bias
     return self._dev(dst), self._dev(b), kpad
 
+  def _pack_split(self, w_kn, scale):
+    """The same folded weights in the split-operand GEMM's layout (three exact bf16
+    pieces per weight, MFMA fragment order): epos_pack_pointwise_weights_split."""
+    k, n = w_kn.shape
+    w = np.ascontiguousarray(w_kn.astype(np.float32) * scale[None, :].astype(
+        np.float32))
+    kpad = (k + 3) // 4 * 4
+    if kpad != k:
+      w = np.concatenate([w, np.zeros((kpad - k, n), np.float32)], 0)
+    total = self.lib.epos_pack_pointwise_weights_split(None, kpad, n, None)
+    dst = np.empty(total, np.uint8)
+    self.lib.epos_pack_pointwise_weights_split(
+        w.ctypes.data_as(ctypes.c_void_p), kpad, n,
+        dst.ctypes.data_as(ctypes.c_void_p))
+    return self._dev(dst)
+
   def _conv_params(self, scope, eps):
     """1x1 / dense conv followed by BN -> (w [K,N], scale, bias)."""
     w = self.ckpt[scope + '/weights']
@@ -142,13 +158,15 @@ class EposNet(object):
     """One 1x1 conv. With ``group`` (a list) the problem is only appended to it;
     ``_flush_group`` later launches the whole list as ONE grouped GEMM."""
     wp, bp, kpad = self._pack_pointwise(w_kn, scale, bias)
+    ws = None if relu_in else self._pack_split(w_kn, scale)
     n = w_kn.shape[1]
     assert kpad == k or (kpad > k and lda >= kpad), (name, k, kpad, lda)
     args = _lib.PointwiseArgs(
         A=_ptr(a, a_off), lda=lda, Wp=_ptr(wp), bias=_ptr(bp),
         R=_ptr(res, res_off) if res is not None else None, ldr=ldr,
         C=_ptr(c, c_off), ldc=ldc, M=m, N=n, K=kpad, relu=int(relu),
-        relu_in=int(relu_in), sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi)
+        relu_in=int(relu_in), sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi,
+        Ws=_ptr(ws) if ws is not None else None)
     lib = self.lib
     if group is not None:
       group.append((name, args, 2 * m * n * k))
@@ -586,8 +604,10 @@ class EposNet(object):
       one_c, one_l = np.ones(F, np.float32), np.ones(3 * F, np.float32)
       pc = self._pack_pointwise(wc[:, o * F:(o + 1) * F], one_c,
                                 bc[o * F:(o + 1) * F])
+      pc = pc + (self._pack_split(wc[:, o * F:(o + 1) * F], one_c),)
       pl = self._pack_pointwise(wl[:, o * 3 * F:(o + 1) * 3 * F], one_l,
                                 bl[o * 3 * F:(o + 1) * 3 * F])
+      pl = pl + (self._pack_split(wl[:, o * 3 * F:(o + 1) * 3 * F], one_l),)
       packs.append((pc, pl))
     self._sparse_packs = packs
 
@@ -610,14 +630,14 @@ class EposNet(object):
     for kind in (0, 1):
       probs = []
       for im, obj_id in slots:
-        wp, bp, _ = self._sparse_packs[obj_id - 1][kind]
+        wp, bp, _, ws = self._sparse_packs[obj_id - 1][kind]
         n = F if kind == 0 else 3 * F
         buf = conf if kind == 0 else loc
         ldc = O * n
         probs.append(_lib.PointwiseArgs(
             A=_ptr(x, im * P * 256), lda=256, Wp=_ptr(wp), bias=_ptr(bp), R=None,
             ldr=0, C=_ptr(buf, im * P * ldc + (obj_id - 1) * n), ldc=ldc, M=P,
-            N=n, K=256, relu=0, relu_in=0, sub=1))
+            N=n, K=256, relu=0, relu_in=0, sub=1, Ws=_ptr(ws)))
         flops += 2 * P * n * 256
       for i in range(0, len(probs), 8):
         chunk = probs[i:i + 8]

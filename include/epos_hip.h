@@ -56,6 +56,14 @@ int epos_clock_probe(int64_t* out2, int microseconds, void* stream);
  * Returns the number of floats written (or required, if dst == NULL). */
 int64_t epos_pack_pointwise_weights(const float* w_kn, int K, int N, float* dst);
 
+/* The same matrix for the split-operand GEMM (pointwise_gemm_split_f32): every fp32
+ * weight is cut EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, hi + mid +
+ * lo == w) and stored in the fragment order of v_mfma_f32_32x32x16_bf16:
+ * [ceil(N/128)][ceil(K/16)][4 column blocks][3 pieces][64 lanes][8 bf16], zero padded.
+ * Host-side helper (host pointers). Returns the number of BYTES written (or required,
+ * if dst == NULL). */
+int64_t epos_pack_pointwise_weights_split(const float* w_kn, int K, int N, void* dst);
+
 /* out[m, n] = act( sum_k A[row(m), k] * W[k, n] + bias[n] (+ R[m, n]) )
  * = slim.conv2d(kernel 1x1, stride `sub`) + folded BatchNorm (+ residual add)
  * (+ ReLU): net_xception.py:167-182 (pointwise half of separable_conv2d_same),
@@ -77,6 +85,8 @@ typedef struct EposPointwiseArgs {
   int32_t relu_in;    /* apply ReLU to A on load (pre-activation) */
   int32_t sub;        /* spatial subsampling of A rows (1 or 2) */
   int32_t Ho, Wo, Hi, Wi;   /* only read when sub > 1 */
+  const void* Ws;     /* optional [device]: the same weights packed by
+                       * epos_pack_pointwise_weights_split (NULL = not provided) */
 } EposPointwiseArgs;
 int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
 

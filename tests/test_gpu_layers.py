@@ -103,6 +103,109 @@ def test_pointwise_gemm_dma_ring(lib, k, m, n, aligned, res):
   assert (out[:, :off] == -7.0).all() and (out[:, off + n:] == -7.0).all()
 
 
+def _pack_split(lib, w_kn):
+  k, n = w_kn.shape
+  total = lib.epos_pack_pointwise_weights_split(None, k, n, None)
+  dst = np.empty(total, np.uint8)
+  w = np.ascontiguousarray(w_kn, np.float32)
+  lib.epos_pack_pointwise_weights_split(w.ctypes.data_as(ctypes.c_void_p), k, n,
+                                        dst.ctypes.data_as(ctypes.c_void_p))
+  return torch.from_numpy(dst).cuda()
+
+
+@pytest.mark.parametrize('k', [16, 32, 48, 64, 80, 96, 112, 128, 144, 40, 92, 728])
+@pytest.mark.parametrize('m,n,aligned,res', [(128, 128, 1, 0), (130, 200, 1, 1),
+                                             (257, 132, 0, 1), (1000, 96, 1, 0)])
+def test_pointwise_gemm_split_ring(lib, k, m, n, aligned, res):
+  """Split-operand kernel (fp32 GEMM on the bf16 matrix pipe, taken when Ws is given):
+  every prologue / steady / tail path of the four-stage ring (1..46 K steps, partial
+  last step), ragged M and N tiles, the float4 and the scalar epilogue, residual +
+  ReLU; NaNs behind every row of A poison any read past K. Tolerance as for the fp32
+  kernels (the accuracy comparison proper is test_pointwise_gemm_split_accuracy)."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(k * 7 + m + n)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  bias = rng.standard_normal(n).astype(np.float32)
+  r = rng.standard_normal((m, n)).astype(np.float32)
+  npad = (n + 127) // 128 * 128
+  bpad = np.zeros(npad, np.float32); bpad[:n] = bias
+  lda = k + 36
+  abuf = np.full((m, lda), np.nan, np.float32); abuf[:, :k] = a
+  A, Wp, Ws, Bd, R = (torch.from_numpy(abuf).cuda(), _pack(lib, w), _pack_split(lib, w),
+                      torch.from_numpy(bpad).cuda(), torch.from_numpy(r).cuda())
+  ldc = n + (4 if aligned else 5)
+  off = 4 if aligned else 3
+  C = torch.full((m, ldc), -7.0, device='cuda')
+  args = _lib.PointwiseArgs(A=_p(A), lda=lda, Wp=_p(Wp), bias=_p(Bd),
+                            R=_p(R) if res else None, ldr=n, C=_p(C, off), ldc=ldc,
+                            M=m, N=n, K=k, relu=res, relu_in=0, sub=1, Ws=_p(Ws))
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  torch.cuda.synchronize()
+  out = C.cpu().numpy()
+  ref = a.astype(np.float64) @ w.astype(np.float64) + bias
+  if res:
+    ref = np.maximum(ref + r, 0)
+  np.testing.assert_allclose(out[:, off:off + n], ref, rtol=2e-5, atol=2e-5)
+  assert (out[:, :off] == -7.0).all() and (out[:, off + n:] == -7.0).all()
+
+
+def test_pointwise_gemm_split_grouped_and_strided(lib):
+  """Three problems in one grid (one of them 22 columns wide: scalar epilogue inside
+  a group) and a stride-2 row gather, through the split kernel."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(12)
+  b, hi, wi, cin = 2, 13, 18, 72
+  ho, wo = (hi + 1) // 2, (wi + 1) // 2
+  x = rng.standard_normal((b, hi, wi, cin)).astype(np.float32)
+  X = torch.from_numpy(x).cuda()
+  outs, refs, arr = [], [], (_lib.PointwiseArgs * 3)()
+  keep = []
+  for i, (n, sub) in enumerate([(136, 2), (22, 2), (260, 2)]):
+    w = (rng.standard_normal((cin, n)) / np.sqrt(cin)).astype(np.float32)
+    Wp, Ws = _pack(lib, w), _pack_split(lib, w)
+    C = torch.zeros(b * ho * wo, n, device='cuda')
+    keep += [Wp, Ws, C]
+    arr[i] = _lib.PointwiseArgs(A=_p(X), lda=cin, Wp=_p(Wp), bias=None, R=None, ldr=0,
+                                C=_p(C), ldc=n, M=b * ho * wo, N=n, K=cin, relu=0,
+                                relu_in=0, sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi,
+                                Ws=_p(Ws))
+    outs.append(C)
+    refs.append(x[:, ::2, ::2, :].reshape(-1, cin).astype(np.float64) @ w)
+  _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
+  torch.cuda.synchronize()
+  for C, ref in zip(outs, refs):
+    np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('m,k,n', [(4800, 728, 728), (2048, 2048, 256), (4096, 256, 1344)])
+def test_pointwise_gemm_split_accuracy(lib, m, k, n):
+  """The claim the split kernel rests on: its error against an fp64 product is NOT
+  larger than the fp32-MFMA kernel's on the same inputs (ReLU-like activations, as in
+  the network). Errors are measured relative to sum_k |a||w| per output."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(k + n)
+  a = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  A, Wp, Ws = torch.from_numpy(a).cuda(), _pack(lib, w), _pack_split(lib, w)
+  ref = a.astype(np.float64) @ w.astype(np.float64)
+  mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64)
+  errs = {}
+  for name, ws in (('fp32_mfma', None), ('split', Ws)):
+    C = torch.zeros(m, n, device='cuda')
+    args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=None, R=None, ldr=0,
+                              C=_p(C), ldc=n, M=m, N=n, K=k, relu=0, relu_in=0, sub=1,
+                              Ws=_p(ws) if ws is not None else None)
+    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+    torch.cuda.synchronize()
+    e = np.abs(C.cpu().numpy().astype(np.float64) - ref) / mag
+    errs[name] = (float(np.sqrt((e * e).mean())), float(e.max()))
+  print('rms / max error relative to sum|a||w|:', errs)
+  assert errs['split'][0] <= errs['fp32_mfma'][0] * 1.05
+  assert errs['split'][1] <= errs['fp32_mfma'][1] * 1.5
+  assert errs['split'][1] < 4e-7
+
+
 def test_pointwise_gemm_dma_grouped_and_strided(lib):
   """One grid for three problems of different shapes (as the heads / ASPP groups)
   plus a stride-2 row gather (shortcut convs), all through the LDS-DMA kernel."""

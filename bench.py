@@ -13,8 +13,9 @@ pose records on the host at the end of the step. Weights are random-init with th
 reference's initialisers (no network access for the released checkpoints).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  "roofline":     fp32-MFMA roofline of the dominant kernel (pointwise_gemm_dma_f32),
-                  measured with HIP events around every launch of it,
+  "roofline":     matrix-pipe roofline of the dominant kernel (pointwise_gemm_split_f32:
+                  fp32 GEMM as six bf16 piece products), measured with HIP events
+                  around every GEMM launch,
   "cpu_baseline": the CPU oracle (torch-CPU net + numpy corresp + C RANSAC) timed
                   on this host on a bounded sample (N=1, rank 0 only).
 """
@@ -43,6 +44,10 @@ from epos_amd import pipeline, synthetic, weights   # noqa: E402
 from epos_amd import _lib                   # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 roof
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+# The split kernel spends six bf16 piece products per fp32 product, so its roof in
+# ALGORITHMIC (fp32) flops is the bf16 peak / 6.
+SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
 ALGO_GFLOP_C2 = 455.0           # SURVEY.md App. A, per image
 
 
@@ -154,6 +159,16 @@ def gemm_roofline(pipe, steps):
       flops += net.op_flops[name]
       per.setdefault(name, []).append(ms)
   achieved = flops / (total_ms * 1e-3) / 1e12
+  split = os.environ.get('EPOS_GEMM_SPLIT', '1') != '0'
+  if split:
+    kernel, peak = 'pointwise_gemm_split_f32', SPLIT_PEAK_TFLOPS
+    peak_note = ('algorithmic fp32 flops against the bf16 dense MFMA peak (2516.6) / 6: the '
+                 'kernel forms every fp32 product exactly from six bf16 piece products '
+                 '(fp32 in, fp32 out, error below the fp32 MFMA kernel\'s); the fp32-MFMA '
+                 'roof of the same work is 157.3')
+  else:
+    kernel, peak = 'pointwise_gemm_dma_f32', FP32_MFMA_PEAK_TFLOPS
+    peak_note = 'dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'
   # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE and
   # WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE) that cannot
   # run inside this process; the committed summary of the last collection is
@@ -166,10 +181,12 @@ def gemm_roofline(pipe, steps):
     traffic_src = 'profiles/r01/gemm_hbm_traffic_pmc.json (rocprofv3 --pmc)'
   return {
       'bound': 'mfma', 'achieved': round(achieved, 2),
-      'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-      'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+      'peak': round(peak, 1), 'unit': 'TFLOP/s',
+      'frac': round(achieved / peak, 4), 'traffic': traffic,
       'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,
-      'kernel': 'pointwise_gemm_dma_f32',
+      'kernel': kernel,
+      'peak_note': peak_note,
+      'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
       'launches_per_image': launches // steps // net.B,
       'avg_launch_us': round(total_ms * 1e3 / launches, 2),
       'gflop_per_image': round(flops / steps / net.B / 1e9, 1),
@@ -297,6 +314,13 @@ def main():
                           'raw' if args.no_calibrate else 'calibrated to ~10% '
                           'masked pixels per object', args.num_objs,
                           args.num_frags, args.objs_per_image, B),
+          'arithmetic': ('fp32 activations / weights / accumulators everywhere, as the '
+                         'reference; 1x1-conv GEMMs: every fp32 product formed exactly '
+                         'from three-way bf16 splits of both operands (six bf16 MFMA '
+                         'piece products, fp32 accumulate), measured error vs fp64 below '
+                         'the fp32-MFMA kernel (EPOS_GEMM_SPLIT=0 selects that kernel)'
+                         if os.environ.get('EPOS_GEMM_SPLIT', '1') != '0' else
+                         'fp32 everywhere, GEMMs on v_mfma_f32_32x32x2_f32'),
           'height': args.height, 'width': args.width,
           'batch_per_gpu': B, 'global_batch': B * world,
           'parallelism': 'dp%d (images sharded, one all_gather of pose records)'
@@ -321,7 +345,8 @@ def main():
     if core_mhz:
       # sampled in extra steps after the timed region; peak stays the 2.4 GHz figure
       roof['core_clock_mhz_under_load'] = round(core_mhz, 0)
-      roof['peak_at_measured_clock'] = round(64 * 1024 * core_mhz * 1e6 / 1e12, 1)
+      per_clk = 1024 / 6.0 if roof['kernel'] == 'pointwise_gemm_split_f32' else 64
+      roof['peak_at_measured_clock'] = round(per_clk * 1024 * core_mhz * 1e6 / 1e12, 1)
     roof['end_to_end_tflops'] = round(value / world * pipe.net.flops / B / 1e12, 2)
     gemm_gflop = roof['gflop_per_image']
     if args.sparse_heads:     # flops actually executed, not the dense plan's

@@ -71,6 +71,16 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const float* sbase,
       : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
 }
 
+// The same without saving M0 (nothing else in these kernels reads it).
+__device__ __forceinline__ void glds16_v_m0(const float* gsrc, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+}
+__device__ __forceinline__ void glds16_s_m0(unsigned voff, const float* sbase,
+                                            unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+               : : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory", "m0");
+}
 __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f),
                      fmaxf(v.w, 0.f));

@@ -36,12 +36,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __attribute__((aligned(16))) float g_zero_chunk_sp[4] = {0.f, 0.f, 0.f, 0.f};
 
-constexpr int SP_BM = 128, SP_BN = 128, SP_BK = 16;
-constexpr int SP_A_BYTES = SP_BM * SP_BK * 4;        // 8192
+constexpr int SP_BN = 128, SP_BK = 16;
 constexpr int SP_W_BYTES = SP_BK * SP_BN * 6;        // 12288: 4 col blocks x 3 pieces x 1 KB
-constexpr int SP_STAGE = SP_A_BYTES + SP_W_BYTES;    // 20480
 constexpr int SP_NST = 4;
-constexpr int SP_LDS = SP_NST * SP_STAGE;            // 81920
+// RB = 32-row blocks per wave: RB 2 -> 128 x 128 tile (A 8 KB per stage, 80 KB ring),
+// RB 1 -> 64 x 128 tile (A 4 KB, 64 KB ring) for grids that would otherwise leave the
+// CUs with one workgroup (= one wave per SIMD) each.
+constexpr int sp_stage_bytes(int rb) { return SP_W_BYTES + 64 * rb * SP_BK * 4; }
+constexpr int sp_lds_bytes(int rb) { return SP_NST * sp_stage_bytes(rb); }
 
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) {   // {b.hi, a.hi}
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
@@ -73,8 +75,11 @@ __device__ __forceinline__ void mfma_bf16(const u32x4& a, const u32x4& b, f32x16
                                               __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <bool HAS_RES, bool SINGLE, bool TWO_ACC>
+template <bool HAS_RES, bool SINGLE, bool TWO_ACC, int RB>
 __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedArgs ga_) {
+  constexpr int SP_BM = 64 * RB;
+  constexpr int SP_STAGE = sp_stage_bytes(RB);
+  constexpr int NP = RB + 3;                 // LDS-DMA pieces per wave and stage
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -113,12 +118,12 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
 
   // ---- A pieces (1 KB = 16 rows x 64 B): piece = wave*2 + i, lane -> (row, slot);
   //      slot s of row r holds chunk s ^ ((r >> 2) & 3)
-  const float* asrc[2];
-  int achunk[2];
-  unsigned a_dst[2];
+  const float* asrc[RB];
+  int achunk[RB];
+  unsigned a_dst[RB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = 16 * (wave * 2 + i) + (lane >> 2);
+  for (int i = 0; i < RB; ++i) {
+    const int r = 16 * (wave * RB + i) + (lane >> 2);
     const int c = (lane & 3) ^ ((r >> 2) & 3);
     int m = m0 + r;
     m = m < M ? m : M - 1;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     }
     asrc[i] = p.A + row * p.lda + c * 4;
     achunk[i] = c * 4;
-    a_dst[i] = lds0 + SP_W_BYTES + (wave_u * 2 + i) * 1024;
+    a_dst[i] = lds0 + SP_W_BYTES + (wave_u * RB + i) * 1024;
   }
   // ---- W pieces: the 12 KB stage image is contiguous in the packed buffer
   unsigned wvoff[3], w_dst[3];
@@ -148,13 +153,22 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     constexpr int PIECE = decltype(piece_tag)::value;
     constexpr bool TAIL = decltype(tail_tag)::value;
     const unsigned so = static_cast<unsigned>(stage) * SP_STAGE;
-    if constexpr (PIECE < 2) {
+    if constexpr (PIECE < RB) {
       const float* src = asrc[PIECE] + kt * SP_BK;
       if (TAIL) src = (kt * SP_BK + achunk[PIECE] < K) ? src : g_zero_chunk_sp;
+#ifdef EPOS_SPLIT_M0SAVE
       glds16_v(src, a_dst[PIECE] + so);
+#else
+      glds16_v_m0(src, a_dst[PIECE] + so);
+#endif
     } else {
-      glds16_s(wvoff[PIECE - 2], wsb + static_cast<int64_t>(kt) * (SP_W_BYTES / 4),
-               w_dst[PIECE - 2] + so);
+#ifdef EPOS_SPLIT_M0SAVE
+      glds16_s(wvoff[PIECE - RB], wsb + static_cast<int64_t>(kt) * (SP_W_BYTES / 4),
+               w_dst[PIECE - RB] + so);
+#else
+      glds16_s_m0(wvoff[PIECE - RB], wsb + static_cast<int64_t>(kt) * (SP_W_BYTES / 4),
+               w_dst[PIECE - RB] + so);
+#endif
     }
   };
   auto issue = [&](int kt, int stage) {
@@ -162,7 +176,8 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     issue_piece(kt, stage, std::integral_constant<int, 1>{}, std::true_type{});
     issue_piece(kt, stage, std::integral_constant<int, 2>{}, std::true_type{});
     issue_piece(kt, stage, std::integral_constant<int, 3>{}, std::true_type{});
-    issue_piece(kt, stage, std::integral_constant<int, 4>{}, std::true_type{});
+    if constexpr (NP > 4)
+      issue_piece(kt, stage, std::integral_constant<int, 4>{}, std::true_type{});
   };
 
   // ---- fragment addresses (float index from the stage base)
@@ -171,16 +186,16 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     const int sw = (l31 >> 2) & 3;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      a_off[j] = SP_W_BYTES / 4 + (wm * 64 + l31) * SP_BK + (((2 * h + j) ^ sw) << 2);
+      a_off[j] = SP_W_BYTES / 4 + (wm * 32 * RB + l31) * SP_BK + (((2 * h + j) ^ sw) << 2);
   }
   const int b_off = (wn * 2 * 3 * 64 + lane) * 4;      // + (cb*3 + piece) * 256 floats
 
-  float4 xa[2][2];          // raw fp32 A fragments of the NEXT stage to compute
+  float4 xa[RB][2];         // raw fp32 A fragments of the NEXT stage to compute
   u32x4 bp[2][3];           // pre-split W fragments
   auto read_a = [&](int stage) {
     const float* s = smem + stage * (SP_STAGE / 4);
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         xa[rb][j] = *reinterpret_cast<const float4*>(s + a_off[j] + rb * 32 * SP_BK);
@@ -193,14 +208,14 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       bp[cb][pc] = *reinterpret_cast<const u32x4*>(s + b_off + (cb * 3 + pc) * 256);
   };
 
-  f32x16 acc[4], acc2[TWO_ACC ? 4 : 1];
+  f32x16 acc[2 * RB], acc2[TWO_ACC ? 2 * RB : 1];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 2 * RB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   if (TWO_ACC) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2 * RB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
   }
@@ -209,8 +224,13 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   issue(0, 0);
   if (nks > 1) issue(1, 1);
   if (nks > 2) issue(2, 2);
-  if (nks > 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if (nks > 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if (nks > 2) {
+    if (NP == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else if (nks > 1) {
+    if (NP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_a(0);
@@ -222,10 +242,10 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   auto tile = [&](int kt, int stage, auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     const int s3 = (stage + 3) & 3, s1 = (stage + 1) & 3;
-    u32x4 ah[2], am[2], al[2];
+    u32x4 ah[RB], am[RB], al[RB];
 #ifdef EPOS_SPLIT_ABL_NOSPLIT
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float* x0 = reinterpret_cast<const float*>(&xa[rb][0]);
@@ -234,8 +254,8 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
         al[rb][j] = ah[rb][j] ^ am[rb][j];
       }
 #else
-    split8(xa[0][0], xa[0][1], ah[0], am[0], al[0]);
-    split8(xa[1][0], xa[1][1], ah[1], am[1], al[1]);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) split8(xa[rb][0], xa[rb][1], ah[rb], am[rb], al[rb]);
 #endif
     auto half = [&](auto cb_tag, auto dma_tag) {
       constexpr int cb = decltype(cb_tag)::value;
@@ -244,14 +264,14 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       f32x16* corr = TWO_ACC ? acc2 : acc;
       auto pair = [&](const u32x4* a, const u32x4& b, f32x16* c, auto n_tag) {
         constexpr int n = decltype(n_tag)::value;
-        mfma_bf16(a[0], b, c[0 * 2 + cb]);
-        mfma_bf16(a[1], b, c[1 * 2 + cb]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) mfma_bf16(a[rb], b, c[rb * 2 + cb]);
 #ifdef EPOS_SPLIT_ABL_NODMA
         constexpr bool kIssue = false;
 #else
         constexpr bool kIssue = true;
 #endif
-        if constexpr (kIssue && DMA && n < 5) {
+        if constexpr (kIssue && DMA && n < NP) {
           __builtin_amdgcn_sched_barrier(0);
           issue_piece(kt + 3, s3, std::integral_constant<int, n>{},
                       std::integral_constant<bool, MODE == 1>{});
@@ -270,8 +290,13 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       // my reads of this stage are complete (fragments are in registers); my pieces
       // of tile kt+1 have landed once at most the later tiles' pieces are outstanding
 #ifndef EPOS_SPLIT_ABL_NOBAR
-      if (MODE <= 1) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-      else if (MODE == 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      if (MODE <= 1) {
+        if (NP == 5) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      } else if (MODE == 2) {
+        if (NP == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      }
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #endif
@@ -311,7 +336,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   }
   if (TWO_ACC) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2 * RB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] += acc2[j][r];
   }
@@ -319,19 +344,19 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   // ---- epilogue --------------------------------------------------------------
   if (vec_epilogue_ok(p, HAS_RES)) {
     __syncthreads();
-    float* ws = smem + wave * 64 * EP_ROW;
-    vec_epilogue<2, 2, HAS_RES>(ws, acc, p, m0 + wm * 64, n0 + wn * 64, lane);
+    float* ws = smem + wave * 32 * RB * EP_ROW;
+    vec_epilogue<RB, 2, HAS_RES>(ws, acc, p, m0 + wm * 32 * RB, n0 + wn * 64, lane);
     return;
   }
   const bool relu = p.relu != 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + wn * 64 + j * 32 + l31;
       const int nc = n < N ? n : N - 1;
       const float bias = p.bias ? p.bias[nc] : 0.f;
-      const int mb = m0 + wm * 64 + i * 32 + 4 * h;
+      const int mb = m0 + wm * 32 * RB + i * 32 + 4 * h;
       float rv[16];
       if (HAS_RES) {
 #pragma unroll
@@ -352,18 +377,40 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     }
 }
 
-template <bool HAS_RES, bool SINGLE, bool TWO_ACC>
+template <bool HAS_RES, bool SINGLE, int RB>
 int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, TWO_ACC>;
+  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, true, RB>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS);
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              sp_lds_bytes(RB));
     attr_set = true;
   }
-  // 80 KB per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), SP_LDS, s, g);
+  // 80 / 64 KB per workgroup: at most two per CU = two MFMA waves per SIMD
+  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), sp_lds_bytes(RB), s, g);
   return launch_status("pointwise_gemm_split_f32");
+}
+
+template <int RB>
+int launch_split_rb(const EposPointwiseArgs* args, int count, hipStream_t s) {
+  GroupedArgs g = {};
+  g.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    g.p[i] = args[i];
+    g.tile_start[i] = total;
+    g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, SP_BN));
+    g.npad[i] = g.tiles_n[i] * SP_BN;
+    total += static_cast<int>(ceil_div(args[i].M, 64 * RB)) * g.tiles_n[i];
+  }
+  for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  const bool res = args[0].R != nullptr;
+  const bool single = count == 1;
+  if (res) return single ? launch_split_tt<true, true, RB>(g, total, s)
+                         : launch_split_tt<true, false, RB>(g, total, s);
+  return single ? launch_split_tt<false, true, RB>(g, total, s)
+                : launch_split_tt<false, false, RB>(g, total, s);
 }
 
 }  // namespace
@@ -388,33 +435,18 @@ bool split_eligible(const EposPointwiseArgs* args, int count) {
 }
 
 int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s) {
-  static const int two_acc = [] {
-    const char* e = getenv("EPOS_GEMM_SPLIT_ACC");
-    return e ? atoi(e) : 2;
+  // 128-row tiles when they alone give every CU two workgroups (two MFMA waves per
+  // SIMD, where the split's VALU work hides behind the other wave's MFMAs); 64-row
+  // tiles otherwise. EPOS_GEMM_SPLIT_ROWS=64|128 forces one of them (tuning).
+  static const int forced = [] {
+    const char* e = getenv("EPOS_GEMM_SPLIT_ROWS");
+    return e ? atoi(e) : 0;
   }();
-  GroupedArgs g = {};
-  g.count = count;
-  int total = 0;
-  for (int i = 0; i < count; ++i) {
-    g.p[i] = args[i];
-    g.tile_start[i] = total;
-    g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, SP_BN));
-    g.npad[i] = g.tiles_n[i] * SP_BN;
-    total += static_cast<int>(ceil_div(args[i].M, SP_BM)) * g.tiles_n[i];
-  }
-  for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
-  const bool res = args[0].R != nullptr;
-  const bool single = count == 1;
-  if (two_acc == 2) {
-    if (res) return single ? launch_split_tt<true, true, true>(g, total, s)
-                           : launch_split_tt<true, false, true>(g, total, s);
-    return single ? launch_split_tt<false, true, true>(g, total, s)
-                  : launch_split_tt<false, false, true>(g, total, s);
-  }
-  if (res) return single ? launch_split_tt<true, true, false>(g, total, s)
-                         : launch_split_tt<true, false, false>(g, total, s);
-  return single ? launch_split_tt<false, true, false>(g, total, s)
-                : launch_split_tt<false, false, false>(g, total, s);
+  int64_t tiles128 = 0;
+  for (int i = 0; i < count; ++i)
+    tiles128 += ceil_div(args[i].M, 128) * ceil_div(args[i].N, SP_BN);
+  const bool big = forced ? forced == 128 : tiles128 >= 512;
+  return big ? launch_split_rb<2>(args, count, s) : launch_split_rb<1>(args, count, s);
 }
 
 }  // namespace epos

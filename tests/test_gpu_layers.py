@@ -115,11 +115,13 @@ def _pack_split(lib, w_kn):
 
 @pytest.mark.parametrize('k', [16, 32, 48, 64, 80, 96, 112, 128, 144, 40, 92, 728])
 @pytest.mark.parametrize('m,n,aligned,res', [(128, 128, 1, 0), (130, 200, 1, 1),
-                                             (257, 132, 0, 1), (1000, 96, 1, 0)])
+                                             (257, 132, 0, 1), (1000, 96, 1, 0),
+                                             (16700, 500, 1, 1), (16450, 490, 0, 0)])
 def test_pointwise_gemm_split_ring(lib, k, m, n, aligned, res):
   """Split-operand kernel (fp32 GEMM on the bf16 matrix pipe, taken when Ws is given):
   every prologue / steady / tail path of the four-stage ring (1..46 K steps, partial
-  last step), ragged M and N tiles, the float4 and the scalar epilogue, residual +
+  last step) in both tile shapes (64 x 128 for small grids, 128 x 128 from 512 tiles
+  on: the two 16 000-row cases), ragged M and N tiles, the float4 and the scalar epilogue, residual +
   ReLU; NaNs behind every row of A poison any read past K. Tolerance as for the fp32
   kernels (the accuracy comparison proper is test_pointwise_gemm_split_accuracy)."""
   from epos_amd import _lib

@@ -14,10 +14,12 @@ VARIANTS = [[], ['-DEPOS_SPLIT_ABL_NODMA'], ['-DEPOS_SPLIT_ABL_NOBAR', '-DEPOS_S
             ['-DEPOS_SPLIT_ABL_NODMA', '-DEPOS_SPLIT_ABL_NOBAR', '-DEPOS_SPLIT_ABL_NOREAD'],
             ['-DEPOS_SPLIT_ABL_NODMA', '-DEPOS_SPLIT_ABL_NOBAR', '-DEPOS_SPLIT_ABL_NOREAD', '-DEPOS_SPLIT_ABL_NOSPLIT']]
 def path(defs):
-  return os.path.join(build.LIB_DIR, 'libepos_abl%s.so' % ''.join(d.replace('-DEPOS_SPLIT_ABL', '') for d in defs))
+  return os.path.join(build.LIB_DIR, 'libepos_abl%s.so' % ''.join(d.replace('-DEPOS_SPLIT_ABL', '').replace('-DEPOS_SPLIT', '') for d in defs))
+if os.environ.get('ABL_VARIANTS'):      # e.g. ABL_VARIANTS=';-DEPOS_SPLIT_M0SAVE;;-DEPOS_SPLIT_M0SAVE'
+  VARIANTS = [v.split() for v in os.environ['ABL_VARIANTS'].split(';')]
 if len(sys.argv) > 1 and sys.argv[1] == 'build':
   srcs = [os.path.join(build.CSRC, f) for f in ('pointwise_gemm_split.hip', 'pointwise_gemm_dma.hip', 'pointwise_gemm.hip', 'runtime.hip')]
-  for defs in VARIANTS:
+  for defs in [list(x) for x in {tuple(v) for v in VARIANTS}]:
     subprocess.check_call([build.HIPCC] + build.FLAGS + defs + ['-o', path(defs)] + srcs)
   sys.exit(0)
 import numpy as np, torch

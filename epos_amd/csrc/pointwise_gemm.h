@@ -106,9 +106,9 @@ __device__ __forceinline__ bool vec_epilogue_ok(const EposPointwiseArgs& p, bool
 }
 
 // acc: TM x TN accumulator tiles of this wave (row-tile major); the wave tile is
-// (TM*32) rows x (TN*32) columns at (m0w, n0w); `ws` = TM*32*EP_ROW floats of LDS
-// owned by this wave.
-template <int TM, int TN, bool HAS_RES>
+// (TM*32) rows x (TN*32) columns at (m0w, n0w); `ws` = TM*32*EPR floats of LDS
+// owned by this wave (EPR = TN*32 + 4 floats per staged row).
+template <int TM, int TN, bool HAS_RES, int EPR = EP_ROW>
 __device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
                                              const EposPointwiseArgs& p, int m0w,
                                              int n0w, int lane) {
@@ -140,7 +140,7 @@ __device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        ws[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EP_ROW + j * 32 + l31] =
+        ws[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * EPR + j * 32 + l31] =
             acc[i * TN + j][r] + bias;
   }
   // same wave wrote and reads: only the LDS counter has to drain
@@ -150,7 +150,7 @@ __device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
   for (int i = 0; i < NI; ++i) {
     const int row = r0 + i * RPI;
     const int m = m0w + row;
-    float4 v = *reinterpret_cast<const float4*>(ws + row * EP_ROW + c4 * 4);
+    float4 v = *reinterpret_cast<const float4*>(ws + row * EPR + c4 * 4);
     if (HAS_RES) {
       v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
     }

@@ -19,11 +19,13 @@
 // (epos_pack_pointwise_weights_split); activations stay fp32 in HBM and are split in
 // registers after the fragment read (11 VALU ops per pair of values).
 //
-// Tile 128 x 128 per 256-thread workgroup (waves 2 x 2, 64 x 64 each: 4 blocks x 2
-// accumulators), K step 16 per stage, FOUR-stage LDS-DMA ring of 20 KB (A 128 rows x
-// 64 B fp32, XOR-swizzled through the per-lane source address; W 12 KB lane-linear
-// fragments) = 80 KB, two workgroups per CU. Tile kt+3 is issued while tile kt is
-// computed; one raw s_barrier per stage as in pointwise_gemm_dma_f32.
+// Tile 128 x 128 per 256-thread workgroup, waves 4 x 1: every wave owns 32 rows and
+// all 128 columns (4 blocks x 2 accumulators), so each A value is split by exactly one
+// wave; K step 16 per stage, FOUR-stage LDS-DMA ring of 20 KB (A 128 rows x 64 B fp32,
+// XOR-swizzled through the per-lane source address; W 12 KB lane-linear fragments) =
+// 80 KB, two workgroups per CU. Small grids take 64 x 128 tiles (waves 2 x 2, 32 x 64
+// each, 64 KB ring). Tile kt+3 is issued while tile kt is computed; one raw s_barrier
+// per stage as in pointwise_gemm_dma_f32.
 #include <string.h>
 
 #include "pointwise_gemm.h"
@@ -39,11 +41,12 @@ __device__ __attribute__((aligned(16))) float g_zero_chunk_sp[4] = {0.f, 0.f, 0.
 constexpr int SP_BN = 128, SP_BK = 16;
 constexpr int SP_W_BYTES = SP_BK * SP_BN * 6;        // 12288: 4 col blocks x 3 pieces x 1 KB
 constexpr int SP_NST = 4;
-// RB = 32-row blocks per wave: RB 2 -> 128 x 128 tile (A 8 KB per stage, 80 KB ring),
-// RB 1 -> 64 x 128 tile (A 4 KB, 64 KB ring) for grids that would otherwise leave the
-// CUs with one workgroup (= one wave per SIMD) each.
-constexpr int sp_stage_bytes(int rb) { return SP_W_BYTES + 64 * rb * SP_BK * 4; }
-constexpr int sp_lds_bytes(int rb) { return SP_NST * sp_stage_bytes(rb); }
+// CB = 32-column blocks per wave: CB 4 -> waves 4 x 1, 128 x 128 tile (A 8 KB per stage,
+// 80 KB ring); CB 2 -> waves 2 x 2, 64 x 128 tile (A 4 KB, 64 KB ring) for grids that
+// would otherwise leave the CUs with one workgroup (= one wave per SIMD) each.
+constexpr int sp_stage_bytes(int cb) { return SP_W_BYTES + 32 * cb * SP_BK * 4; }
+constexpr int sp_lds_bytes(int cb) { return SP_NST * sp_stage_bytes(cb); }
+constexpr int sp_ep_row(int cb) { return cb * 32 + 4; }     // floats per staged row
 
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) {   // {b.hi, a.hi}
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
@@ -75,17 +78,19 @@ __device__ __forceinline__ void mfma_bf16(const u32x4& a, const u32x4& b, f32x16
                                               __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <bool HAS_RES, bool SINGLE, bool TWO_ACC, int RB>
+template <bool HAS_RES, bool SINGLE, bool TWO_ACC, int CB>
 __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedArgs ga_) {
-  constexpr int SP_BM = 64 * RB;
-  constexpr int SP_STAGE = sp_stage_bytes(RB);
+  constexpr int WN = 4 / CB;                 // waves along N (1 or 2); CB along M
+  constexpr int SP_BM = 32 * CB;
+  constexpr int SP_STAGE = sp_stage_bytes(CB);
+  constexpr int RB = CB / 2;                 // A pieces (16 rows) per wave and stage
   constexpr int NP = RB + 3;                 // LDS-DMA pieces per wave and stage
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
   (void)ga_;
@@ -186,19 +191,16 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     const int sw = (l31 >> 2) & 3;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      a_off[j] = SP_W_BYTES / 4 + (wm * 32 * RB + l31) * SP_BK + (((2 * h + j) ^ sw) << 2);
+      a_off[j] = SP_W_BYTES / 4 + (wm * 32 + l31) * SP_BK + (((2 * h + j) ^ sw) << 2);
   }
-  const int b_off = (wn * 2 * 3 * 64 + lane) * 4;      // + (cb*3 + piece) * 256 floats
+  const int b_off = (wn * CB * 3 * 64 + lane) * 4;     // + (cb*3 + piece) * 256 floats
 
-  float4 xa[RB][2];         // raw fp32 A fragments of the NEXT stage to compute
-  u32x4 bp[2][3];           // pre-split W fragments
+  float4 xa[2];             // raw fp32 A fragments of the NEXT stage to compute
+  u32x4 bp[CB][3];          // pre-split W fragments
   auto read_a = [&](int stage) {
     const float* s = smem + stage * (SP_STAGE / 4);
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        xa[rb][j] = *reinterpret_cast<const float4*>(s + a_off[j] + rb * 32 * SP_BK);
+    for (int j = 0; j < 2; ++j) xa[j] = *reinterpret_cast<const float4*>(s + a_off[j]);
   };
   auto read_b = [&](int stage, auto cb_tag) {
     constexpr int cb = decltype(cb_tag)::value;
@@ -208,14 +210,14 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       bp[cb][pc] = *reinterpret_cast<const u32x4*>(s + b_off + (cb * 3 + pc) * 256);
   };
 
-  f32x16 acc[2 * RB], acc2[TWO_ACC ? 2 * RB : 1];
+  f32x16 acc[CB], acc2[TWO_ACC ? CB : 1];
 #pragma unroll
-  for (int j = 0; j < 2 * RB; ++j)
+  for (int j = 0; j < CB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   if (TWO_ACC) {
 #pragma unroll
-    for (int j = 0; j < 2 * RB; ++j)
+    for (int j = 0; j < CB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
   }
@@ -236,56 +238,69 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   read_a(0);
   read_b(0, std::integral_constant<int, 0>{});
   read_b(0, std::integral_constant<int, 1>{});
+  if constexpr (CB == 4) {
+    read_b(0, std::integral_constant<int, 2>{});
+    read_b(0, std::integral_constant<int, 3>{});
+  }
 
   // MODE 0: issue tile kt+3 (full)  1: issue tile kt+3 (the last, maybe partial)
   //      2: kt+2 is the last tile   3: kt+1 is the last tile   4: last tile
   auto tile = [&](int kt, int stage, auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     const int s3 = (stage + 3) & 3, s1 = (stage + 1) & 3;
-    u32x4 ah[RB], am[RB], al[RB];
+    u32x4 ah, am, al;
 #ifdef EPOS_SPLIT_ABL_NOSPLIT
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float* x0 = reinterpret_cast<const float*>(&xa[rb][0]);
-        const float* x1 = reinterpret_cast<const float*>(&xa[rb][1]);
-        ah[rb][j] = __float_as_uint(x0[j]); am[rb][j] = __float_as_uint(x1[j]);
-        al[rb][j] = ah[rb][j] ^ am[rb][j];
-      }
+    for (int j = 0; j < 4; ++j) {
+      const float* x0 = reinterpret_cast<const float*>(&xa[0]);
+      const float* x1 = reinterpret_cast<const float*>(&xa[1]);
+      ah[j] = __float_as_uint(x0[j]); am[j] = __float_as_uint(x1[j]);
+      al[j] = ah[j] ^ am[j];
+    }
 #else
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) split8(xa[rb][0], xa[rb][1], ah[rb], am[rb], al[rb]);
+    split8(xa[0], xa[1], ah, am, al);
 #endif
-    auto half = [&](auto cb_tag, auto dma_tag) {
+    f32x16* corr = TWO_ACC ? acc2 : acc;
+    // one column block: small terms first, into the correction accumulator
+    auto block = [&](auto cb_tag, auto dma_tag) {
       constexpr int cb = decltype(cb_tag)::value;
-      constexpr bool DMA = decltype(dma_tag)::value;
+      constexpr int DMA0 = decltype(dma_tag)::value;    // first piece to issue, -1: none
       const u32x4 bh = bp[cb][0], bm = bp[cb][1], bl = bp[cb][2];
-      f32x16* corr = TWO_ACC ? acc2 : acc;
-      auto pair = [&](const u32x4* a, const u32x4& b, f32x16* c, auto n_tag) {
-        constexpr int n = decltype(n_tag)::value;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) mfma_bf16(a[rb], b, c[rb * 2 + cb]);
+      auto one = [&](const u32x4& a, const u32x4& b, f32x16& c, auto n_tag) {
+        constexpr int n = decltype(n_tag)::value;       // 0..5 within the block
+        mfma_bf16(a, b, c);
 #ifdef EPOS_SPLIT_ABL_NODMA
         constexpr bool kIssue = false;
 #else
         constexpr bool kIssue = true;
 #endif
-        if constexpr (kIssue && DMA && n < NP) {
+        // the LDS-DMA pieces of tile kt+3 go out one at a time between MFMAs: after
+        // every second MFMA of column blocks 0 and 1 (CB 4), after each of the first
+        // four MFMAs of block 0 (CB 2)
+        constexpr int piece = DMA0 < 0 ? -1 : CB == 4 ? ((n & 1) ? DMA0 + n / 2 : -1) : DMA0 + n;
+        if constexpr (kIssue && piece >= 0 && piece < NP) {
           __builtin_amdgcn_sched_barrier(0);
-          issue_piece(kt + 3, s3, std::integral_constant<int, n>{},
+          issue_piece(kt + 3, s3, std::integral_constant<int, piece>{},
                       std::integral_constant<bool, MODE == 1>{});
           __builtin_amdgcn_sched_barrier(0);
         }
       };
-      pair(al, bh, corr, std::integral_constant<int, 0>{});
-      pair(ah, bl, corr, std::integral_constant<int, 1>{});
-      pair(am, bm, corr, std::integral_constant<int, 2>{});
-      pair(am, bh, corr, std::integral_constant<int, 3>{});
-      pair(ah, bm, corr, std::integral_constant<int, 4>{});
-      pair(ah, bh, acc, std::integral_constant<int, 5>{});
+      one(al, bh, corr[cb], std::integral_constant<int, 0>{});
+      one(ah, bl, corr[cb], std::integral_constant<int, 1>{});
+      one(am, bm, corr[cb], std::integral_constant<int, 2>{});
+      one(am, bh, corr[cb], std::integral_constant<int, 3>{});
+      one(ah, bm, corr[cb], std::integral_constant<int, 4>{});
+      one(ah, bh, acc[cb], std::integral_constant<int, 5>{});
     };
-    half(std::integral_constant<int, 0>{}, std::integral_constant<bool, (MODE <= 1)>{});
+    using NoDma = std::integral_constant<int, -1>;
+    constexpr bool ISSUE = MODE <= 1;
+    // first half of the column blocks (+ the DMA pieces), barrier, second half
+    if constexpr (CB == 4) {
+      block(std::integral_constant<int, 0>{}, std::integral_constant<int, ISSUE ? 0 : -1>{});
+      block(std::integral_constant<int, 1>{}, std::integral_constant<int, ISSUE ? 3 : -1>{});
+    } else {
+      block(std::integral_constant<int, 0>{}, std::integral_constant<int, ISSUE ? 0 : -1>{});
+    }
     if constexpr (MODE != 4) {
       // my reads of this stage are complete (fragments are in registers); my pieces
       // of tile kt+1 have landed once at most the later tiles' pieces are outstanding
@@ -303,12 +318,25 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
 #ifndef EPOS_SPLIT_ABL_NOREAD
       read_a(s1);
       read_b(s1, std::integral_constant<int, 0>{});
+      if constexpr (CB == 4) read_b(s1, std::integral_constant<int, 1>{});
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
-    half(std::integral_constant<int, 1>{}, std::false_type{});
+    if constexpr (CB == 4) {
+      block(std::integral_constant<int, 2>{}, NoDma{});
+      block(std::integral_constant<int, 3>{}, NoDma{});
+    } else {
+      block(std::integral_constant<int, 1>{}, NoDma{});
+    }
 #ifndef EPOS_SPLIT_ABL_NOREAD
-    if constexpr (MODE != 4) read_b(s1, std::integral_constant<int, 1>{});
+    if constexpr (MODE != 4) {
+      if constexpr (CB == 4) {
+        read_b(s1, std::integral_constant<int, 2>{});
+        read_b(s1, std::integral_constant<int, 3>{});
+      } else {
+        read_b(s1, std::integral_constant<int, 1>{});
+      }
+    }
 #endif
   };
   {
@@ -336,7 +364,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   }
   if (TWO_ACC) {
 #pragma unroll
-    for (int j = 0; j < 2 * RB; ++j)
+    for (int j = 0; j < CB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] += acc2[j][r];
   }
@@ -344,19 +372,19 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   // ---- epilogue --------------------------------------------------------------
   if (vec_epilogue_ok(p, HAS_RES)) {
     __syncthreads();
-    float* ws = smem + wave * 32 * RB * EP_ROW;
-    vec_epilogue<RB, 2, HAS_RES>(ws, acc, p, m0 + wm * 32 * RB, n0 + wn * 64, lane);
+    float* ws = smem + wave * 32 * sp_ep_row(CB);
+    vec_epilogue<1, CB, HAS_RES, sp_ep_row(CB)>(ws, acc, p, m0 + wm * 32,
+                                                 n0 + wn * CB * 32, lane);
     return;
   }
   const bool relu = p.relu != 0;
+  constexpr int i = 0;
 #pragma unroll
-  for (int i = 0; i < RB; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < CB; ++j) {
+      const int n = n0 + wn * CB * 32 + j * 32 + l31;
       const int nc = n < N ? n : N - 1;
       const float bias = p.bias ? p.bias[nc] : 0.f;
-      const int mb = m0 + wm * 32 * RB + i * 32 + 4 * h;
+      const int mb = m0 + wm * 32 + i * 32 + 4 * h;
       float rv[16];
       if (HAS_RES) {
 #pragma unroll
@@ -369,7 +397,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
-        float v = acc[i * 2 + j][r] + bias;
+        float v = acc[i * CB + j][r] + bias;
         if (HAS_RES) v += rv[r];
         if (relu) v = fmaxf(v, 0.f);
         if (m < M && n < N) p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
@@ -377,22 +405,22 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     }
 }
 
-template <bool HAS_RES, bool SINGLE, int RB>
+template <bool HAS_RES, bool SINGLE, int CB>
 int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, true, RB>;
+  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, true, CB>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              sp_lds_bytes(RB));
+                              sp_lds_bytes(CB));
     attr_set = true;
   }
   // 80 / 64 KB per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), sp_lds_bytes(RB), s, g);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), sp_lds_bytes(CB), s, g);
   return launch_status("pointwise_gemm_split_f32");
 }
 
-template <int RB>
+template <int CB>
 int launch_split_rb(const EposPointwiseArgs* args, int count, hipStream_t s) {
   GroupedArgs g = {};
   g.count = count;
@@ -402,15 +430,15 @@ int launch_split_rb(const EposPointwiseArgs* args, int count, hipStream_t s) {
     g.tile_start[i] = total;
     g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, SP_BN));
     g.npad[i] = g.tiles_n[i] * SP_BN;
-    total += static_cast<int>(ceil_div(args[i].M, 64 * RB)) * g.tiles_n[i];
+    total += static_cast<int>(ceil_div(args[i].M, 32 * CB)) * g.tiles_n[i];
   }
   for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
   const bool res = args[0].R != nullptr;
   const bool single = count == 1;
-  if (res) return single ? launch_split_tt<true, true, RB>(g, total, s)
-                         : launch_split_tt<true, false, RB>(g, total, s);
-  return single ? launch_split_tt<false, true, RB>(g, total, s)
-                : launch_split_tt<false, false, RB>(g, total, s);
+  if (res) return single ? launch_split_tt<true, true, CB>(g, total, s)
+                         : launch_split_tt<true, false, CB>(g, total, s);
+  return single ? launch_split_tt<false, true, CB>(g, total, s)
+                : launch_split_tt<false, false, CB>(g, total, s);
 }
 
 }  // namespace
@@ -446,7 +474,7 @@ int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s
   for (int i = 0; i < count; ++i)
     tiles128 += ceil_div(args[i].M, 128) * ceil_div(args[i].N, SP_BN);
   const bool big = forced ? forced == 128 : tiles128 >= 512;
-  return big ? launch_split_rb<2>(args, count, s) : launch_split_rb<1>(args, count, s);
+  return big ? launch_split_rb<4>(args, count, s) : launch_split_rb<2>(args, count, s);
 }
 
 }  // namespace epos

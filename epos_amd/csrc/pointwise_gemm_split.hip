@@ -463,9 +463,12 @@ bool split_eligible(const EposPointwiseArgs* args, int count) {
 }
 
 int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s) {
-  // 128-row tiles when they alone give every CU two workgroups (two MFMA waves per
-  // SIMD, where the split's VALU work hides behind the other wave's MFMAs); 64-row
-  // tiles otherwise. EPOS_GEMM_SPLIT_ROWS=64|128 forces one of them (tuning).
+  // 128-row tiles (half the W traffic per MFMA, every A value split once) unless the
+  // grid would leave a fifth of the CUs without any workgroup; 64-row tiles then. With
+  // several steps in flight the other streams' workgroups fill the second slot of a CU,
+  // so the larger tile wins from ~200 tiles on (measured end to end: 303 -> 327
+  // images/s against the earlier ">= 512 tiles" rule). EPOS_GEMM_SPLIT_ROWS=64|128
+  // forces one of them (tuning).
   static const int forced = [] {
     const char* e = getenv("EPOS_GEMM_SPLIT_ROWS");
     return e ? atoi(e) : 0;
@@ -473,7 +476,7 @@ int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s
   int64_t tiles128 = 0;
   for (int i = 0; i < count; ++i)
     tiles128 += ceil_div(args[i].M, 128) * ceil_div(args[i].N, SP_BN);
-  const bool big = forced ? forced == 128 : tiles128 >= 512;
+  const bool big = forced ? forced == 128 : tiles128 >= 200;
   return big ? launch_split_rb<4>(args, count, s) : launch_split_rb<2>(args, count, s);
 }
 

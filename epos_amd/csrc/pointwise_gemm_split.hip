@@ -243,6 +243,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     read_b(0, std::integral_constant<int, 3>{});
   }
 
+  const bool live2 = n0 + 64 < N, live3 = n0 + 96 < N;     // workgroup-uniform
   // MODE 0: issue tile kt+3 (full)  1: issue tile kt+3 (the last, maybe partial)
   //      2: kt+2 is the last tile   3: kt+1 is the last tile   4: last tile
   auto tile = [&](int kt, int stage, auto mode_tag) {
@@ -323,8 +324,10 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (CB == 4) {
-      block(std::integral_constant<int, 2>{}, NoDma{});
-      block(std::integral_constant<int, 3>{}, NoDma{});
+      // column blocks entirely past N (the last tile of N = 728: one of four) are
+      // skipped: with waves 4 x 1 every wave of the workgroup saves the same MFMAs
+      if (live2) block(std::integral_constant<int, 2>{}, NoDma{});
+      if (live3) block(std::integral_constant<int, 3>{}, NoDma{});
     } else {
       block(std::integral_constant<int, 1>{}, NoDma{});
     }
@@ -405,9 +408,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     }
 }
 
-template <bool HAS_RES, bool SINGLE, int CB>
+template <bool HAS_RES, bool SINGLE, int CB, bool TWO_ACC>
 int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, true, CB>;
+  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, TWO_ACC, CB>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -435,10 +438,22 @@ int launch_split_rb(const EposPointwiseArgs* args, int count, hipStream_t s) {
   for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
   const bool res = args[0].R != nullptr;
   const bool single = count == 1;
-  if (res) return single ? launch_split_tt<true, true, CB>(g, total, s)
-                         : launch_split_tt<true, false, CB>(g, total, s);
-  return single ? launch_split_tt<false, true, CB>(g, total, s)
-                : launch_split_tt<false, false, CB>(g, total, s);
+  // EPOS_GEMM_SPLIT_ACC=1: correction terms share the main accumulator (64 registers
+  // less per wave; error = the fp32-MFMA kernel's instead of a third of it)
+  static const int nacc = [] {
+    const char* e = getenv("EPOS_GEMM_SPLIT_ACC");
+    return e ? atoi(e) : 2;
+  }();
+  if (nacc == 1) {
+    if (res) return single ? launch_split_tt<true, true, CB, false>(g, total, s)
+                           : launch_split_tt<true, false, CB, false>(g, total, s);
+    return single ? launch_split_tt<false, true, CB, false>(g, total, s)
+                  : launch_split_tt<false, false, CB, false>(g, total, s);
+  }
+  if (res) return single ? launch_split_tt<true, true, CB, true>(g, total, s)
+                         : launch_split_tt<true, false, CB, true>(g, total, s);
+  return single ? launch_split_tt<false, true, CB, true>(g, total, s)
+                : launch_split_tt<false, false, CB, true>(g, total, s);
 }
 
 }  // namespace

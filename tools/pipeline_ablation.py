@@ -54,7 +54,10 @@ def measure(drop, steps=80, inst0=0):
   return dt * 1e3
 
 base = None
-for k, drop in enumerate([(), ('dw',), ('gemm',), ('dw', 'other', 'im2col'), ()]):
+CASES = [(), ('dw',), ('gemm',), ('dw', 'other', 'im2col'), ()]
+if os.environ.get('ABL_CASES'):
+  CASES = [tuple(c.split('+')) if c else () for c in os.environ['ABL_CASES'].split(',')]
+for k, drop in enumerate(CASES):
   ms = measure(set(drop), inst0=k * DEPTH)
   base = base or ms
   print('without %-22s %.3f ms/step  (%+.3f)' % ('+'.join(drop) or '(nothing)', ms, ms - base))

@@ -243,29 +243,55 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     read_b(0, std::integral_constant<int, 3>{});
   }
 
-  const bool live2 = n0 + 64 < N, live3 = n0 + 96 < N;     // workgroup-uniform
-  // MODE 0: issue tile kt+3 (full)  1: issue tile kt+3 (the last, maybe partial)
-  //      2: kt+2 is the last tile   3: kt+1 is the last tile   4: last tile
-  auto tile = [&](int kt, int stage, auto mode_tag) {
-    constexpr int MODE = decltype(mode_tag)::value;
-    const int s3 = (stage + 3) & 3, s1 = (stage + 1) & 3;
-    u32x4 ah, am, al;
+  // bf16 pieces of this wave's A fragment for the stage being computed; the next
+  // stage's are split in the middle of the current one (between its MFMAs)
+  u32x4 ah, am, al;
+  auto split_xa = [&](u32x4& hi, u32x4& mid, u32x4& lo) {
 #ifdef EPOS_SPLIT_ABL_NOSPLIT
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float* x0 = reinterpret_cast<const float*>(&xa[0]);
       const float* x1 = reinterpret_cast<const float*>(&xa[1]);
-      ah[j] = __float_as_uint(x0[j]); am[j] = __float_as_uint(x1[j]);
-      al[j] = ah[j] ^ am[j];
+      hi[j] = __float_as_uint(x0[j]); mid[j] = __float_as_uint(x1[j]);
+      lo[j] = hi[j] ^ mid[j];
     }
 #else
-    split8(xa[0], xa[1], ah, am, al);
+    split8(xa[0], xa[1], hi, mid, lo);
 #endif
+  };
+  split_xa(ah, am, al);
+  // MODE 0: issue tile kt+3 (full)  1: issue tile kt+3 (the last, maybe partial)
+  //      2: kt+2 is the last tile   3: kt+1 is the last tile   4: last tile
+  auto tile = [&](int kt, int stage, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const int s3 = (stage + 3) & 3, s1 = (stage + 1) & 3;
     f32x16* corr = TWO_ACC ? acc2 : acc;
     // one column block: small terms first, into the correction accumulator
-    auto block = [&](auto cb_tag, auto dma_tag) {
+    // next stage's pieces, produced value by value between the MFMAs of the second half
+    u32x4 nh, nm, nl;
+    unsigned hb[8], mb[8], lb[8];
+    auto split_val = [&](auto j_tag) {
+      constexpr int j = decltype(j_tag)::value;
+      const float x = reinterpret_cast<const float*>(&xa[j >> 2])[j & 3];
+#ifdef EPOS_SPLIT_ABL_NOSPLIT
+      hb[j] = __float_as_uint(x); mb[j] = hb[j] ^ 0x3f80u; lb[j] = hb[j] ^ 0x40u;
+#else
+      hb[j] = __float_as_uint(x);
+      const float r1 = x - __uint_as_float(hb[j] & 0xffff0000u);
+      mb[j] = __float_as_uint(r1);
+      const float r2 = r1 - __uint_as_float(mb[j] & 0xffff0000u);
+      lb[j] = __float_as_uint(r2);
+#endif
+      if constexpr (j & 1) {
+        nh[j >> 1] = pack_hi16(hb[j - 1], hb[j]);
+        nm[j >> 1] = pack_hi16(mb[j - 1], mb[j]);
+        nl[j >> 1] = pack_hi16(lb[j - 1], lb[j]);
+      }
+    };
+    auto block = [&](auto cb_tag, auto dma_tag, auto slot_tag) {
       constexpr int cb = decltype(cb_tag)::value;
       constexpr int DMA0 = decltype(dma_tag)::value;    // first piece to issue, -1: none
+      constexpr int SLOT0 = decltype(slot_tag)::value;  // second half: MFMA slot of n = 0, -1: none
       const u32x4 bh = bp[cb][0], bm = bp[cb][1], bl = bp[cb][2];
       auto one = [&](const u32x4& a, const u32x4& b, f32x16& c, auto n_tag) {
         constexpr int n = decltype(n_tag)::value;       // 0..5 within the block
@@ -285,6 +311,20 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
                       std::integral_constant<bool, MODE == 1>{});
           __builtin_amdgcn_sched_barrier(0);
         }
+        // second half: the next stage's A values are split one (CB 4) or two (CB 2) per
+        // MFMA, pinned between the MFMAs (the bf16 MFMA leaves the vector ALU free);
+        // the first slots cover the LDS latency of the fragment just requested
+        if constexpr (SLOT0 >= 0 && MODE != 4) {
+          constexpr int slot = SLOT0 + n;
+          constexpr int first = CB == 4 ? slot - 2 : 2 * (slot - 1);
+          constexpr int cnt = CB == 4 ? 1 : 2;
+          if constexpr (first >= 0 && first < 8) {
+            __builtin_amdgcn_sched_barrier(0);
+            split_val(std::integral_constant<int, first>{});
+            if constexpr (cnt == 2) split_val(std::integral_constant<int, first + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       };
       one(al, bh, corr[cb], std::integral_constant<int, 0>{});
       one(ah, bl, corr[cb], std::integral_constant<int, 1>{});
@@ -297,10 +337,10 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     constexpr bool ISSUE = MODE <= 1;
     // first half of the column blocks (+ the DMA pieces), barrier, second half
     if constexpr (CB == 4) {
-      block(std::integral_constant<int, 0>{}, std::integral_constant<int, ISSUE ? 0 : -1>{});
-      block(std::integral_constant<int, 1>{}, std::integral_constant<int, ISSUE ? 3 : -1>{});
+      block(std::integral_constant<int, 0>{}, std::integral_constant<int, ISSUE ? 0 : -1>{}, NoDma{});
+      block(std::integral_constant<int, 1>{}, std::integral_constant<int, ISSUE ? 3 : -1>{}, NoDma{});
     } else {
-      block(std::integral_constant<int, 0>{}, std::integral_constant<int, ISSUE ? 0 : -1>{});
+      block(std::integral_constant<int, 0>{}, std::integral_constant<int, ISSUE ? 0 : -1>{}, NoDma{});
     }
     if constexpr (MODE != 4) {
       // my reads of this stage are complete (fragments are in registers); my pieces
@@ -324,12 +364,10 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (CB == 4) {
-      // column blocks entirely past N (the last tile of N = 728: one of four) are
-      // skipped: with waves 4 x 1 every wave of the workgroup saves the same MFMAs
-      if (live2) block(std::integral_constant<int, 2>{}, NoDma{});
-      if (live3) block(std::integral_constant<int, 3>{}, NoDma{});
+      block(std::integral_constant<int, 2>{}, NoDma{}, std::integral_constant<int, 0>{});
+      block(std::integral_constant<int, 3>{}, NoDma{}, std::integral_constant<int, 6>{});
     } else {
-      block(std::integral_constant<int, 1>{}, NoDma{});
+      block(std::integral_constant<int, 1>{}, NoDma{}, std::integral_constant<int, 0>{});
     }
 #ifndef EPOS_SPLIT_ABL_NOREAD
     if constexpr (MODE != 4) {
@@ -341,6 +379,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       }
     }
 #endif
+    if constexpr (MODE != 4) { ah = nh; am = nm; al = nl; }
   };
   {
     using M0 = std::integral_constant<int, 0>;

@@ -57,6 +57,7 @@ class Conv3x3Args(ctypes.Structure):
       ('Cin', ctypes.c_int32), ('Cout', ctypes.c_int32),
       ('stride', ctypes.c_int32), ('rate', ctypes.c_int32),
       ('relu', ctypes.c_int32),
+      ('Ws', vp),
   ]
 
 

@@ -22,7 +22,8 @@ int launch_grouped_sk(const EposPointwiseArgs* args, int count, void* workspace,
 int64_t sk_workspace_bytes();
 // pointwise_gemm_split.hip: fp32 GEMM on the bf16 matrix pipe (exact three-way operand
 // split, six piece products); every problem carries split-packed weights (p.Ws).
-int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s);
+int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s,
+                         const int* conv_cin = nullptr, const int* conv_rate = nullptr);
 bool split_eligible(const EposPointwiseArgs* args, int count);
 
 namespace {

@@ -729,7 +729,12 @@ extern "C" int epos_conv3x3_f32(const EposConv3x3Args* a, void* stream) {
   p.M = a->B * ho * wo; p.N = a->Cout; p.K = 9 * a->Cin;
   p.relu = a->relu; p.relu_in = 0; p.sub = a->stride;
   p.Ho = ho; p.Wo = wo; p.Hi = a->H; p.Wi = a->W;
+  p.Ws = a->Ws;
   const int cin = a->Cin, rate = a->rate;
+  // split-operand kernel when the split-packed weights came along (K steps of 16
+  // channels inside one tap: Cin % 32 == 0 covers it)
+  if (a->Ws && split_eligible(&p, 1))
+    return launch_grouped_split(&p, 1, static_cast<hipStream_t>(stream), &cin, &rate);
   return launch_grouped_dma(&p, 1, static_cast<hipStream_t>(stream), &cin, &rate);
 }
 

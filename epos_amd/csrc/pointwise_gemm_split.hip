@@ -78,7 +78,11 @@ __device__ __forceinline__ void mfma_bf16(const u32x4& a, const u32x4& b, f32x16
                                               __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <bool HAS_RES, bool SINGLE, bool TWO_ACC, int CB>
+// CONV: implicit GEMM of a dense 3x3 conv with Cin % 16 == 0, as in
+// pointwise_gemm_dma_f32: K step kt is channel block kt % (Cin/16) of tap kt / (Cin/16),
+// the A rows are the input pixels (y*stride + dy*rate, x*stride + dx*rate), taps outside
+// the image come from a zero block (a per-lane source select).
+template <bool HAS_RES, bool SINGLE, bool TWO_ACC, int CB, bool CONV>
 __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedArgs ga_) {
   constexpr int WN = 4 / CB;                 // waves along N (1 or 2); CB along M
   constexpr int SP_BM = 32 * CB;
@@ -117,6 +121,8 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
   const int M = p.M, N = p.N, K = p.K;
   const int nks = (K + SP_BK - 1) / SP_BK;
+  const int cblocks = CONV ? gp->conv_cin[pi] / SP_BK : 1;   // channel blocks per tap
+  const int crate = CONV ? gp->conv_rate[pi] : 1;
 
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   //      slot s of row r holds chunk s ^ ((r >> 2) & 3)
   const float* asrc[RB];
   int achunk[RB];
+  int apy[CONV ? RB : 1], apx[CONV ? RB : 1];     // CONV: pixel of the lane's row
   unsigned a_dst[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
@@ -133,7 +140,14 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     int m = m0 + r;
     m = m < M ? m : M - 1;
     int64_t row = m;
-    if (p.sub > 1) {
+    if (CONV) {                      // centre tap of output pixel m
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      apy[i] = yo * p.sub;
+      apx[i] = xo * p.sub;
+      row = (static_cast<int64_t>(b) * p.Hi + apy[i]) * p.Wi + apx[i];
+    } else if (p.sub > 1) {
       asm volatile("" ::: "memory");        // keep the divisions off the common path
       const int hw = p.Ho * p.Wo;
       const int b = m / hw, rem = m - b * hw;
@@ -159,8 +173,18 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     constexpr bool TAIL = decltype(tail_tag)::value;
     const unsigned so = static_cast<unsigned>(stage) * SP_STAGE;
     if constexpr (PIECE < RB) {
-      const float* src = asrc[PIECE] + kt * SP_BK;
-      if (TAIL) src = (kt * SP_BK + achunk[PIECE] < K) ? src : g_zero_chunk_sp;
+      const float* src;
+      if constexpr (CONV) {
+        const int tap = kt / cblocks, cb = kt - tap * cblocks;       // uniform
+        const int ky = tap / 3, dy = (ky - 1) * crate, dx = (tap - ky * 3 - 1) * crate;
+        const bool ok = static_cast<unsigned>(apy[PIECE] + dy) < static_cast<unsigned>(p.Hi) &&
+                        static_cast<unsigned>(apx[PIECE] + dx) < static_cast<unsigned>(p.Wi);
+        src = asrc[PIECE] + ((dy * p.Wi + dx) * p.lda + cb * SP_BK);
+        src = ok ? src : g_zero_chunk_sp;
+      } else {
+        src = asrc[PIECE] + kt * SP_BK;
+        if (TAIL) src = (kt * SP_BK + achunk[PIECE] < K) ? src : g_zero_chunk_sp;
+      }
 #ifdef EPOS_SPLIT_M0SAVE
       glds16_v(src, a_dst[PIECE] + so);
 #else
@@ -447,9 +471,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     }
 }
 
-template <bool HAS_RES, bool SINGLE, int CB, bool TWO_ACC>
+template <bool HAS_RES, bool SINGLE, int CB, bool TWO_ACC, bool CONV = false>
 int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, TWO_ACC, CB>;
+  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, TWO_ACC, CB, CONV>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -463,7 +487,8 @@ int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s) {
 }
 
 template <int CB>
-int launch_split_rb(const EposPointwiseArgs* args, int count, hipStream_t s) {
+int launch_split_rb(const EposPointwiseArgs* args, int count, hipStream_t s,
+                    const int* conv_cin, const int* conv_rate) {
   GroupedArgs g = {};
   g.count = count;
   int total = 0;
@@ -472,11 +497,16 @@ int launch_split_rb(const EposPointwiseArgs* args, int count, hipStream_t s) {
     g.tile_start[i] = total;
     g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, SP_BN));
     g.npad[i] = g.tiles_n[i] * SP_BN;
+    g.conv_cin[i] = conv_cin ? conv_cin[i] : 0;
+    g.conv_rate[i] = conv_rate ? conv_rate[i] : 1;
     total += static_cast<int>(ceil_div(args[i].M, 32 * CB)) * g.tiles_n[i];
   }
   for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
   const bool res = args[0].R != nullptr;
   const bool single = count == 1;
+  if (conv_cin) {                       // one problem, no residual (checked by the caller)
+    return launch_split_tt<false, true, CB, true, true>(g, total, s);
+  }
   // EPOS_GEMM_SPLIT_ACC=1: correction terms share the main accumulator (64 registers
   // less per wave; error = the fp32-MFMA kernel's instead of a third of it)
   static const int nacc = [] {
@@ -516,7 +546,8 @@ bool split_eligible(const EposPointwiseArgs* args, int count) {
   return true;
 }
 
-int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s) {
+int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s,
+                         const int* conv_cin, const int* conv_rate) {
   // 128-row tiles (half the W traffic per MFMA, every A value split once) unless the
   // grid would leave a fifth of the CUs without any workgroup; 64-row tiles then. With
   // several steps in flight the other streams' workgroups fill the second slot of a CU,
@@ -531,7 +562,12 @@ int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s
   for (int i = 0; i < count; ++i)
     tiles128 += ceil_div(args[i].M, 128) * ceil_div(args[i].N, SP_BN);
   const bool big = forced ? forced == 128 : tiles128 >= 200;
-  return big ? launch_split_rb<4>(args, count, s) : launch_split_rb<2>(args, count, s);
+  if (conv_cin && (count != 1 || args[0].R != nullptr)) {
+    set_error("launch_grouped_split: implicit conv = one problem without residual");
+    return EPOS_E_INVALID;
+  }
+  return big ? launch_split_rb<4>(args, count, s, conv_cin, conv_rate)
+             : launch_split_rb<2>(args, count, s, conv_cin, conv_rate);
 }
 
 }  // namespace epos

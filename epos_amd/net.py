@@ -226,11 +226,13 @@ class EposNet(object):
       # implicit GEMM: the LDS-DMA kernel gathers the shifted input pixels itself
       w_kn, scale, bias = self._conv_params(scope, eps)
       wp, bp, kpad = self._pack_pointwise(w_kn, scale, bias)
+      ws = self._pack_split(w_kn, scale)
       cout = w_kn.shape[1]
       y = self._empty(self.B, ho, wo, cout)
       cargs = _lib.Conv3x3Args(X=_ptr(x), ldx=cin, Wp=_ptr(wp), bias=_ptr(bp),
                                Y=_ptr(y), ldy=cout, B=self.B, H=hi, W=wi, Cin=cin,
-                               Cout=cout, stride=stride, rate=rate, relu=1)
+                               Cout=cout, stride=stride, rate=rate, relu=1,
+                               Ws=_ptr(ws))
       lib = self.lib
 
       def run_conv(stream, cargs=cargs):

@@ -130,6 +130,8 @@ typedef struct EposConv3x3Args {
   int32_t B, H, W, Cin, Cout;
   int32_t stride, rate;
   int32_t relu;
+  const void* Ws;     /* optional [device]: epos_pack_pointwise_weights_split of the same
+                       * [9*Cin][Cout] matrix (NULL = fp32-MFMA kernel) */
 } EposConv3x3Args;
 int epos_conv3x3_f32(const EposConv3x3Args* args, void* stream);
 

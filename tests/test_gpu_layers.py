@@ -275,12 +275,15 @@ def test_pointwise_stride2_shortcut(lib):
 @pytest.mark.parametrize('b,h,w,cin,cout,stride,rate', [
     (2, 12, 16, 32, 64, 1, 1), (1, 9, 21, 64, 40, 1, 1), (2, 7, 5, 32, 136, 1, 1),
     (1, 30, 44, 96, 64, 1, 1), (2, 15, 21, 64, 72, 2, 1), (1, 16, 24, 32, 64, 2, 1),
-    (1, 20, 28, 64, 130, 1, 2), (2, 13, 17, 32, 48, 1, 4)])
-def test_conv3x3_implicit_gemm(lib, b, h, w, cin, cout, stride, rate):
-  """Dense 3x3 'SAME' conv as an implicit GEMM in the LDS-DMA kernel (taps gathered
-  by the DMA, zero block outside the image) vs conv2d_same of the oracle
-  (external/slim/nets/resnet_utils.py:77-122): both tile layouts (Cout <= 64 and
-  > 64), one and several channel blocks per tap, ragged M tiles."""
+    (1, 20, 28, 64, 130, 1, 2), (2, 13, 17, 32, 48, 1, 4), (4, 60, 80, 32, 64, 1, 1)])
+@pytest.mark.parametrize('split', [0, 1])
+def test_conv3x3_implicit_gemm(lib, b, h, w, cin, cout, stride, rate, split):
+  """Dense 3x3 'SAME' conv as an implicit GEMM (taps gathered by the LDS-DMA, zero
+  block outside the image) vs conv2d_same of the oracle
+  (external/slim/nets/resnet_utils.py:77-122), through the fp32-MFMA kernel (both
+  tile layouts: Cout <= 64 and > 64) and, with the split-packed weights, through the
+  split-operand kernel (both tile shapes: the last case has >= 200 tiles); one and
+  several channel blocks per tap, ragged M tiles."""
   from epos_amd import _lib
   from oracle import net_ref
   rng = np.random.RandomState(b * h + cin)
@@ -300,9 +303,10 @@ def test_conv3x3_implicit_gemm(lib, b, h, w, cin, cout, stride, rate):
   bpad = np.zeros(npad, np.float32); bpad[:cout] = bias
   Bd = torch.from_numpy(bpad).cuda()
   Y = torch.full((b, ho, wo, cout), -3.0, device='cuda')
+  Ws = _pack_split(lib, wgt.reshape(9 * cin, cout)) if split else None
   args = _lib.Conv3x3Args(X=_p(X), ldx=cin, Wp=_p(Wp), bias=_p(Bd), Y=_p(Y), ldy=cout,
                           B=b, H=h, W=w, Cin=cin, Cout=cout, stride=stride, rate=rate,
-                          relu=1)
+                          relu=1, Ws=_p(Ws) if split else None)
   _lib.check(lib.epos_conv3x3_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)

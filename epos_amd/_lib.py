@@ -182,6 +182,11 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
+  # PyTorch's HIP runtime has to be the first one mapped into the process: loading
+  # this library (linked against /opt/rocm's libamdhip64) BEFORE torch initialises
+  # leaves the process with a runtime that reports "no ROCm-capable device" to
+  # whichever side came second (seen with build() and smoke() in one interpreter).
+  import torch  # noqa: F401
   path = lib_path()
   if not os.path.exists(path):
     raise EposError(

@@ -169,6 +169,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       static_cast<const char*>(p.Ws) + static_cast<int64_t>(tile_n) * nks * SP_W_BYTES));
 
   auto issue_piece = [&](int kt, int stage, auto piece_tag, auto tail_tag) {
+#ifdef EPOS_SPLIT_ABL_DMAHOT
+    kt = kt & 1;        // ablation: always the same two K steps (cache-hot sources)
+#endif
     constexpr int PIECE = decltype(piece_tag)::value;
     constexpr bool TAIL = decltype(tail_tag)::value;
     const unsigned so = static_cast<unsigned>(stage) * SP_STAGE;

@@ -1,17 +1,18 @@
 #!/bin/bash
 # SQ / LDS counters of ONE GEMM shape (separate --pmc passes, no trace options):
 #   bash tools/pmc_one_gemm.sh 4800 728 728 > gpurun_out/pmc_gemm.json
+#   BENCH_SPLIT=1 bash tools/pmc_one_gemm.sh 19200 728 728   (split-operand kernel)
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_one; rm -rf $OUT; mkdir -p $OUT
 i=0
 for set in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" \
-           "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU" \
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS"; do
   i=$((i+1)); mkdir -p $OUT/p$i
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python tools/bench_one_gemm.py $1 $2 $3 5 > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python tools/bench_one_gemm.py $1 $2 $3 ${PMC_ITERS:-5} > $OUT/p$i.log 2>&1
 done
 python - "$@" <<'PY'
 import csv, glob, json, sys

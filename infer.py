@@ -297,10 +297,16 @@ def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
                   if args.task_type == pipeline.LOCALIZATION else -1)
       if args.max_instances_to_fit is not None:
         num_inst = min(num_inst, args.max_instances_to_fit)
+      opencv = args.fitting_method == 'opencv_ransac'
+      if opencv:
+        # infer.py:505-528: ONE instance per object, no coverage test, score 0.0. cv2
+        # is not available; the single model comes from this build's P3P-RANSAC + local
+        # optimisation instead of cv2.solvePnPRansac(EPNP) -- parity unpinned.
+        num_inst = 1
       est, _, quals = fitting.find6DPoses(
           c['coord_2d'], c['coord_3d'], f[3], threshold=fit.threshold,
           max_tanimoto_similarity=fit.max_tanimoto_similarity,
-          max_iters=fit.max_iters, min_coverage=fit.min_coverage,
+          max_iters=fit.max_iters, min_coverage=0.0 if opencv else fit.min_coverage,
           min_triangle_area=fit.min_triangle_area, min_point_number=6,
           max_model_number=num_inst, use_prosac=args.use_prosac,
           seed=args.seed * 1000003 + f[1] * 1009 + obj_id)
@@ -309,7 +315,7 @@ def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
           poses.append({'scene_id': f[0], 'im_id': f[1], 'obj_id': obj_id,
                         'R': est[3 * i:3 * i + 3, :3],
                         't': est[3 * i:3 * i + 3, 3].reshape(3, 1),
-                        'score': float(quals[i])})
+                        'score': 0.0 if opencv else float(quals[i])})
     t_fit += time.time() - tf_
   rt = {'prediction': t1 - t0, 'establish_corr': t_corr, 'fitting': t_fit}
   rt['total'] = sum(rt.values())
@@ -326,7 +332,7 @@ def main(argv=None):
   update_flags(args, os.path.join(model_dir, PARAMS_FILENAME))  # infer.py:561-564
   if args.cpu_only:
     raise SystemExit('--cpu_only: this build has no CPU path (MI355X only).')
-  if args.fitting_method != 'progressive_x':
+  if args.fitting_method not in ('progressive_x', 'opencv_ransac'):
     raise ValueError('Unknown pose fitting method ({}).'.format(
         args.fitting_method))                                   # infer.py:530-532
   if args.vis:
@@ -398,7 +404,7 @@ def main(argv=None):
   # those runs go operator by operator (HIP network -> HIP correspondences -> host
   # sort -> HIP fitting per object) instead of through the fused device pipeline.
   operator_path = (args.max_correspondences is not None or args.use_prosac or
-                   args.project_to_surface)
+                   args.project_to_surface or args.fitting_method == 'opencv_ransac')
   if args.project_to_surface:
     # infer.py:622 prepare_for_projection: the 'eval' models of the dataset
     # (datagen.py:250-252,299-306), closest-point queries on the GPU

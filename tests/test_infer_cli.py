@@ -32,8 +32,7 @@ def test_unknown_fitting_method_raises(tmp_path, monkeypatch):
   import infer
   monkeypatch.setenv('TF_MODELS_PATH', str(tmp_path))
   with pytest.raises((ValueError, SystemExit, RuntimeError)):
-    infer.main(['--model', 'm', '--fitting_method', 'opencv_ransac',
-                '--synthetic', '1'])
+    infer.main(['--model', 'm', '--fitting_method', 'ceres', '--synthetic', '1'])
 
 
 def test_fragments_pkl_roundtrip(tmp_path):
@@ -79,6 +78,28 @@ def test_infer_operator_path_with_max_correspondences(tmp_path):
       env=env, capture_output=True, text=True, timeout=600)
   assert out.returncode == 0, out.stdout + out.stderr
   assert (tmp_path / 'toy' / 'infer' / 'estimated-poses.csv').exists()
+
+
+@pytest.mark.gpu
+def test_infer_opencv_ransac_method_gives_one_unscored_pose_per_object(tmp_path):
+  """--fitting_method=opencv_ransac (infer.py:505-528): at most one pose per
+  (image, object), score 0.0. PARITY UNPINNED: cv2 is not installable; the model
+  comes from this build's P3P-RANSAC."""
+  env = dict(os.environ, TF_MODELS_PATH=str(tmp_path))
+  (tmp_path / 'toy').mkdir()
+  (tmp_path / 'toy' / 'params.yml').write_text('infer_crop_size: "128,96"\n')
+  out = subprocess.run(
+      [sys.executable, os.path.join(ROOT, 'infer.py'), '--model=toy',
+       '--synthetic', '2', '--num_objs', '3', '--fitting_method', 'opencv_ransac'],
+      env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stdout + out.stderr
+  rows = (tmp_path / 'toy' / 'infer' / 'estimated-poses.csv').read_text().strip().split('\n')[1:]
+  seen = set()
+  for r in rows:
+    scene, im, obj, score = r.split(',')[:4]
+    assert float(score) == 0.0
+    assert (scene, im, obj) not in seen
+    seen.add((scene, im, obj))
 
 
 @pytest.mark.gpu

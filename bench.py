@@ -149,7 +149,7 @@ def gemm_roofline(pipe, steps):
         fn(s)
     evs.append(row)
   torch.cuda.synchronize()
-  total_ms, launches, flops = 0.0, 0, 0
+  total_ms, launches, flops, abytes = 0.0, 0, 0, 0
   per = {}
   for row in evs:
     for name, e0, e1 in row:
@@ -157,6 +157,7 @@ def gemm_roofline(pipe, steps):
       total_ms += ms
       launches += 1
       flops += net.op_flops[name]
+      abytes += net.op_bytes.get(name, 0)
       per.setdefault(name, []).append(ms)
   achieved = flops / (total_ms * 1e-3) / 1e12
   split = os.environ.get('EPOS_GEMM_SPLIT', '1') != '0'
@@ -184,6 +185,7 @@ def gemm_roofline(pipe, steps):
       'peak': round(peak, 1), 'unit': 'TFLOP/s',
       'frac': round(achieved / peak, 4), 'traffic': traffic,
       'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,
+      'algorithmic_bytes_per_launch': round(abytes / max(launches, 1)),
       'kernel': kernel,
       'peak_note': peak_note,
       'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),

@@ -78,6 +78,7 @@ class EposNet(object):
     self.flops = 0           # multiply-add * 2 of the whole plan
     self.op_flops = {}
     self.op_kind = {}        # 'gemm' | 'dw' | 'im2col' | 'other'
+    self.op_bytes = {}       # GEMM launches: algorithmic bytes (A + W + out + residual)
     self._graph = None
     self._graph_sparse = None
     # Workspace of the persistent stream-K GEMM (partial-sum slabs + flags); one
@@ -146,7 +147,8 @@ class EposNet(object):
     return self._dev(w9c), self._dev(bias)
 
   # --------------------------------------------------------------- ops ---
-  def _add(self, name, fn, flops=0, kind='other'):
+  def _add(self, name, fn, flops=0, kind='other', nbytes=0):
+    self.op_bytes[name] = nbytes
     self.ops.append((name, fn))
     self.flops += flops
     self.op_flops[name] = flops
@@ -168,8 +170,11 @@ class EposNet(object):
         relu_in=int(relu_in), sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi,
         Ws=_ptr(ws) if ws is not None else None)
     lib = self.lib
+    # fp32 activations in and out, weights once (4 B each: what the layer IS; the
+    # split kernel streams 6 B per weight), residual once
+    nbytes = 4 * (m * k + k * n + m * n + (m * n if res is not None else 0))
     if group is not None:
-      group.append((name, args, 2 * m * n * k))
+      group.append((name, args, 2 * m * n * k, nbytes))
       return
 
     ws = _ptr(self._gemm_ws)
@@ -177,7 +182,7 @@ class EposNet(object):
     def run(stream, args=args):
       _lib.check(lib.epos_pointwise_conv_grouped_ws_f32(ctypes.byref(args), 1, ws,
                                                         stream), name)
-    self._add(name, run, 2 * m * n * k, 'gemm')
+    self._add(name, run, 2 * m * n * k, 'gemm', nbytes)
 
   def _flush_group(self, group):
     """Launches the collected problems as one grouped GEMM (they must agree on
@@ -187,6 +192,7 @@ class EposNet(object):
     name = '+'.join(g[0] for g in group)
     arr = (_lib.PointwiseArgs * len(group))(*[g[1] for g in group])
     flops = sum(g[2] for g in group)
+    nbytes = sum(g[3] for g in group)
     lib = self.lib
     n = len(group)
 
@@ -194,7 +200,7 @@ class EposNet(object):
 
     def run(stream, arr=arr):
       _lib.check(lib.epos_pointwise_conv_grouped_ws_f32(arr, n, ws, stream), name)
-    self._add(name, run, flops, 'gemm')
+    self._add(name, run, flops, 'gemm', nbytes)
     del group[:]
 
   def _depthwise(self, name, x, ldx, hi, wi, c, stride, rate, scope, eps,
@@ -237,7 +243,8 @@ class EposNet(object):
 
       def run_conv(stream, cargs=cargs):
         _lib.check(lib.epos_conv3x3_f32(ctypes.byref(cargs), stream), name)
-      self._add(name, run_conv, 2 * self.B * ho * wo * cout * k, 'gemm')
+      self._add(name, run_conv, 2 * self.B * ho * wo * cout * k, 'gemm',
+                4 * (self.B * hi * wi * cin + k * cout + self.B * ho * wo * cout))
       return y, ho, wo, cout
     ldcol = (k + 3) // 4 * 4
     m = self.B * ho * wo

@@ -543,7 +543,7 @@ class EposNet(object):
     # Sparse-head mode (pipeline option): only the object head runs densely; the
     # fragment heads are evaluated per (image, target object) -- see
     # run_sparse_heads().
-    oname, oargs, oflops = obj_only[0]
+    oname, oargs, oflops = obj_only[0][:3]
 
     def run_obj_head(stream, args=oargs):
       _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), stream), oname)

@@ -29,8 +29,29 @@ PRED_FRAG_CONF = 'pred_frag_conf'
 PRED_FRAG_LOC = 'pred_frag_loc'
 
 
+# Arithmetic type of the restatement: fp32 as the reference (default). fp64 (same fp32
+# weights and inputs, every operation carried out in double) is the yardstick the tests
+# use to ask which of two fp32 implementations is CLOSER to the exact result.
+DTYPE = torch.float32
+
+
+class precision(object):
+  """with net_ref.precision(torch.float64): ..."""
+
+  def __init__(self, dtype):
+    self.dtype = dtype
+
+  def __enter__(self):
+    global DTYPE
+    self.prev, DTYPE = DTYPE, self.dtype
+
+  def __exit__(self, *exc):
+    global DTYPE
+    DTYPE = self.prev
+
+
 def _t(a):
-  return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+  return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DTYPE)
 
 
 # ----------------------------------------------------------------------------
@@ -378,7 +399,7 @@ def logits(images, wts, num_objs, num_frags, model_variant='xception_65',
   """model.py:461-514 (get_logits). images: float [B,H,W,3] in [0,255] (NHWC)."""
   if model_variant not in DECODER_TAP:
     raise ValueError('oracle covers xception_65 and resnet_v1_101_beta.')
-  x = torch.as_tensor(np.asarray(images), dtype=torch.float32)
+  x = torch.as_tensor(np.asarray(images), dtype=torch.float32).to(DTYPE)
   x = x.permute(0, 3, 1, 2).contiguous()
   if crop_size_wh is None:
     crop_size_wh = (x.shape[3], x.shape[2])

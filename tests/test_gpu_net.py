@@ -114,3 +114,58 @@ def test_maxpool_subsample_add_relu():
   Yt = torch.zeros(1024, device='cuda')
   _lib.check(lib.epos_add_relu_f32(p(A), p(Bt), p(Yt), 1024, None))
   assert np.array_equal(Yt.cpu().numpy(), np.maximum(a + b, 0))
+
+
+def test_split_gemm_network_is_not_less_accurate_than_fp32_mfma(tmp_path):
+  """The whole network through the split-operand GEMM (default) and through the
+  fp32-MFMA GEMM (EPOS_GEMM_SPLIT=0, read once per process: two subprocesses), both
+  against the oracle carried out in fp64 on the same fp32 weights: the split path's
+  logits are not further from the exact result than the fp32-MFMA path's."""
+  import os
+  import subprocess
+  import sys
+  from oracle import net_ref
+  from epos_amd import weights
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  h, w, num_objs = 96, 128, 2
+  script = (
+      "import sys, numpy as np, torch\n"
+      "sys.path.insert(0, %r)\n"
+      "from epos_amd import model, weights\n"
+      "ckpt = weights.random_init(num_objs=%d, seed=3, randomize_bn=True, logits_std=0.2)\n"
+      "img = np.random.RandomState(0).randint(0, 256, (1, %d, %d, 3)).astype('f')\n"
+      "mo = model.ModelOptions(model.get_outputs_to_num_channels(%d, 64))\n"
+      "net = model.get_net(ckpt, 1, %d, %d, %d, 64, mo)\n"
+      "net.forward(torch.from_numpy(img).cuda()); torch.cuda.synchronize()\n"
+      "np.savez(sys.argv[1], **{k: v.cpu().numpy() for k, v in net.logits.items()},\n"
+      "         decoder=net.decoder_out.cpu().numpy())\n" % (root, num_objs, h, w, num_objs,
+                                                           h, w, num_objs))
+  outs = {}
+  for mode in ('1', '0'):
+    path = str(tmp_path / ('logits_%s.npz' % mode))
+    r = subprocess.run([sys.executable, '-c', script, path],
+                       env=dict(os.environ, EPOS_GEMM_SPLIT=mode), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    outs[mode] = dict(np.load(path))
+  ckpt = weights.random_init(num_objs=num_objs, seed=3, randomize_bn=True, logits_std=0.2)
+  img = np.random.RandomState(0).randint(0, 256, (1, h, w, 3)).astype('f')
+  with torch.no_grad(), net_ref.precision(torch.float64):
+    ref, ep = net_ref.logits(img, ckpt, num_objs, 64)
+  exact = {k: v.permute(0, 2, 3, 1) for k, v in ref.items()}
+  # the plan's confidence buffers hold the softmaxed values (model.py:677-678)
+  exact['pred_obj_conf'] = torch.softmax(exact['pred_obj_conf'], dim=-1)
+  fc = exact['pred_frag_conf']
+  exact['pred_frag_conf'] = torch.softmax(
+      fc.reshape(fc.shape[:3] + (num_objs, 64)), dim=-1).reshape(fc.shape)
+  exact = {k: v.numpy() for k, v in exact.items()}
+  exact['decoder'] = ep['decoder/decoder_conv1'].permute(0, 2, 3, 1).numpy()
+  rms = {}
+  for mode in outs:
+    rms[mode] = {k: float(np.sqrt(np.mean((outs[mode][k].reshape(exact[k].shape)
+                                           .astype(np.float64) - exact[k]) ** 2)))
+                 for k in exact}
+  print('rms error vs the fp64 oracle: split', rms['1'], ' fp32 MFMA', rms['0'])
+  assert not np.array_equal(outs['1']['decoder'], outs['0']['decoder'])   # two kernels ran
+  for k in exact:
+    assert rms['1'][k] <= rms['0'][k] * 1.15, k

@@ -289,8 +289,12 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   split_xa(ah, am, al);
   // MODE 0: issue tile kt+3 (full)  1: issue tile kt+3 (the last, maybe partial)
   //      2: kt+2 is the last tile   3: kt+1 is the last tile   4: last tile
-  auto tile = [&](int kt, int stage, auto mode_tag) {
+  // LIVE: column blocks of this wave that hold any column < N (CB, or CB - 1 for the
+  // last column tile of e.g. N = 728 with CB 4: with waves 4 x 1 every wave of the
+  // workgroup then skips the same quarter of its MFMAs)
+  auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
+    constexpr int LIVE = decltype(live_tag)::value;
     const int s3 = (stage + 3) & 3, s1 = (stage + 1) & 3;
     f32x16* corr = TWO_ACC ? acc2 : acc;
     // one column block: small terms first, into the correction accumulator
@@ -343,8 +347,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
         // the first slots cover the LDS latency of the fragment just requested
         if constexpr (SLOT0 >= 0 && MODE != 4) {
           constexpr int slot = SLOT0 + n;
-          constexpr int first = CB == 4 ? slot - 2 : 2 * (slot - 1);
-          constexpr int cnt = CB == 4 ? 1 : 2;
+          constexpr bool kOnePerSlot = CB == 4 && LIVE == 4;     // 12 MFMAs, else 6
+          constexpr int first = kOnePerSlot ? slot - 2 : 2 * (slot - 1);
+          constexpr int cnt = kOnePerSlot ? 1 : 2;
           if constexpr (first >= 0 && first < 8) {
             __builtin_amdgcn_sched_barrier(0);
             split_val(std::integral_constant<int, first>{});
@@ -392,7 +397,8 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     }
     if constexpr (CB == 4) {
       block(std::integral_constant<int, 2>{}, NoDma{}, std::integral_constant<int, 0>{});
-      block(std::integral_constant<int, 3>{}, NoDma{}, std::integral_constant<int, 6>{});
+      if constexpr (LIVE == 4)
+        block(std::integral_constant<int, 3>{}, NoDma{}, std::integral_constant<int, 6>{});
     } else {
       block(std::integral_constant<int, 1>{}, NoDma{}, std::integral_constant<int, 0>{});
     }
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     if constexpr (MODE != 4) {
       if constexpr (CB == 4) {
         read_b(s1, std::integral_constant<int, 2>{});
-        read_b(s1, std::integral_constant<int, 3>{});
+        if constexpr (LIVE == 4) read_b(s1, std::integral_constant<int, 3>{});
       } else {
         read_b(s1, std::integral_constant<int, 1>{});
       }
@@ -408,7 +414,8 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
 #endif
     if constexpr (MODE != 4) { ah = nh; am = nm; al = nl; }
   };
-  {
+  auto k_loop = [&](auto live_tag) {
+    using LV = decltype(live_tag);
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
@@ -416,21 +423,23 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     using M4 = std::integral_constant<int, 4>;
     int kt = 0;
     for (; kt + 7 < nks; kt += 4) {        // every LDS offset an immediate
-      tile(kt, 0, M0{});
-      tile(kt + 1, 1, M0{});
-      tile(kt + 2, 2, M0{});
-      tile(kt + 3, 3, M0{});
+      tile(kt, 0, M0{}, LV{});
+      tile(kt + 1, 1, M0{}, LV{});
+      tile(kt + 2, 2, M0{}, LV{});
+      tile(kt + 3, 3, M0{}, LV{});
     }
     int stage = 0;                          // kt is a multiple of 4 here
     for (; kt + 4 < nks; ++kt) {
-      tile(kt, stage, M0{});
+      tile(kt, stage, M0{}, LV{});
       stage = (stage + 1) & 3;
     }
-    if (kt + 4 == nks) { tile(kt, stage, M1{}); stage = (stage + 1) & 3; ++kt; }
-    if (kt + 3 == nks) { tile(kt, stage, M2{}); stage = (stage + 1) & 3; ++kt; }
-    if (kt + 2 == nks) { tile(kt, stage, M3{}); stage = (stage + 1) & 3; ++kt; }
-    tile(kt, stage, M4{});
-  }
+    if (kt + 4 == nks) { tile(kt, stage, M1{}, LV{}); stage = (stage + 1) & 3; ++kt; }
+    if (kt + 3 == nks) { tile(kt, stage, M2{}, LV{}); stage = (stage + 1) & 3; ++kt; }
+    if (kt + 2 == nks) { tile(kt, stage, M3{}, LV{}); stage = (stage + 1) & 3; ++kt; }
+    tile(kt, stage, M4{}, LV{});
+  };
+  if (CB == 4 && n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{});   // uniform
+  else k_loop(std::integral_constant<int, CB>{});
   if (TWO_ACC) {
 #pragma unroll
     for (int j = 0; j < CB; ++j)

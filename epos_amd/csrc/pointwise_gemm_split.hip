@@ -116,10 +116,27 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   }
   const EposPointwiseArgs p = gp->p[pi];
   const int tiles_n = gp->tiles_n[pi];
-  const int tile_n = bid % tiles_n;
-  const int tile_m = bid / tiles_n;
-  const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
   const int M = p.M, N = p.N, K = p.K;
+  // Tile order inside an XCD's range: column fastest, but for wide problems (more than 8
+  // column tiles: the 4032- and 1344-channel heads, N = 1536 / 2048) in bands of 8 column
+  // tiles with all row tiles of a band before the next band, so that the workgroups in
+  // flight on an XCD share 8 tiles' weights (K = 256: 1.5 MB, L2-resident) instead of
+  // sweeping all of them (6 MB for the 4032-channel head) once per row tile.
+  int tile_m, tile_n;
+  if (tiles_n <= 8) {
+    tile_n = bid % tiles_n;
+    tile_m = bid / tiles_n;
+  } else {
+    const int tiles_m = (M + SP_BM - 1) / SP_BM;
+    const int per_band = tiles_m * 8;
+    const int band = bid / per_band;
+    const int rem = bid - band * per_band;
+    const int left = tiles_n - band * 8;
+    const int bw = left < 8 ? left : 8;
+    tile_m = rem / bw;
+    tile_n = band * 8 + (rem - tile_m * bw);
+  }
+  const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
   const int nks = (K + SP_BK - 1) / SP_BK;
   const int cblocks = CONV ? gp->conv_cin[pi] / SP_BK : 1;   // channel blocks per tap
   const int crate = CONV ? gp->conv_rate[pi] : 1;

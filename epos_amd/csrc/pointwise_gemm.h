@@ -74,13 +74,34 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const float* sbase,
 
 // The same without saving M0 (nothing else in these kernels reads it).
 __device__ __forceinline__ void glds16_v_m0(const float* gsrc, unsigned lds_dst) {
+#ifdef EPOS_SPLIT_ABL_SAMEM0      // ablation: no M0 write (every piece lands on one spot)
+  asm volatile("global_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+#else
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
+#endif
 }
 __device__ __forceinline__ void glds16_s_m0(unsigned voff, const float* sbase,
                                             unsigned lds_dst) {
+#ifdef EPOS_SPLIT_ABL_SAMEM0
+  asm volatile("global_load_lds_dwordx4 %0, %2"
+               : : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory", "m0");
+#else
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
                : : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory", "m0");
+#endif
+}
+// LDS-DMA with an instruction offset: the immediate is added to the global address AND to
+// the LDS address (LDS_ADDR = M0 + inst_offset + lane * 16), so pieces that are 1 KB apart
+// in LDS share one M0 write when the source pointer is moved back by the same amount.
+template <int OFF>
+__device__ __forceinline__ void glds16_v_off(const float* gsrc) {
+  asm volatile("global_load_lds_dwordx4 %0, off offset:%1" : : "v"(gsrc), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void glds16_s_off(unsigned voff, const float* sbase) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2"
+               : : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f),

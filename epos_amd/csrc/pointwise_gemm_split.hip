@@ -205,18 +205,21 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
         src = asrc[PIECE] + kt * SP_BK;
         if (TAIL) src = (kt * SP_BK + achunk[PIECE] < K) ? src : g_zero_chunk_sp;
       }
-#ifdef EPOS_SPLIT_M0SAVE
-      glds16_v(src, a_dst[PIECE] + so);
-#else
+      // pieces of one kind are 1 KB apart in LDS: one M0 write for the first, the
+      // instruction offset (added to both addresses) for the others
+#ifdef EPOS_SPLIT_M0_EACH
       glds16_v_m0(src, a_dst[PIECE] + so);
+#else
+      if constexpr (PIECE == 0) glds16_v_m0(src, a_dst[0] + so);
+      else glds16_v_off<PIECE * 1024>(src - PIECE * 256);
 #endif
     } else {
-#ifdef EPOS_SPLIT_M0SAVE
-      glds16_s(wvoff[PIECE - RB], wsb + static_cast<int64_t>(kt) * (SP_W_BYTES / 4),
-               w_dst[PIECE - RB] + so);
+      const float* wb = wsb + static_cast<int64_t>(kt) * (SP_W_BYTES / 4);
+#ifdef EPOS_SPLIT_M0_EACH
+      glds16_s_m0(wvoff[PIECE - RB], wb, w_dst[PIECE - RB] + so);
 #else
-      glds16_s_m0(wvoff[PIECE - RB], wsb + static_cast<int64_t>(kt) * (SP_W_BYTES / 4),
-               w_dst[PIECE - RB] + so);
+      if constexpr (PIECE == RB) glds16_s_m0(wvoff[0], wb, w_dst[0] + so);
+      else glds16_s_off<(PIECE - RB) * 1024>(wvoff[0], wb);
 #endif
     }
   };

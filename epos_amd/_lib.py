@@ -198,7 +198,7 @@ def load():
     fn.restype = restype
     if argtypes is not None:
       fn.argtypes = argtypes
-  if lib.epos_abi_version() != 1:
+  if lib.epos_abi_version() != 2:
     raise EposError('libepos_hip.so ABI version mismatch')
   _lib = lib
   return lib

@@ -33,7 +33,7 @@ extern "C" {
 #define EPOS_E_NODEVICE (-3)  /* no HIP device available */
 #define EPOS_E_HIP_BASE (-1000)
 
-#define EPOS_ABI_VERSION 1
+#define EPOS_ABI_VERSION 2   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing */
 
 int epos_abi_version(void);
 const char* epos_last_error(void);

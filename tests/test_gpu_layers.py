@@ -503,3 +503,43 @@ def test_clock_probe_reports_a_plausible_core_clock(lib):
   assert 19000 <= ticks <= 40000                    # ~200 us of the 100 MHz counter
   mhz = cyc / ticks * 100.0
   assert 500.0 < mhz < 3000.0, mhz
+
+
+@pytest.mark.parametrize('env', [{'EPOS_GEMM_SPLIT': '0'}, {'EPOS_GEMM_SPLIT_ACC': '1'},
+                                 {'EPOS_GEMM_SPLIT_ROWS': '64'},
+                                 {'EPOS_GEMM_SPLIT_ROWS': '128'}])
+def test_pointwise_gemm_split_switches(env):
+  """The process-wide switches of the split-operand GEMM (read once per process, hence a
+  subprocess each): fp32-MFMA kernel instead, one accumulator, forced tile height -- all
+  must give the same result within the fp32 tolerance."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = r'''
+import ctypes, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from epos_amd import _lib
+lib = _lib.load()
+def p(t): return ctypes.c_void_p(t.data_ptr())
+rng = np.random.RandomState(5)
+for (m, k, n) in [(700, 728, 200), (16500, 80, 520)]:
+  a = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  tot = lib.epos_pack_pointwise_weights(None, k, n, None); d = np.empty(tot, np.float32)
+  lib.epos_pack_pointwise_weights(w.ctypes.data_as(ctypes.c_void_p), k, n, d.ctypes.data_as(ctypes.c_void_p))
+  tot = lib.epos_pack_pointwise_weights_split(None, k, n, None); d8 = np.empty(tot, np.uint8)
+  lib.epos_pack_pointwise_weights_split(w.ctypes.data_as(ctypes.c_void_p), k, n, d8.ctypes.data_as(ctypes.c_void_p))
+  A, Wp, Ws = torch.from_numpy(a).cuda(), torch.from_numpy(d).cuda(), torch.from_numpy(d8).cuda()
+  C = torch.zeros(m, n, device='cuda')
+  args = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Wp), bias=None, R=None, ldr=0, C=p(C), ldc=n,
+                            M=m, N=n, K=k, relu=0, relu_in=0, sub=1, Ws=p(Ws))
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  torch.cuda.synchronize()
+  ref = a.astype(np.float64) @ w.astype(np.float64)
+  np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+print('ok')
+''' % root
+  r = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, **env),
+                     capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr

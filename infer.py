@@ -107,6 +107,9 @@ def build_parser():
     help='object channels (default: from the checkpoint)')
   a('--batch', type=int, default=1, help='images per GPU per step')
   a('--seed', type=int, default=0)
+  a('--pipeline_depth', type=int, default=1,
+    help='batches in flight (independent plans on their own HIP streams); 1 = one '
+         'image at a time with per-stage times like the reference, >1 = throughput')
   return ap
 
 
@@ -416,30 +419,20 @@ def main(argv=None):
                                    obj_ids=store.dp_model['obj_ids'])
   B = args.batch
   max_inst = args.max_instances_to_fit or 4
-  pipe = pipeline.EposPipeline(
+  depth = max(1, args.pipeline_depth)
+  if operator_path or args.save_corresp:
+    depth = 1                      # those paths read the plan's buffers after the step
+  pipes = [pipeline.EposPipeline(
       ckpt, B, h, w, num_objs, args.num_frags, store, fit_params=fit,
       corr_min_obj_conf=args.corr_min_obj_conf,
       corr_min_frag_rel_conf=args.corr_min_frag_rel_conf,
-      max_instances=max_inst, model_options=mo, device=dev)
+      max_instances=max_inst, model_options=mo, device=dev, instance=j)
+           for j in range(depth)]
+  pipe = pipes[0]
 
   poses_all, time_start = [], time.time()
-  for i0 in range(0, len(frames), B):
-    chunk = frames[i0:i0 + B]
-    while len(chunk) < B:                      # pad the last batch
-      chunk = chunk + [chunk[-1]]
-    imgs = torch.from_numpy(np.stack([f[2] for f in chunk])).to(dev)
-    Ks = np.stack([f[3] for f in chunk])
-    tg = [f[4] for f in chunk]
-    if args.max_instances_to_fit is not None:  # infer.py:467-468
-      tg = [{o: min(c, args.max_instances_to_fit) for o, c in t.items()}
-            for t in tg]
-    if operator_path:
-      poses, rt = process_by_operators(pipe, store, imgs, chunk, tg, args, fit)
-    else:
-      poses, rt = pipe.process_batch(
-          imgs, Ks, tg, task_type=args.task_type,
-          image_ids=[f[1] for f in chunk], scene_ids=[f[0] for f in chunk],
-          seed=args.seed, timing=True)
+
+  def finish(i0, chunk, poses, rt):
     n_real = len(frames[i0:i0 + B])
     real_ids = set((f[0], f[1]) for f in frames[i0:i0 + n_real])
     seen = set()
@@ -464,6 +457,33 @@ def main(argv=None):
             '{:.3f}, total time: {:.3f}'.format(
                 i0, rt.get('prediction', 0), rt.get('establish_corr', 0),
                 rt.get('fitting', 0), rt.get('total', 0)))
+
+  inflight = []                                 # (pipeline, i0, chunk), oldest first
+  for step, i0 in enumerate(range(0, len(frames), B)):
+    chunk = frames[i0:i0 + B]
+    while len(chunk) < B:                      # pad the last batch
+      chunk = chunk + [chunk[-1]]
+    imgs = torch.from_numpy(np.stack([f[2] for f in chunk])).to(dev)
+    Ks = np.stack([f[3] for f in chunk])
+    tg = [f[4] for f in chunk]
+    if args.max_instances_to_fit is not None:  # infer.py:467-468
+      tg = [{o: min(c, args.max_instances_to_fit) for o, c in t.items()}
+            for t in tg]
+    if operator_path:
+      poses, rt = process_by_operators(pipe, store, imgs, chunk, tg, args, fit)
+      finish(i0, chunk, poses, rt)
+      continue
+    if len(inflight) == depth:
+      q, j0, ch = inflight.pop(0)
+      finish(j0, ch, *q.collect())
+    p = pipes[step % depth]
+    p.launch(imgs, Ks, tg, task_type=args.task_type,
+             image_ids=[f[1] for f in chunk], scene_ids=[f[0] for f in chunk],
+             seed=args.seed, timing=True)
+    inflight.append((p, i0, chunk))
+  while inflight:
+    q, j0, ch = inflight.pop(0)
+    finish(j0, ch, *q.collect())
   # First-image time := mean time of the others (infer.py:741-749).
   if len(poses_all) > 1 and frames:
     first = (frames[0][0], frames[0][1])

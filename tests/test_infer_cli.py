@@ -103,6 +103,26 @@ def test_infer_opencv_ransac_method_gives_one_unscored_pose_per_object(tmp_path)
 
 
 @pytest.mark.gpu
+def test_infer_pipeline_depth_gives_the_same_poses(tmp_path):
+  """--pipeline_depth 3 (three batches in flight on their own streams) writes the same
+  rows as the serial run, up to the time column."""
+  rows = {}
+  for depth in (1, 3):
+    d = tmp_path / ('d%d' % depth)
+    (d / 'toy').mkdir(parents=True)
+    (d / 'toy' / 'params.yml').write_text('infer_crop_size: "128,96"\n')
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'infer.py'), '--model=toy', '--synthetic', '7',
+         '--num_objs', '3', '--pipeline_depth', str(depth)],
+        env=dict(os.environ, TF_MODELS_PATH=str(d)), capture_output=True, text=True,
+        timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = (d / 'toy' / 'infer' / 'estimated-poses.csv').read_text().strip().split('\n')
+    rows[depth] = [','.join(r.split(',')[:-1]) for r in txt]
+  assert len(rows[1]) > 1 and rows[1] == rows[3]
+
+
+@pytest.mark.gpu
 def test_infer_from_tfrecord(tmp_path):
   """--infer_tfrecord_names path: records written with the build's own encoder
   (the reference writes them with TensorFlow, scripts/create_tfrecord.py)."""

@@ -6,10 +6,13 @@ extraction + PnP-RANSAC), BASELINE.json's metric, on synthetic 640x480 frames.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one batch (default: 1 image per GPU =
-BASELINE config C2, "YCB-V, xc65, batch=1 on 1 MI355X": 21 objects, 64 fragments,
-5 target objects per image) with the image tensor already resident in HBM and the
-pose records on the host at the end of the step. Weights are random-init with the
+One step = one pass of the hot path over one batch with the image tensor already
+resident in HBM and the pose records on the host at the end of the step. Default
+batch: N = 1 -> 1 image = BASELINE config C2 ("YCB-V, xc65, batch=1 on 1 MI355X": 21
+objects, 64 fragments, 5 target objects per image); N > 1 -> 4 images per GPU = the
+per-GPU shard of config C3 ("batch=32 sharded across 8 MI355X"; weak scaling: the
+shard stays 4 images at N = 2 and 4 too). The ranks exchange nothing per step; their
+pose records are gathered once (RCCL all_gather) before the timed region closes. Weights are random-init with the
 reference's initialisers (no network access for the released checkpoints).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
@@ -56,7 +59,9 @@ def parse_args():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
-  ap.add_argument('--batch-per-gpu', type=int, default=1)
+  ap.add_argument('--batch-per-gpu', type=int, default=None,
+                  help='images per GPU per step; default 1 at --gpus 1 (config C2), 4 '
+                       'at --gpus > 1 (the per-GPU shard of config C3: 32 images / 8)')
   ap.add_argument('--height', type=int, default=480)
   ap.add_argument('--width', type=int, default=640)
   ap.add_argument('--num-objs', type=int, default=21)
@@ -80,7 +85,12 @@ def parse_args():
                        'heads as model.predict defines them')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-roofline', action='store_true')
-  ap.add_argument('--cpu-baseline-images', type=int, default=1)
+  ap.add_argument('--cpu-baseline-images', type=int, default=8,
+                  help='frames of the same workload the CPU oracle is timed on '
+                       '(~1.6 s each on 10 threads: a bounded 10-30 s sample)')
+  ap.add_argument('--no-stage-times', action='store_true',
+                  help='skip the serial (depth 1) steps with per-stage HIP events that '
+                       'follow the timed region')
   return ap.parse_args()
 
 
@@ -164,9 +174,9 @@ def gemm_roofline(pipe, steps):
   if split:
     kernel, peak = 'pointwise_gemm_split_f32', SPLIT_PEAK_TFLOPS
     peak_note = ('algorithmic fp32 flops against the bf16 dense MFMA peak (2516.6) / 6: the '
-                 'kernel forms every fp32 product exactly from six bf16 piece products '
-                 '(fp32 in, fp32 out, error below the fp32 MFMA kernel\'s); the fp32-MFMA '
-                 'roof of the same work is 157.3')
+                 'kernel forms every fp32 product from six bf16 piece products of exact '
+                 'three-way operand splits (fp32-equivalent: fp32 in, fp32 out, error below '
+                 'the fp32 MFMA kernel\'s); the fp32-MFMA roof of the same work is 157.3')
   else:
     kernel, peak = 'pointwise_gemm_dma_f32', FP32_MFMA_PEAK_TFLOPS
     peak_note = 'dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'
@@ -175,16 +185,22 @@ def gemm_roofline(pipe, steps):
   # run inside this process; the committed summary of the last collection is
   # reported here (profiles/r01/gemm_hbm_traffic_pmc.json).
   traffic, traffic_src = None, None
-  tpath = os.path.join(ROOT, 'profiles', 'r01', 'gemm_hbm_traffic_pmc.json')
-  if os.path.exists(tpath):
-    with open(tpath) as f:
-      traffic = round(json.load(f)['traffic_bytes_per_launch'])
-    traffic_src = 'profiles/r01/gemm_hbm_traffic_pmc.json (rocprofv3 --pmc)'
+  for rnd in ('r02', 'r01'):
+    tpath = os.path.join(ROOT, 'profiles', rnd, 'gemm_hbm_traffic_pmc.json')
+    if os.path.exists(tpath):
+      with open(tpath) as f:
+        traffic = round(json.load(f)['traffic_bytes_per_launch'])
+      traffic_src = ('STATIC, not measured in this run: profiles/%s/gemm_hbm_traffic_'
+                     'pmc.json (rocprofv3 --pmc passes of tools/profile_round.sh on the '
+                     'same plan; PMC counters cannot be read from inside the process)'
+                     % rnd)
+      break
   return {
       'bound': 'mfma', 'achieved': round(achieved, 2),
       'peak': round(peak, 1), 'unit': 'TFLOP/s',
       'frac': round(achieved / peak, 4), 'traffic': traffic,
       'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,
+      'traffic_measured_in_run': False,
       'algorithmic_bytes_per_launch': round(abytes / max(launches, 1)),
       'kernel': kernel,
       'peak_note': peak_note,
@@ -210,6 +226,8 @@ def main():
   dev_index = int(os.environ.get('EPOS_FORCE_DEVICE', local_rank))
   torch.cuda.set_device(dev_index)
   dev = 'cuda:%d' % dev_index
+  if args.batch_per_gpu is None:
+    args.batch_per_gpu = 1 if world == 1 else 4
   B = args.batch_per_gpu
   # Random-init weights with the reference's initialisers; BatchNorm statistics
   # are randomised so that activations keep an O(0.1..1) scale through the 65
@@ -249,25 +267,24 @@ def main():
     tg = [synthetic.targets(i, args.num_objs, args.objs_per_image) for i in idx]
     pool.append((torch.from_numpy(imgs).to(dev), tg, idx))
   Ks = np.tile(synthetic.YCBV_K, (B, 1, 1))
-  max_records = B * args.objs_per_image * 2
   lib = _lib.load()
   clk = torch.zeros((64, 2), dtype=torch.int64, device=dev)
   clk_stream = None      # created after the timed region (an extra stream changes
                          # the stream -> hardware-queue mapping of the pipelines)
 
-  def finish(p):
-    poses, _ = p.collect()
-    return len(edist.gather_poses(poses, max_records))
-
-  def run(first, count, probe=False):
+  def run(first, count, probe=False, use=None):
     """`count` steps; step i is launched on pipes[i % depth] after the step that
-    used that pipeline `depth` steps earlier has been collected. Returns the
-    number of poses; every step is complete (poses on the host) on return."""
-    n, inflight = 0, []
+    used that pipeline `depth` steps earlier has been collected. Every step is
+    complete (its poses on this rank's host) on return; the ranks' records are then
+    gathered ONCE (dist.gather_poses: one all_gather over RCCL) -- images are
+    independent, so nothing is exchanged per step. Returns the merged pose list."""
+    ps = use or pipes
+    d = len(ps)
+    local, inflight = [], []
     for i in range(first, first + count):
-      p = pipes[i % depth]
-      if len(inflight) == depth:
-        n += finish(inflight.pop(0))
+      p = ps[i % d]
+      if len(inflight) == d:
+        local += inflight.pop(0).collect()[0]
       imgs, tg, idx = pool[i % n_pool]
       p.launch(imgs, Ks, tg, image_ids=idx, seed=i)
       inflight.append(p)
@@ -276,8 +293,10 @@ def main():
             ctypes.c_void_p(clk[i % clk.shape[0]].data_ptr()), 200,
             ctypes.c_void_p(clk_stream.cuda_stream)), 'clock_probe')
     while inflight:
-      n += finish(inflight.pop(0))
-    return n
+      local += inflight.pop(0).collect()[0]
+    # rank-independent record capacity: every target object of every image of the
+    # `count` steps, two instances each
+    return edist.gather_poses(local, max(1, count * B * args.objs_per_image * 2))
 
   # Set-up, not a step: every plan captures its hipGraph on first use, so each of the
   # `depth` plans is exercised once here (otherwise plans beyond the warm-up count
@@ -291,7 +310,7 @@ def main():
   torch.cuda.synchronize()
   edist.barrier()
   t0 = time.perf_counter()
-  n_poses = run(args.warmup, args.steps)
+  n_poses = len(run(args.warmup, args.steps)) / max(world, 1)
   torch.cuda.synchronize()
   edist.barrier()
   elapsed = edist.max_over_ranks(time.perf_counter() - t0)
@@ -308,7 +327,10 @@ def main():
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
       'config': {
-          'workload': 'C2: synthetic 640x480 RGB, %s random-init ' % args.model_variant +
+          'workload': ('C2' if B == 1 else 'C3 per-GPU shard (batch %d per GPU)' % B if
+                       B == 4 else 'batch %d per GPU' % B) +
+                      ': synthetic %dx%d RGB, %s random-init ' % (
+                          args.width, args.height, args.model_variant) +
                       '(reference initialisers, randomised BN statistics, logits '
                       'layers %s), %d objects x %d fragments, %d target '
                       'objects/image, batch %d per GPU, dense heads + corr + '
@@ -317,16 +339,21 @@ def main():
                           'masked pixels per object', args.num_objs,
                           args.num_frags, args.objs_per_image, B),
           'arithmetic': ('fp32 activations / weights / accumulators everywhere, as the '
-                         'reference; 1x1-conv GEMMs: every fp32 product formed exactly '
-                         'from three-way bf16 splits of both operands (six bf16 MFMA '
-                         'piece products, fp32 accumulate), measured error vs fp64 below '
-                         'the fp32-MFMA kernel (EPOS_GEMM_SPLIT=0 selects that kernel)'
+                         'reference; 1x1-conv GEMMs: fp32-equivalent products from exact '
+                         'three-way bf16 splits of both operands (six of the nine bf16 '
+                         'piece products, fp32 accumulate; the three dropped terms are '
+                         'below 2^-23 of the product), measured error vs fp64 below the '
+                         'fp32-MFMA kernel (EPOS_GEMM_SPLIT=0 selects that kernel)'
                          if os.environ.get('EPOS_GEMM_SPLIT', '1') != '0' else
                          'fp32 everywhere, GEMMs on v_mfma_f32_32x32x2_f32'),
           'height': args.height, 'width': args.width,
           'batch_per_gpu': B, 'global_batch': B * world,
-          'parallelism': 'dp%d (images sharded, one all_gather of pose records)'
-                         % world,
+          'parallelism': 'dp%d (images sharded, one all_gather of pose records per '
+                         'timed region)' % world,
+          'dist_backend': (torch.distributed.get_backend()
+                           if torch.distributed.is_initialized() else None),
+          'rccl_ranks_seen': (torch.distributed.get_world_size()
+                              if torch.distributed.is_initialized() else 1),
           'hip_graph': not args.no_graph, 'pipeline_depth': depth,
           'heads': 'sparse (target objects only)' if args.sparse_heads else 'dense',
           'corr_per_slot_last_step': [int(x) for x in totals[:, 1]],
@@ -342,8 +369,47 @@ def main():
   clk_h = clk.cpu().numpy()
   clk_h = clk_h[clk_h[:, 1] > 0]
   core_mhz = float((clk_h[:, 0] / clk_h[:, 1]).mean() * 100.0) if len(clk_h) else None
+  # Strictly serial steps (ONE plan, depth 1: C2's "batch = 1" read as latency) and the
+  # per-stage HIP-event split of such a step (the reference prints the same three
+  # stages per image, scripts/infer.py:730-734). Every rank runs them (run() gathers).
+  serial = None
+  if not args.no_stage_times:
+    k = max(3, min(args.steps, 10))
+    run(0, 2, use=[pipes[0]])
+    torch.cuda.synchronize()
+    edist.barrier()
+    t1 = time.perf_counter()
+    run(2, k, use=[pipes[0]])
+    torch.cuda.synchronize()
+    dt = edist.max_over_ranks(time.perf_counter() - t1)
+    stage = {}
+    for i in range(k):
+      imgs, tg, idx = pool[i % n_pool]
+      _, rt = pipes[0].process_batch(imgs, Ks, tg, image_ids=idx, seed=i, timing=True)
+      for name, v in rt.items():
+        stage[name] = stage.get(name, 0.0) + v * 1e3 / k
+    serial = {'images_per_sec': round(k * B * world / dt, 2),
+              'ms_per_step': round(dt / k * 1e3, 3), 'steps': k,
+              'stage_ms': {n: round(v, 3) for n, v in stage.items()},
+              'note': 'pipeline depth 1: one step at a time on one plan; stage_ms = HIP '
+                      'events around network / correspondences / PnP-RANSAC of such a '
+                      'step (prediction, establish_corr, fitting as scripts/infer.py:'
+                      '730-734 prints them)'}
+    result['serial_depth1'] = serial
   if rank == 0 and not args.no_roofline:
     roof, _ = gemm_roofline(pipe, max(2, min(args.steps, 5)))
+    # The HBM view north_star names: images/s x algorithmic bytes per image against
+    # the 8 TB/s spec (3.30 GB per 640x480 image at 21 objects with
+    # fused separable convs, dense heads written once; 3.15 GB/image at batch 8).
+    if (args.model_variant == 'xception_65' and (args.height, args.width) == (480, 640)
+        and args.num_objs == 21 and args.num_frags == 64 and not args.sparse_heads):
+      gb = 3.30 if B == 1 else 3.15 if B >= 8 else 3.30 - 0.15 * (B - 1) / 7.0
+      roof['hbm_view'] = {
+          'bound': 'hbm', 'algorithmic_gb_per_image': round(gb, 3),
+          'achieved': round(value / world * gb, 1), 'peak': 8000.0, 'unit': 'GB/s',
+          'frac': round(value / world * gb / 8000.0, 4),
+          'note': 'whole network, per GPU: the step is bound by the matrix pipe (the '
+                  'GEMMs are 99 % of the flops at ~150 flop/B), not by HBM'}
     if core_mhz:
       # sampled in extra steps after the timed region; peak stays the 2.4 GHz figure
       roof['core_clock_mhz_under_load'] = round(core_mhz, 0)

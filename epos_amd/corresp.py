@@ -36,6 +36,17 @@ def pack_model_store(model_store, num_objs, num_frags):
   return centers, sizes
 
 
+def check_obj_ids(obj_ids, num_objs):
+  """Every object the kernels are asked about must have head channels: they index
+  obj_confs[..., obj_id], frag_confs[..., obj_id - 1, :] and the fragment tables at
+  obj_id - 1 (corresp.py:46,60,76 -- the reference raises IndexError there, e.g. for
+  an LM model store used with an LM-O checkpoint)."""
+  bad = [int(o) for o in obj_ids if not 1 <= int(o) <= num_objs]
+  if bad:
+    raise ValueError('object ids %s have no channels in a %d-object network '
+                     '(valid: 1..%d)' % (bad, num_objs, num_objs))
+
+
 class CorrExtractor(object):
   """Batched device-side extractor with preallocated buffers.
 
@@ -86,6 +97,9 @@ class CorrExtractor(object):
     """slots: list of (image index, obj_id)."""
     if len(slots) > self.max_slots:
       raise ValueError('too many slots (%d > %d)' % (len(slots), self.max_slots))
+    check_obj_ids([o for _, o in slots], self.O)
+    if any(not 0 <= im < self.B for im, _ in slots):
+      raise ValueError('slot image index outside the batch of %d' % self.B)
     self.S = len(slots)
     if self.S:
       arr = torch.tensor(slots, dtype=torch.int32).reshape(-1, 2)
@@ -146,6 +160,7 @@ def establish_many_to_many(
              if not (only_annotated_objs and o not in gt_obj_ids)]  # :39-43
   if not obj_ids:
     return {}
+  check_obj_ids(obj_ids, num_objs)
   centers, sizes = pack_model_store(model_store, num_objs, num_frags)
   ex = CorrExtractor(1, h, w, num_objs, num_frags, centers, sizes,
                      max_slots=len(obj_ids), capacity=0, device=device)

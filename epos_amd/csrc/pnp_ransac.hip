@@ -380,10 +380,13 @@ struct Work {
 __global__ __launch_bounds__(256) void ransac_init(const int64_t* slot_base, int S,
                                                    Work w, int32_t* labels,
                                                    int32_t* num_models,
-                                                   int min_pts) {
+                                                   int min_pts, int64_t n_capacity) {
   const int s = blockIdx.x;
   const int64_t base = slot_base[s];
-  const int64_t n = slot_base[s + 1] - base;
+  // A slot whose rows would end beyond the pooled arrays (the correspondence stage
+  // raised its overflow flag and wrote nothing there) is fitted as EMPTY: no kernel of
+  // this stage then touches a row >= n_capacity. The host reports the overflow.
+  const int64_t n = slot_base[s + 1] <= n_capacity ? slot_base[s + 1] - base : 0;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
     w.active[base + i] = static_cast<int32_t>(i);
     labels[base + i] = -1;
@@ -820,7 +823,7 @@ extern "C" int epos_find6d_poses_device(
   w.words_total = L.words_total;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(ransac_init, dim3(S), dim3(256), 0, st, slot_base, S, w, labels,
-                     num_models, p->min_point_number);
+                     num_models, p->min_point_number, n_capacity);
   int rc = launch_status("ransac_init");
   if (rc) return rc;
   const dim3 hgrid(static_cast<unsigned>(ceil_div(p->max_iters, 4)), S);

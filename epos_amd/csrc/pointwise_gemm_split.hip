@@ -387,8 +387,64 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     };
     using NoDma = std::integral_constant<int, -1>;
     constexpr bool ISSUE = MODE <= 1;
+    // Two column blocks interleaved (CB 4): the same six piece products per block in the
+    // same order per accumulator (bit-identical sums), but consecutive MFMAs alternate
+    // between the two blocks' accumulators. An MFMA that accumulates into the register
+    // block its predecessor writes only issues back to back when NOTHING sits between
+    // them; the DMA pieces and the operand split pinned between such a pair cost ~40+
+    // cycles each (MI355X_MICROARCH.md, "extra issue slot between two MFMAs on the same
+    // accumulator"), between MFMAs on different accumulators they hide.
+    auto pair = [&](auto ca_tag, auto cb_tag, auto dma_tag, auto slot_tag) {
+      constexpr int ca = decltype(ca_tag)::value, cbb = decltype(cb_tag)::value;
+      constexpr int DMA0 = decltype(dma_tag)::value;     // 0: issue pieces 0..NP-1, -1: none
+      constexpr int SLOT0 = decltype(slot_tag)::value;   // 0: split the next A values, -1: no
+      auto step = [&](const u32x4& a, const u32x4& b, f32x16& c, auto s_tag) {
+        constexpr int s = decltype(s_tag)::value;        // 0..11 within the pair
+        mfma_bf16(a, b, c);
+#ifdef EPOS_SPLIT_ABL_NODMA
+        constexpr bool kIssue = false;
+#else
+        constexpr bool kIssue = true;
+#endif
+        constexpr int piece = (DMA0 < 0 || !(s & 1)) ? -1 : DMA0 + s / 2;
+        if constexpr (kIssue && piece >= 0 && piece < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(kt + 3, s3, std::integral_constant<int, piece>{},
+                      std::integral_constant<bool, MODE == 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (SLOT0 >= 0 && MODE != 4) {
+          constexpr int first = SLOT0 + s - 2;           // one value per MFMA, slots 2..9
+          if constexpr (first >= 0 && first < 8) {
+            __builtin_amdgcn_sched_barrier(0);
+            split_val(std::integral_constant<int, first>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+      step(al, bp[ca][0], corr[ca], std::integral_constant<int, 0>{});
+      step(al, bp[cbb][0], corr[cbb], std::integral_constant<int, 1>{});
+      step(ah, bp[ca][2], corr[ca], std::integral_constant<int, 2>{});
+      step(ah, bp[cbb][2], corr[cbb], std::integral_constant<int, 3>{});
+      step(am, bp[ca][1], corr[ca], std::integral_constant<int, 4>{});
+      step(am, bp[cbb][1], corr[cbb], std::integral_constant<int, 5>{});
+      step(am, bp[ca][0], corr[ca], std::integral_constant<int, 6>{});
+      step(am, bp[cbb][0], corr[cbb], std::integral_constant<int, 7>{});
+      step(ah, bp[ca][1], corr[ca], std::integral_constant<int, 8>{});
+      step(ah, bp[cbb][1], corr[cbb], std::integral_constant<int, 9>{});
+      step(ah, bp[ca][0], acc[ca], std::integral_constant<int, 10>{});
+      step(ah, bp[cbb][0], acc[cbb], std::integral_constant<int, 11>{});
+    };
+#ifndef EPOS_SPLIT_NOILV
+    constexpr bool kPair = CB == 4;
+#else
+    constexpr bool kPair = false;
+#endif
     // first half of the column blocks (+ the DMA pieces), barrier, second half
-    if constexpr (CB == 4) {
+    if constexpr (kPair) {
+      pair(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{},
+           std::integral_constant<int, ISSUE ? 0 : -1>{}, NoDma{});
+    } else if constexpr (CB == 4) {
       block(std::integral_constant<int, 0>{}, std::integral_constant<int, ISSUE ? 0 : -1>{}, NoDma{});
       block(std::integral_constant<int, 1>{}, std::integral_constant<int, ISSUE ? 3 : -1>{}, NoDma{});
     } else {
@@ -415,7 +471,10 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (CB == 4) {
+    if constexpr (kPair && LIVE == 4) {
+      pair(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, NoDma{},
+           std::integral_constant<int, 0>{});
+    } else if constexpr (CB == 4) {
       block(std::integral_constant<int, 2>{}, NoDma{}, std::integral_constant<int, 0>{});
       if constexpr (LIVE == 4)
         block(std::integral_constant<int, 3>{}, NoDma{}, std::integral_constant<int, 6>{});

@@ -16,13 +16,15 @@ import torch.distributed as dist
 RECORD_COLS = 17
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
   """Initialises torch.distributed from the torchrun environment (RANK,
-  WORLD_SIZE, MASTER_ADDR, MASTER_PORT). Returns (rank, world, local_rank)."""
+  WORLD_SIZE, MASTER_ADDR, MASTER_PORT). Returns (rank, world, local_rank). A
+  single-rank job needs no process group and gets none unless ``force`` (the RCCL
+  smoke test initialises a world of one on the one-GPU box)."""
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world > 1 and not dist.is_initialized():
+  if (world > 1 or force) and not dist.is_initialized():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
@@ -73,17 +75,23 @@ def records_to_poses(rec, n):
   return out
 
 
-def gather_poses(poses, max_records, device=None):
+def gather_poses(poses, max_records=None, device=None):
   """All ranks contribute their pose lists; every rank gets the concatenation in
   rank order (rank 0 writes the CSV). One all_gather of a fixed-size tensor:
-  [max_records*17 + 1] float64 per rank -- KB-sized, latency bound."""
+  [max_records*17 + 1] float64 per rank -- KB-sized, latency bound. ``max_records``
+  must be the same on every rank (poses beyond it are dropped); None = agreed on
+  by a MAX all-reduce of the local counts."""
   world = dist.get_world_size() if dist.is_initialized() else 1
   if world == 1:
     return list(poses)
-  rec, n = poses_to_records(poses, max_records)
   if device is None:
     device = (torch.device('cuda', torch.cuda.current_device())
               if dist.get_backend() == 'nccl' else torch.device('cpu'))
+  if max_records is None:
+    # every rank must bring the SAME tensor size to all_gather_into_tensor: agree on
+    # the largest local count first (one 8-byte MAX all-reduce)
+    max_records = max(1, int(max_over_ranks(float(len(poses)), device)))
+  rec, n = poses_to_records(poses, max_records)
   local = torch.empty(max_records * RECORD_COLS + 1, dtype=torch.float64,
                       device=device)
   local[:-1] = torch.from_numpy(rec.reshape(-1)).to(device)

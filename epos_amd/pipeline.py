@@ -136,6 +136,7 @@ class EposPipeline(object):
         else:
           wants.append(-1)
         slots.append((im, obj_id))
+    _corresp.check_obj_ids([o for _, o in slots], self.O)
     return slots, wants
 
   def launch(self, images, Ks, targets, task_type=LOCALIZATION, image_ids=None,

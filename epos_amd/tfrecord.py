@@ -249,13 +249,31 @@ def _scalar(feats, key, default):
   return v[0] if v else default
 
 
+def crop_offsets(max_offset_h, max_offset_w, crop_seed, scene_id, im_id):
+  """datagen.py:451-455: offset ~ U{0..max_offset} per axis, independently per
+  frame. TensorFlow's op-level random stream cannot be reproduced without
+  TensorFlow, so the draw here is a counter-based one keyed by (crop_seed, scene_id,
+  im_id): same distribution, reproducible, and independent of the order in which
+  ranks read the file. Frames exactly as large as the crop (YCB-V 640x480, the
+  headline configuration) get offset 0 in both, as in the reference."""
+  if max_offset_h <= 0 and max_offset_w <= 0:
+    return 0, 0
+  rng = np.random.Generator(np.random.Philox(key=[
+      int(crop_seed) & 0xffffffffffffffff,
+      ((int(scene_id) & 0xffffffff) << 32) | (int(im_id) & 0xffffffff)]))
+  off_h = int(rng.integers(0, max(max_offset_h, 0) + 1))
+  off_w = int(rng.integers(0, max(max_offset_w, 0) + 1))
+  return off_h, off_w
+
+
 def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
-                  min_visib_fract=0.1):
+                  min_visib_fract=0.1, crop_seed=0, crop_offset=None):
   """One parsed Example -> the inference sample of datagen.py:424-476,545-575:
   dict(scene_id, im_id, image_path, image f32[crop_h, crop_w, 3], K f64[3,3],
-  gt_obj_ids list). crop_size = (width, height) as the reference consumes it
-  (datagen.py:448-449). The crop offset is 0 (the reference draws it at random
-  when the frame is larger than the crop, datagen.py:451-455)."""
+  gt_obj_ids list, crop_offset (h, w)). crop_size = (width, height) as the reference
+  consumes it (datagen.py:448-449). A frame larger than the crop is cropped at a
+  random offset (datagen.py:451-455, see crop_offsets; ``crop_offset=(h, w)`` fixes
+  it) and the principal point moves with it (datagen.py:465-466)."""
   from PIL import Image
   im = np.asarray(Image.open(io.BytesIO(feats['image/encoded'][0])).convert('RGB'),
                   dtype=np.float32)
@@ -270,11 +288,20 @@ def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
   if crop_h > h_new or crop_w > w_new:
     raise ValueError('crop %dx%d larger than the frame %dx%d' % (
         crop_w, crop_h, w_new, h_new))
-  im = im[:crop_h, :crop_w]
+  scene_id = int(_scalar(feats, 'image/scene_id', -1))
+  im_id = int(_scalar(feats, 'image/im_id', -1))
+  if crop_offset is None:
+    crop_offset = crop_offsets(h_new - crop_h, w_new - crop_w, crop_seed, scene_id,
+                               im_id)
+  off_h, off_w = crop_offset
+  if not (0 <= off_h <= h_new - crop_h and 0 <= off_w <= w_new - crop_w):
+    raise ValueError('crop offset (%d, %d) outside the frame' % (off_h, off_w))
+  im = im[off_h:off_h + crop_h, off_w:off_w + crop_w]       # misc.crop_image
+  # float32 arithmetic as in the TF graph (datagen.py:463-466)
   fx = np.float32(_scalar(feats, 'image/camera/fx', -1.0)) * scale
   fy = np.float32(_scalar(feats, 'image/camera/fy', -1.0)) * scale
-  cx = np.float32(_scalar(feats, 'image/camera/cx', -1.0)) * scale
-  cy = np.float32(_scalar(feats, 'image/camera/cy', -1.0)) * scale
+  cx = np.float32(_scalar(feats, 'image/camera/cx', -1.0)) * scale - np.float32(off_w)
+  cy = np.float32(_scalar(feats, 'image/camera/cy', -1.0)) * scale - np.float32(off_h)
   K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float64)
   ids = [int(x) for x in feats.get('image/object/id', [])]
   vis = list(feats.get('image/object/visibility', [1.0] * len(ids)))
@@ -283,8 +310,7 @@ def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
           (min_visib_fract is None or vis[i] >= min_visib_fract)]   # :555-575
   path = _scalar(feats, 'image/path', b'')
   return {
-      'scene_id': int(_scalar(feats, 'image/scene_id', -1)),
-      'im_id': int(_scalar(feats, 'image/im_id', -1)),
+      'scene_id': scene_id, 'im_id': im_id, 'crop_offset': (off_h, off_w),
       'image_path': path.decode('utf-8') if isinstance(path, bytes) else path,
       'image': np.ascontiguousarray(im), 'K': K,
       'gt_obj_ids': [ids[i] for i in keep],
@@ -292,9 +318,9 @@ def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
 
 
 def load_samples(path, crop_size, max_height_before_crop=480, obj_ids=None,
-                 min_visib_fract=0.1, verify_crc=False):
+                 min_visib_fract=0.1, verify_crc=False, crop_seed=0):
   """Iterates the inference samples of one .tfrecord file in file order (the
   reference keeps reading sequential at inference, datagen.py:680-683)."""
   for rec in read_records(path, verify_crc):
     yield decode_sample(parse_example(rec), crop_size, max_height_before_crop,
-                        obj_ids, min_visib_fract)
+                        obj_ids, min_visib_fract, crop_seed)

@@ -57,8 +57,12 @@ int epos_clock_probe(int64_t* out2, int microseconds, void* stream);
 int64_t epos_pack_pointwise_weights(const float* w_kn, int K, int N, float* dst);
 
 /* The same matrix for the split-operand GEMM (pointwise_gemm_split_f32): every fp32
- * weight is cut EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits, hi + mid +
- * lo == w) and stored in the fragment order of v_mfma_f32_32x32x16_bf16:
+ * weight is cut into three bf16 pieces (8 + 8 + 8 significand bits; the cut itself is
+ * exact, hi + mid + lo == w) and stored in the fragment order of
+ * v_mfma_f32_32x32x16_bf16. The kernel then forms each product a*w from SIX of the nine
+ * piece products (the three lowest-order cross terms, below 2^-23 |a*w|, are dropped):
+ * fp32-equivalent, not exact -- its measured error against fp64 is below the fp32-MFMA
+ * kernel's (tests/test_gpu_layers.py). Layout:
  * [ceil(N/128)][ceil(K/16)][4 column blocks][3 pieces][64 lanes][8 bf16], zero padded.
  * Host-side helper (host pointers). Returns the number of BYTES written (or required,
  * if dst == NULL). */

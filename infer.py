@@ -100,6 +100,22 @@ def build_parser():
   a('--upsample_logits', type=str2bool, default=False)
   a('--frag_cls_agnostic', type=str2bool, default=False)
   a('--frag_loc_agnostic', type=str2bool, default=False)
+  a('--multi_grid', default=None,
+    help='e.g. 1,2,4 for the resnet_v1_*_beta checkpoints (common.py:111-115)')
+  # common.py:96-154: known to the reference, supported here at their defaults only
+  # (check_supported_flags raises otherwise -- a params.yml must not be half-applied)
+  a('--logits_kernel_size', type=int, default=1)
+  a('--image_pyramid', default=None)
+  a('--add_image_level_feature', type=str2bool, default=True)
+  a('--image_pooling_stride', default='1,1')
+  a('--aspp_with_batch_norm', type=str2bool, default=True)
+  a('--aspp_with_separable_conv', type=str2bool, default=True)
+  a('--depth_multiplier', type=float, default=1.0)
+  a('--divisible_by', type=int, default=None)
+  a('--decoder_use_separable_conv', type=str2bool, default=True)
+  a('--merge_method', default='max')
+  a('--prediction_with_upsampled_logits', type=str2bool, default=True)
+  a('--use_bounded_activation', type=str2bool, default=False)
   # this build
   a('--frames', default=None, help='directory with frames.json + images')
   a('--synthetic', type=int, default=0, help='number of synthetic frames')
@@ -125,6 +141,59 @@ def update_flags(args, params_path):
   for name, val in params.items():
     if hasattr(args, name):
       setattr(args, name, val)
+
+
+def _as_list(v, cast):
+  if v is None:
+    return None
+  if isinstance(v, (list, tuple)):
+    return [cast(x) for x in v]
+  return [cast(x) for x in str(v).strip('[]()').split(',') if str(x).strip()]
+
+
+# Flags of common.py:60-154 the network plan implements at ONE value only. A model
+# trained with another value has a different graph (other layers, other head layout),
+# so running it through this plan would silently produce garbage: raise instead.
+_FIXED_FLAGS = [
+    ('upsample_logits', False, 'model.py:661-672: logits stay at the decoder stride'),
+    ('frag_cls_agnostic', False, 'common.py:198-202: per-object fragment heads only'),
+    ('frag_loc_agnostic', False, 'common.py:61-66: per-object fragment heads only'),
+    ('logits_kernel_size', 1, 'model.py:428-431'),
+    ('add_image_level_feature', True, 'model.py:217-226'),
+    ('aspp_with_batch_norm', True, 'model.py:187-199'),
+    ('aspp_with_separable_conv', True, 'model.py:243-256'),
+    ('decoder_use_separable_conv', True, 'model.py:369-392'),
+    ('use_bounded_activation', False, 'model.py:202,317: ReLU, not ReLU6'),
+    ('depth_multiplier', 1.0, 'MobileNet only'),
+    ('divisible_by', None, 'MobileNet only'),
+]
+
+
+def check_supported_flags(args):
+  """Raises NotImplementedError for a known common.py flag set (on the command line
+  or by params.yml) to a value this build's network plan does not implement."""
+  bad = []
+  for name, want, why in _FIXED_FLAGS:
+    got = getattr(args, name)
+    if isinstance(want, bool):
+      got = str2bool(got) if not isinstance(got, bool) else got
+    if got != want and not (want is None and got in (None, 'None', '')):
+      bad.append('%s=%r (supported: %r; %s)' % (name, getattr(args, name), want, why))
+  pyr = _as_list(args.image_pyramid, float)
+  if pyr not in (None, [], [1.0]):
+    bad.append('image_pyramid=%r (single scale only, model.py:545-546,597)' % (
+        args.image_pyramid,))
+  if _as_list(args.image_pooling_stride, int) not in ([1, 1],):
+    bad.append('image_pooling_stride=%r (supported: 1,1)' % (args.image_pooling_stride,))
+  if args.model_variant not in ('xception_65', 'resnet_v1_101_beta'):
+    bad.append('model_variant=%r (xception_65, resnet_v1_101_beta)' % args.model_variant)
+  if int(args.encoder_output_stride) != 8:
+    bad.append('encoder_output_stride=%r (supported: 8)' % args.encoder_output_stride)
+  if _as_list(args.decoder_output_stride, int) != [4]:
+    bad.append('decoder_output_stride=%r (supported: 4)' % (args.decoder_output_stride,))
+  if bad:
+    raise NotImplementedError(
+        'flags outside what this build implements (common.py:60-154): ' + '; '.join(bad))
 
 
 def load_fragments(model_dir, num_frags):
@@ -202,9 +271,11 @@ def load_frames(args, num_objs, rank, world, store_obj_ids=None):
       path = os.path.join(data_path, name + '.tfrecord')
       if not os.path.exists(path):
         raise ValueError('No input files: {}'.format(path))   # datagen.py:720-721
+      # min_visib_fract=None: the reference builds its inference Dataset without a
+      # visibility filter (scripts/infer.py:614), every annotated instance is a target
       all_samples += list(tfrecord.load_samples(
-          path, (w, h), args.infer_max_height_before_crop, obj_ids,
-          args.min_visib_fract))
+          path, (w, h), args.infer_max_height_before_crop, obj_ids, None,
+          crop_seed=args.seed))
     b, e = edist.shard_range(len(all_samples), rank, world)
     for sm in all_samples[b:e]:
       tg = {}
@@ -333,6 +404,7 @@ def main(argv=None):
   models_path = os.environ.get('TF_MODELS_PATH', '.')          # config.py:9-16
   model_dir = os.path.join(models_path, args.model)
   update_flags(args, os.path.join(model_dir, PARAMS_FILENAME))  # infer.py:561-564
+  check_supported_flags(args)
   if args.cpu_only:
     raise SystemExit('--cpu_only: this build has no CPU path (MI355X only).')
   if args.fitting_method not in ('progressive_x', 'opencv_ransac'):
@@ -343,8 +415,11 @@ def main(argv=None):
   checkpoint_dir = os.path.join(model_dir, 'train')             # infer.py:570
   infer_dir = os.path.join(model_dir, 'infer')
   os.makedirs(infer_dir, exist_ok=True)
-  dev = 'cuda:%d' % local_rank
-  torch.cuda.set_device(local_rank)
+  # EPOS_FORCE_DEVICE=0 maps every rank onto one GPU (multi-rank flow on a one-GPU
+  # test box, together with EPOS_DIST_BACKEND=gloo), as in bench.py
+  dev_index = int(os.environ.get('EPOS_FORCE_DEVICE', local_rank))
+  dev = 'cuda:%d' % dev_index
+  torch.cuda.set_device(dev_index)
 
   ckpt_path = find_checkpoint(checkpoint_dir, args.checkpoint_name)
   tf_prefix = None
@@ -380,14 +455,14 @@ def main(argv=None):
 
   frames, h, w = load_frames(args, num_objs, rank, world,
                             store.dp_model['obj_ids'])
-  atrous = [int(x) for x in str(args.atrous_rates).strip('[]').split(',')]
+  atrous = _as_list(args.atrous_rates, int)
   mo = model.ModelOptions(
       model.get_outputs_to_num_channels(num_objs, args.num_frags),
       crop_size=(w, h), atrous_rates=atrous,
       encoder_output_stride=args.encoder_output_stride,
-      decoder_output_stride=[int(x) for x in str(
-          args.decoder_output_stride).strip('[]').split(',')],
-      model_variant=args.model_variant)
+      decoder_output_stride=_as_list(args.decoder_output_stride, int),
+      model_variant=args.model_variant,
+      multi_grid=_as_list(args.multi_grid, int))
   fit = fitting.fit_params(
       threshold=args.inlier_thresh,
       neighborhood_ball_radius=args.neighbour_max_dist,
@@ -492,8 +567,9 @@ def main(argv=None):
       for p in poses_all:
         if (p['scene_id'], p['im_id']) == first:
           p['time'] = float(np.mean(rest))
-  merged = edist.gather_poses(poses_all, max_records=max(
-      1, len(frames) * num_objs * max_inst)) if world > 1 else poses_all
+  # max_records=None: the ranks first agree on the largest local pose count (their
+  # shards differ by a frame whenever N % world != 0, and a rank may hold none)
+  merged = edist.gather_poses(poses_all, max_records=None) if world > 1 else poses_all
   if rank == 0 and args.save_estimates:
     suffix = '' if args.infer_name is None else '_' + args.infer_name
     path = os.path.join(infer_dir, 'estimated-poses{}.csv'.format(suffix))

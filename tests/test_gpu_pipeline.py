@@ -150,14 +150,71 @@ def test_bench_multi_rank_flow_on_one_gpu():
   env = dict(os.environ, EPOS_DIST_BACKEND='gloo', EPOS_FORCE_DEVICE='0')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
-         str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6',
-         '--warmup', '2', '--no-cpu-baseline', '--no-roofline']
+         str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4',
+         '--warmup', '1', '--no-cpu-baseline', '--no-roofline']
   out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True,
                        timeout=600)
   assert out.returncode == 0, out.stderr[-2000:]
   lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
   assert len(lines) == 1                      # rank 0 only
   d = json.loads(lines[0])
-  assert d['n_gpus'] == 2 and d['steps'] == 6 and d['scaling'] == 'weak'
-  assert d['config']['global_batch'] == 2 and d['value'] > 0
+  assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak'
+  # N > 1 defaults to the per-GPU shard of config C3 (4 images per GPU and step)
+  assert d['config']['global_batch'] == 8 and d['value'] > 0
+  assert d['config']['workload'].startswith('C3 per-GPU shard')
+  assert d['config']['rccl_ranks_seen'] == 2 and d['config']['dist_backend'] == 'gloo'
+  assert d['serial_depth1']['images_per_sec'] > 0
   assert d['config']['poses_per_step'] > 0
+
+
+def test_capacity_overflow_is_reported_and_contained():
+  """More correspondences than the pooled arrays hold: the fill kernel raises the
+  overflow flag, the fitting stage treats every slot that would reach beyond the
+  arrays as empty (no out-of-range row is read or written on the device), the host
+  raises EposError -- and the same process keeps working afterwards."""
+  from epos_amd import _lib, model, pipeline, synthetic, weights
+  O, F, H, W_ = 3, 64, 96, 128
+  ckpt = weights.random_init(num_objs=O, seed=1, randomize_bn=True, logits_std=0.6)
+  store = synthetic.ModelStore(O, F, seed=0)
+  img = torch.from_numpy(synthetic.image(0, H, W_)[None]).cuda()
+  K = np.array([[300., 0, 64], [0, 300., 48], [0, 0, 1]])[None]
+  targets = [{1: 1, 2: 1, 3: 1}]
+  big = pipeline.EposPipeline(ckpt, 1, H, W_, O, F, store, capacity=1 << 16)
+  poses_ok, _ = big.process_batch(img, K, targets, seed=3)
+  total = int(big.last_totals[:, 1].sum())
+  assert total > 64 and len(poses_ok) > 0
+  # guard words behind the (too small) pooled arrays must survive the overflowing run
+  small = pipeline.EposPipeline(ckpt, 1, H, W_, O, F, store, capacity=total // 2,
+                                instance=1)
+  guard = torch.full((4096,), 12345, dtype=torch.int32, device='cuda')
+  with pytest.raises(_lib.EposError):
+    small.process_batch(img, K, targets, seed=3)
+  torch.cuda.synchronize()
+  assert int((guard != 12345).sum()) == 0
+  assert int((small.labels[:small.corr.capacity] < -1).sum()) == 0
+  again, _ = big.process_batch(img, K, targets, seed=3)
+  assert len(again) == len(poses_ok)
+  for a, b in zip(again, poses_ok):
+    assert np.array_equal(a['R'], b['R']) and np.array_equal(a['t'], b['t'])
+
+
+def test_object_ids_without_channels_are_rejected():
+  """A model store that lists more objects than the network has channels (an LM store
+  with an LM-O checkpoint): ValueError on the host instead of out-of-range channel
+  reads on the device (the reference raises IndexError at corresp.py:46)."""
+  from epos_amd import corresp, pipeline, synthetic, weights
+  O, F, H, W_ = 2, 64, 64, 64
+  ckpt = weights.random_init(num_objs=O, seed=1)
+  store = synthetic.ModelStore(O + 1, F, seed=0)          # lists object 3 too
+  pipe = pipeline.EposPipeline(ckpt, 1, H, W_, O, F, store, capacity=1 << 12)
+  with pytest.raises(ValueError):
+    pipe.make_slots([{1: 1, 3: 1}])
+  slots, _ = pipe.make_slots([{1: 1, 2: 1}])             # targets inside: fine
+  assert slots == [(0, 1), (0, 2)]
+  with pytest.raises(ValueError):
+    pipe.make_slots([{}], task_type=pipeline.DETECTION)  # every store object
+  z = np.zeros
+  with pytest.raises(ValueError):
+    corresp.establish_many_to_many(z((16, 16, O + 1), 'f'), z((16, 16, O, F), 'f'),
+                                   z((16, 16, O, F, 3), 'f'), [3], store, 0.25, 0.1,
+                                   0.5, False, True)

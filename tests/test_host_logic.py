@@ -117,7 +117,13 @@ poses = [{'scene_id': 1, 'im_id': i, 'obj_id': 3 + rank, 'score': float(i),
           'time': 0.1} for i in range(b, e)]
 merged = ed.gather_poses(poses, max_records=8)
 tmax = ed.max_over_ranks(1.0 + rank)
+# uneven shards (N %% world != 0, a rank with nothing): the ranks agree on the record
+# count themselves (max_records=None) instead of deriving it from their local shard
+uneven = ed.gather_poses(poses if rank == 0 else [], max_records=None)
+uneven2 = ed.gather_poses(poses, max_records=None)
 ed.barrier()
+assert [p['im_id'] for p in uneven] == [0, 1, 2], uneven
+assert [p['im_id'] for p in uneven2] == [0, 1, 2, 3, 4], uneven2
 if rank == 0:
   assert [p['im_id'] for p in merged] == [0, 1, 2, 3, 4], merged
   assert [p['obj_id'] for p in merged] == [3, 3, 3, 4, 4]

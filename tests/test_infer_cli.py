@@ -28,6 +28,35 @@ def test_params_yml_overrides_flag_defaults(tmp_path):
                        else None)
 
 
+def test_unsupported_model_flags_raise(tmp_path):
+  """A params.yml (or flag) that asks for a graph this build does not implement must
+  stop the run, not be half-applied (common.py:96-154)."""
+  import infer
+  ok = infer.build_parser().parse_args(['--model', 'm', '--multi_grid', '1,2,4'])
+  infer.check_supported_flags(ok)                        # defaults + multi_grid: fine
+  assert infer._as_list(ok.multi_grid, int) == [1, 2, 4]
+  for text in ['aspp_with_separable_conv: false\n', 'upsample_logits: true\n',
+               'frag_cls_agnostic: true\n', 'image_pyramid: [0.5, 1.0]\n',
+               'logits_kernel_size: 3\n', 'decoder_use_separable_conv: false\n',
+               'add_image_level_feature: false\n', 'use_bounded_activation: true\n',
+               'encoder_output_stride: 16\n', 'model_variant: mobilenet_v2\n',
+               'aspp_with_batch_norm: false\n', 'image_pooling_stride: "2,2"\n']:
+    args = infer.build_parser().parse_args(['--model', 'm'])
+    p = tmp_path / 'params.yml'
+    p.write_text(text)
+    infer.update_flags(args, str(p))
+    with pytest.raises(NotImplementedError):
+      infer.check_supported_flags(args)
+  # values equal to the defaults, in YAML spellings, pass
+  args = infer.build_parser().parse_args(['--model', 'm'])
+  (tmp_path / 'params.yml').write_text(
+      'image_pyramid: [1.0]\ndecoder_output_stride: [4]\natrous_rates: [12, 24, 36]\n'
+      'aspp_with_batch_norm: true\nmulti_grid: [1, 2, 4]\n')
+  infer.update_flags(args, str(tmp_path / 'params.yml'))
+  infer.check_supported_flags(args)
+  assert infer._as_list(args.atrous_rates, int) == [12, 24, 36]
+
+
 def test_unknown_fitting_method_raises(tmp_path, monkeypatch):
   import infer
   monkeypatch.setenv('TF_MODELS_PATH', str(tmp_path))
@@ -219,3 +248,37 @@ def test_fragments_from_bop_ply_models(tmp_path, monkeypatch):
   # a dataset without model files falls through (the caller then raises)
   args.dataset = 'ycbv'
   assert infer.fragment_from_bop_models(str(model_dir), args, 'cuda:0') is None
+
+
+@pytest.mark.gpu
+def test_infer_two_ranks_with_an_odd_frame_count(tmp_path):
+  """Three frames over two ranks (shards of 2 and 1): the pose gather must not depend on
+  the rank-local shard size (two torchrun ranks on the one GPU, gloo for the gather)."""
+  import socket
+  with socket.socket() as sck:
+    sck.bind(('127.0.0.1', 0))
+    port = sck.getsockname()[1]
+  (tmp_path / 'toy').mkdir()
+  (tmp_path / 'toy' / 'params.yml').write_text('infer_crop_size: "128,96"\n')
+  env = dict(os.environ, TF_MODELS_PATH=str(tmp_path), EPOS_DIST_BACKEND='gloo',
+             EPOS_FORCE_DEVICE='0')
+  common = [os.path.join(ROOT, 'infer.py'), '--model=toy', '--synthetic', '3',
+            '--num_objs', '3']
+  out = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+       '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+       str(port)] + common + ['--infer_name', 'two'],
+      env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+  one = subprocess.run([sys.executable] + common + ['--infer_name', 'one'],
+                       env=env, capture_output=True, text=True, timeout=600)
+  assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+  from epos_amd import bop_io
+  a = bop_io.load_bop_results(str(tmp_path / 'toy' / 'infer' / 'estimated-poses_two.csv'))
+  b = bop_io.load_bop_results(str(tmp_path / 'toy' / 'infer' / 'estimated-poses_one.csv'))
+  key = lambda r: (r['im_id'], r['obj_id'], r['score'])      # noqa: E731
+  assert len(a) == len(b) and len(a) > 0
+  for x, y in zip(sorted(a, key=key), sorted(b, key=key)):
+    assert (x['im_id'], x['obj_id']) == (y['im_id'], y['obj_id'])
+    np.testing.assert_array_equal(x['R'], y['R'])
+    np.testing.assert_array_equal(x['t'], y['t'])

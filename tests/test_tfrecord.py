@@ -128,3 +128,32 @@ def test_oversized_frame_is_shrunk_and_K_scaled(tmp_path):
   np.testing.assert_allclose(s['K'][0, 0], 100.0)   # fx * 48/96
   np.testing.assert_allclose(s['K'][1, 2], 24.0)
   np.testing.assert_allclose(s['image'], tfrecord.resize_area(rgb.astype(np.float32), 48, 64))
+
+
+def test_crop_offset_and_principal_point_shift():
+  """datagen.py:451-468: a frame larger than the crop is cropped at an offset drawn
+  per frame, and cx / cy move by it (fx, fy do not)."""
+  rgb = np.random.RandomState(1).randint(0, 256, (60, 90, 3)).astype(np.uint8)
+  feats = tfrecord.parse_example(tfrecord.encode_example(
+      _example(7, 11, rgb, [1], [1.0])))
+  full = rgb.astype(np.float32)
+  s = tfrecord.decode_sample(feats, (64, 48), 480, crop_offset=(5, 9))
+  np.testing.assert_array_equal(s['image'], full[5:53, 9:73])
+  assert s['crop_offset'] == (5, 9)
+  np.testing.assert_allclose(s['K'][0, 2], np.float32(312.9869) - 9, rtol=1e-7)
+  np.testing.assert_allclose(s['K'][1, 2], np.float32(241.3109) - 5, rtol=1e-7)
+  np.testing.assert_allclose(s['K'][0, 0], np.float32(1066.778), rtol=1e-7)
+  # drawn offsets: inside the legal range, reproducible, keyed by the frame
+  seen = set()
+  for im_id in range(40):
+    oh, ow = tfrecord.crop_offsets(12, 26, 0, 7, im_id)
+    assert 0 <= oh <= 12 and 0 <= ow <= 26
+    assert (oh, ow) == tfrecord.crop_offsets(12, 26, 0, 7, im_id)
+    seen.add((oh, ow))
+  assert len(seen) > 20
+  assert tfrecord.crop_offsets(0, 0, 3, 1, 2) == (0, 0)        # frame == crop (YCB-V)
+  s2 = tfrecord.decode_sample(feats, (64, 48), 480, crop_seed=3)
+  oh, ow = s2['crop_offset']
+  np.testing.assert_array_equal(s2['image'], full[oh:oh + 48, ow:ow + 64])
+  with pytest.raises(ValueError):
+    tfrecord.decode_sample(feats, (64, 48), 480, crop_offset=(13, 0))

@@ -48,6 +48,11 @@ class DepthwiseArgs(ctypes.Structure):
   ]
 
 
+class SepConvArgs(ctypes.Structure):
+  _fields_ = [('dw', DepthwiseArgs), ('pw', PointwiseArgs), ('sync', vp),
+              ('stats', vp)]
+
+
 class Conv3x3Args(ctypes.Structure):
   _fields_ = [
       ('X', vp), ('ldx', ctypes.c_int64),
@@ -124,6 +129,8 @@ SYMBOLS = {
     'epos_conv3x3_f32': (ctypes.c_int, [ctypes.POINTER(Conv3x3Args), ctypes.c_void_p]),
     'epos_depthwise3x3_f32': (ctypes.c_int,
                               [ctypes.POINTER(DepthwiseArgs), vp]),
+    'epos_separable_conv_sync_words': (ctypes.c_int64, [ctypes.c_int32]),
+    'epos_separable_conv_f32': (ctypes.c_int, [ctypes.POINTER(SepConvArgs), vp]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),
     'epos_global_avg_pool_f32': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
@@ -198,7 +205,7 @@ def load():
     fn.restype = restype
     if argtypes is not None:
       fn.argtypes = argtypes
-  if lib.epos_abi_version() != 2:
+  if lib.epos_abi_version() != 3:
     raise EposError('libepos_hip.so ABI version mismatch')
   _lib = lib
   return lib

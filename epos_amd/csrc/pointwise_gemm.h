@@ -25,6 +25,10 @@ int64_t sk_workspace_bytes();
 int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s,
                          const int* conv_cin = nullptr, const int* conv_rate = nullptr);
 bool split_eligible(const EposPointwiseArgs* args, int count);
+// pointwise_gemm_split.hip: the fused separable conv (depthwise producer phase inside
+// the split GEMM's workgroups).
+int launch_sepconv_split(const EposSepConvArgs* a, hipStream_t s);
+int64_t sepconv_sync_words(int M);
 
 namespace {
 

@@ -738,6 +738,37 @@ extern "C" int epos_conv3x3_f32(const EposConv3x3Args* a, void* stream) {
   return launch_grouped_dma(&p, 1, static_cast<hipStream_t>(stream), &cin, &rate);
 }
 
+extern "C" int64_t epos_separable_conv_sync_words(int32_t M) {
+  return epos::sepconv_sync_words(M);
+}
+
+extern "C" int epos_separable_conv_f32(const EposSepConvArgs* a, void* stream) {
+  using namespace epos;
+  EPOS_REQUIRE(a && a->dw.X && a->dw.w9c && a->dw.bias && a->dw.Y, "null pointer");
+  const EposDepthwiseArgs& d = a->dw;
+  const EposPointwiseArgs& p = a->pw;
+  EPOS_REQUIRE(p.A == d.Y && p.lda == d.ldy && p.K == d.C,
+               "the pointwise conv must read the depthwise output");
+  EPOS_REQUIRE(static_cast<int64_t>(p.M) == static_cast<int64_t>(d.B) * d.Ho * d.Wo,
+               "pw.M must be the number of depthwise output pixels");
+  const int rc = validate(&p);
+  if (rc) return rc;
+  static const int fused = [] {
+    const char* e = getenv("EPOS_SEPCONV_FUSED");
+    return e ? atoi(e) : 1;
+  }();
+  const bool ok = fused != 0 && a->sync && d.stride == 1 && d.Hi == d.Ho && d.Wi == d.Wo &&
+                  d.C % 4 == 0 && d.ldx % 4 == 0 && d.ldy % 4 == 0 && p.sub == 1 &&
+                  p.M > 8 && split_eligible(&p, 1) &&
+                  (reinterpret_cast<uintptr_t>(d.X) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(d.Y) & 127) == 0 &&
+                  static_cast<int64_t>(d.Hi) * d.Wi * d.ldx < (1LL << 29);
+  if (ok) return launch_sepconv_split(a, static_cast<hipStream_t>(stream));
+  const int rd = epos_depthwise3x3_f32(&d, stream);
+  if (rd) return rd;
+  return epos_pointwise_conv_f32(&p, stream);
+}
+
 extern "C" int epos_pointwise_conv_f32(const EposPointwiseArgs* a, void* stream) {
   return epos_pointwise_conv_grouped_f32(a, 1, stream);
 }

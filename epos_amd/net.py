@@ -85,6 +85,17 @@ class EposNet(object):
     # per plan, because launches sharing it must be ordered on one stream.
     self._gemm_ws = torch.zeros(int(self.lib.epos_pointwise_workspace_bytes()),
                                 dtype=torch.uint8, device=self.dev)
+    # Fused separable convs (depthwise as a producer phase of the pointwise GEMM's
+    # workgroups, epos_separable_conv_f32) for every stride-1 sep-conv whose GEMM is a
+    # launch of its own: OPT-IN (EPOS_SEPCONV_FUSED=1). Same bits either way, but
+    # measured slower (round 2, DESIGN.md: 294 vs 331 images/s): the producer phase costs
+    # a workgroup 14 us of latency-bound loads + 5 us of hand-off where the stand-alone
+    # depthwise launch costs 8.8 us, and a CU with one GEMM workgroup in its K loop
+    # only reaches ~70 % of the two-workgroup rate, so little of it hides.
+    import os
+    self.fuse_sepconv = os.environ.get('EPOS_SEPCONV_FUSED', '0') == '1'
+    self.fused_sepconvs = []
+    self.sepconv_stats = torch.zeros(2, dtype=torch.int32, device=self.dev)
     self._build_plan()
 
   # ------------------------------------------------------------ buffers ---
@@ -156,9 +167,12 @@ class EposNet(object):
 
   def _pointwise(self, name, a, a_off, lda, m, k, w_kn, scale, bias, c, c_off,
                  ldc, relu, relu_in=False, res=None, res_off=0, ldr=0, sub=1,
-                 ho=0, wo=0, hi=0, wi=0, group=None):
+                 ho=0, wo=0, hi=0, wi=0, group=None, dw=None):
     """One 1x1 conv. With ``group`` (a list) the problem is only appended to it;
-    ``_flush_group`` later launches the whole list as ONE grouped GEMM."""
+    ``_flush_group`` later launches the whole list as ONE grouped GEMM. With ``dw``
+    (the deferred depthwise of ``_depthwise(defer=True)`` whose output is ``a``) the
+    two halves of the separable conv go out as ONE launch
+    (epos_separable_conv_f32: depthwise = producer phase of the GEMM's workgroups)."""
     wp, bp, kpad = self._pack_pointwise(w_kn, scale, bias)
     ws = None if relu_in else self._pack_split(w_kn, scale)
     n = w_kn.shape[1]
@@ -175,6 +189,25 @@ class EposNet(object):
     nbytes = 4 * (m * k + k * n + m * n + (m * n if res is not None else 0))
     if group is not None:
       group.append((name, args, 2 * m * n * k, nbytes))
+      return
+
+    if dw is not None:
+      dname, dargs, dflops = dw
+      nsync = int(lib.epos_separable_conv_sync_words(m))
+      sync = torch.zeros(nsync, dtype=torch.int32, device=self.dev)
+      self._keep.append(sync)
+      sargs = _lib.SepConvArgs(dw=dargs, pw=args, sync=_ptr(sync),
+                               stats=_ptr(self.sepconv_stats))
+
+      def run_sep(stream, sargs=sargs):
+        _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sargs), stream), name)
+      # accounted as the GEMM it is (its flops and bytes; the depthwise flops ride
+      # along: 1 % of the layer's)
+      self._add(name, run_sep, 2 * m * n * k, 'gemm', nbytes)
+      self.flops += dflops
+      self.op_flops[dname] = dflops
+      self.op_kind[dname] = 'dw-fused'
+      self.fused_sepconvs.append(name)
       return
 
     ws = _ptr(self._gemm_ws)
@@ -204,7 +237,10 @@ class EposNet(object):
     del group[:]
 
   def _depthwise(self, name, x, ldx, hi, wi, c, stride, rate, scope, eps,
-                 relu_in, relu_out):
+                 relu_in, relu_out, defer=False):
+    """One depthwise 3x3 launch. ``defer``: only build the arguments and return
+    them as a 4th value -- the caller fuses the layer with its pointwise conv
+    (``_separable``)."""
     ho = hi if stride == 1 else (hi - 1) // 2 + 1
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     w9c, bias = self._dw_params(scope, eps)
@@ -214,6 +250,8 @@ class EposNet(object):
         B=self.B, Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c, stride=stride, rate=rate,
         relu_in=int(relu_in), relu_out=int(relu_out))
     lib = self.lib
+    if defer:
+      return y, ho, wo, (name, args, 2 * 9 * self.B * ho * wo * c)
 
     def run(stream, args=args):
       _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(args), stream), name)
@@ -422,10 +460,12 @@ class EposNet(object):
     for i in range(3):
       sc = '%s/separable_conv%d' % (scope, i + 1)
       s_i = stride if i == 2 else 1
-      d, dh, dw_ = self._depthwise(
+      grouped = i == 0 and bool(grp)          # shares its launch with the shortcut
+      fuse = self.fuse_sepconv and s_i == 1 and not grouped and rc % 4 == 0
+      d, dh, dw_, *dwa = self._depthwise(
           sc + '_depthwise', r, rc, rh, rw, rc, s_i, rate * unit_rates[i],
           sc + '_depthwise', eps, relu_in=(not act_in_sep) and not r_is_relu,
-          relu_out=act_in_sep)
+          relu_out=act_in_sep, defer=fuse)
       w_kn, scl, bi = self._conv_params(sc + '_pointwise', eps)
       y = self._empty(self.B, dh, dw_, depths[i])
       res, ldr = None, 0
@@ -436,7 +476,8 @@ class EposNet(object):
       fold_next_relu = (not act_in_sep) and i < 2 and i not in linear_taps
       self._pointwise(sc + '_pointwise', d, 0, rc, self.B * dh * dw_, rc, w_kn,
                       scl, bi, y, 0, depths[i], relu=act_in_sep or fold_next_relu,
-                      res=res, ldr=ldr, group=grp if i == 0 else None)
+                      res=res, ldr=ldr, group=grp if (i == 0 and not fuse) else None,
+                      dw=dwa[0] if fuse else None)
       r_is_relu = fold_next_relu
       if i == 0:
         self._flush_group(grp)
@@ -515,12 +556,14 @@ class EposNet(object):
     x, c = dcat, 304
     for j in range(2):
       scope = 'decoder/decoder_conv%d' % j
-      d, _, _ = self._depthwise(scope + '_depthwise', x, c, dh, dw_, c, 1, 1,
-                                scope + '_depthwise', HEAD_BN_EPS, False, True)
+      fuse = self.fuse_sepconv
+      d, _, _, *dwa = self._depthwise(scope + '_depthwise', x, c, dh, dw_, c, 1, 1,
+                                      scope + '_depthwise', HEAD_BN_EPS, False, True,
+                                      defer=fuse)
       w_kn, sc, bi = self._conv_params(scope + '_pointwise', HEAD_BN_EPS)
       y = self._empty(B, dh, dw_, 256)
       self._pointwise(scope + '_pointwise', d, 0, c, m_dec, c, w_kn, sc, bi, y,
-                      0, 256, relu=True)
+                      0, 256, relu=True, dw=dwa[0] if fuse else None)
       x, c = y, 256
     self.decoder_out = x
     self.out_h, self.out_w = dh, dw_

@@ -33,7 +33,7 @@ extern "C" {
 #define EPOS_E_NODEVICE (-3)  /* no HIP device available */
 #define EPOS_E_HIP_BASE (-1000)
 
-#define EPOS_ABI_VERSION 2   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing */
+#define EPOS_ABI_VERSION 3   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32 */
 
 int epos_abi_version(void);
 const char* epos_last_error(void);
@@ -153,6 +153,32 @@ typedef struct EposDepthwiseArgs {
   int32_t relu_in, relu_out;
 } EposDepthwiseArgs;
 int epos_depthwise3x3_f32(const EposDepthwiseArgs* args, void* stream);
+
+/* Separable conv in ONE launch: depthwise 3x3 (+BN, ReLU before/after) followed by
+ * the pointwise 1x1 (+BN, +residual, +ReLU) -- slim.separable_conv2d as
+ * net_xception.py:96-194 (separable_conv2d_same, stride 1) and model.py:58-97
+ * (split_separable_conv2d) build it. Result and intermediate are bit-identical to
+ * epos_depthwise3x3_f32(&dw) followed by epos_pointwise_conv_f32(&pw): the depthwise
+ * runs as a producer phase of the GEMM's own workgroups (the workgroups that share a
+ * row tile each compute a channel slice of it and hand it over through `sync`), so it
+ * needs no launch and no workgroup slots of its own.
+ * Requirements: dw.stride == 1 (Ho == Hi, Wo == Wi); pw.A == dw.Y, pw.lda == dw.ldy,
+ * pw.K == dw.C, pw.M == dw.B * dw.Ho * dw.Wo, pw.sub == 1, pw.relu_in == 0, pw.Ws given
+ * (split-packed weights). When a requirement of the fused kernel is not met (or
+ * EPOS_SEPCONV_FUSED=0) the two launches are issued instead.
+ * dw.Y [device] keeps the depthwise output (the GEMM reads it; callers may too).
+ * sync [device]: epos_separable_conv_sync_words(pw.M) uint32 words, zero-initialised
+ * ONCE by the caller, private to this layer and stream (the kernel re-arms them);
+ * stats [device, optional]: one uint32 counting workgroups that stopped waiting for
+ * their siblings and computed the siblings' slices themselves (diagnostics). */
+typedef struct EposSepConvArgs {
+  EposDepthwiseArgs dw;
+  EposPointwiseArgs pw;
+  uint32_t* sync;
+  uint32_t* stats;
+} EposSepConvArgs;
+int64_t epos_separable_conv_sync_words(int32_t M);
+int epos_separable_conv_f32(const EposSepConvArgs* args, void* stream);
 
 /* im2col for a dense 3x3 conv (slim resnet_utils.conv2d_same,
  * external/slim/nets/resnet_utils.py:77-122, used at net_xception.py:460-463):

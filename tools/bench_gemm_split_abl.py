@@ -18,7 +18,7 @@ def path(defs):
 if os.environ.get('ABL_VARIANTS'):      # e.g. ABL_VARIANTS=';-DEPOS_SPLIT_M0SAVE;;-DEPOS_SPLIT_M0SAVE'
   VARIANTS = [v.split() for v in os.environ['ABL_VARIANTS'].split(';')]
 if len(sys.argv) > 1 and sys.argv[1] == 'build':
-  srcs = [os.path.join(build.CSRC, f) for f in ('pointwise_gemm_split.hip', 'pointwise_gemm_dma.hip', 'pointwise_gemm.hip', 'runtime.hip')]
+  srcs = [os.path.join(build.CSRC, f) for f in ('pointwise_gemm_split.hip', 'pointwise_gemm_dma.hip', 'pointwise_gemm.hip', 'layers.hip', 'runtime.hip')]
   for defs in [list(x) for x in {tuple(v) for v in VARIANTS}]:
     subprocess.check_call([build.HIPCC] + build.FLAGS + defs + ['-o', path(defs)] + srcs)
   sys.exit(0)

@@ -104,6 +104,8 @@ class FitParams(ctypes.Structure):
       ('max_model_number_for_optimization', ctypes.c_int32),
       ('use_prosac', ctypes.c_int32),
       ('lo_iters', ctypes.c_int32),
+      ('gc_sweeps', ctypes.c_int32),
+      ('pearl_iters', ctypes.c_int32),
   ]
 
 

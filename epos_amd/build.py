@@ -34,11 +34,31 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-  """Compiles every HIP source into epos_amd/lib/libepos_hip.so."""
+  """Compiles every HIP source into epos_amd/lib/libepos_hip.so: one hipcc job per
+  translation unit (in parallel, objects cached by mtime under lib/obj/), then a link."""
   if not force and not _stale():
     return LIB_PATH
-  os.makedirs(LIB_DIR, exist_ok=True)
-  cmd = [HIPCC] + FLAGS + ['-o', LIB_PATH] + sources()
+  from concurrent.futures import ThreadPoolExecutor
+  obj_dir = os.path.join(LIB_DIR, 'obj')
+  os.makedirs(obj_dir, exist_ok=True)
+  headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(
+      os.path.join(HERE, '..', 'include', '*.h'))
+  hdr_time = max(os.path.getmtime(h) for h in headers)
+  cflags = [f for f in FLAGS if f != '-shared'] + ['-c', '-Wno-inline-asm']
+
+  def compile_one(src):
+    obj = os.path.join(obj_dir, os.path.basename(src) + '.o')
+    if (not force and os.path.exists(obj) and
+        os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time)):
+      return obj
+    cmd = [HIPCC] + cflags + ['-o', obj, src]
+    if verbose:
+      print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return obj
+  with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+    objs = list(ex.map(compile_one, sources()))
+  cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
   if verbose:
     print(' '.join(cmd))
   subprocess.check_call(cmd)

@@ -18,6 +18,10 @@
 // Arithmetic is fp64 (the reference hands f64 arrays to progressive-x) using only
 // + - * / sqrt, compiled with -ffp-contract=off: results are reproducible run to
 // run and identical to a scalar evaluation in the same canonical order.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.h"
 
 namespace epos {
@@ -301,10 +305,10 @@ constexpr int PF = 4;           // items fetched together per lane / thread
 struct PointBatch {
   double x2[PF][2], x3[PF][3];
   bool ok[PF];
+  int32_t p[PF];
   __device__ __forceinline__ void load(const double* xy, const double* xyz,
                                        const int32_t* idx, int64_t i0, int stride,
                                        int64_t m) {
-    int32_t p[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int64_t i = i0 + static_cast<int64_t>(u) * stride;
@@ -375,7 +379,54 @@ struct Work {
   int32_t* done;         // [S]
   uint64_t* inl_bits;    // [max_k][words_total]
   int64_t words_total;
+  // proposal state between the kernels of one round
+  double* cur_pose;      // [S][12]
+  double* cur_score;     // [S]
+  int32_t* cur_count;    // [S]
+  int32_t* state;        // [S] 0: nothing to do, 1: label + refit, 2: refit / accept only
+  int32_t* tries;        // [S] failed proposals since the last accepted instance
+  int32_t* last_new;     // [S] newly explained points of the last accepted instance
+  int32_t* gq;           // [N] fixed-point truncated residuals of the labelling
+  uint8_t* lab_a;        // [N] labels, ping
+  uint8_t* lab_b;        // [N] labels, pong
+  const int32_t* yorder; // [N] correspondences of a slot sorted by image y (or null:
+  const int32_t* ypos;   //     they already are), and the inverse permutation
 };
+
+constexpr int GC_Q = 1 << 20;          // fixed point of the labelling energies
+
+// b^e by binary exponentiation (multiplications only: every implementation of the
+// stage gets the same bits)
+__device__ __forceinline__ double powi(double b, int64_t e) {
+  double r = 1.0;
+  while (e > 0) {
+    if (e & 1) r = r * b;
+    b = b * b;
+    e >>= 1;
+  }
+  return r;
+}
+
+// A proposal round of slot s failed (no model, too few inliers, Tanimoto / coverage):
+// single-instance search stops; the multi-instance search retries with fresh samples
+// while the samples drawn since the last success have not reached confidence `conf` of
+// having hit an instance as large as the last accepted one (DESIGN.md "Pose fitting").
+__device__ void round_failed(int s, const Work& w, const EposFitParams& prm, int want,
+                             int k, int64_t n_active) {
+  const int tries = ++w.tries[s];
+  bool stop = want == 1;
+  if (!stop) {
+    const int64_t ref = k == 0 ? prm.min_point_number : w.last_new[s];
+    if (ref >= n_active) {
+      stop = true;
+    } else {
+      const double r = static_cast<double>(ref) / static_cast<double>(n_active);
+      stop = !(powi(1.0 - r * r * r, static_cast<int64_t>(tries) * prm.max_iters) >
+               1.0 - prm.conf);
+    }
+  }
+  if (stop) w.done[s] = 1;
+}
 
 __global__ __launch_bounds__(256) void ransac_init(const int64_t* slot_base, int S,
                                                    Work w, int32_t* labels,
@@ -395,6 +446,9 @@ __global__ __launch_bounds__(256) void ransac_init(const int64_t* slot_base, int
     w.n_active[s] = static_cast<int32_t>(n);
     num_models[s] = 0;
     w.done[s] = (n < min_pts || n < 3) ? 1 : 0;      // infer.py:420-422
+    w.state[s] = 0;
+    w.tries[s] = 0;
+    w.last_new[s] = min_pts;
   }
 }
 
@@ -535,10 +589,12 @@ __device__ double score_pose_block(const double* pose, const double* K, const do
   return sc;
 }
 
+// lab == nullptr: the inliers of `pose` at thr2; otherwise the points with lab[p] == sel
+// (fixed membership, full weight)
 __device__ int gn_step_block(const double* pose, const double* K, const double* xy,
                              const double* xyz, const int32_t* idx, int64_t m,
                              double thr2, int t, double* s_red27 /*[4][27]*/,
-                             double* next) {
+                             double* next, const uint8_t* lab = nullptr, int sel = 1) {
   double acc[27];
 #pragma unroll
   for (int v = 0; v < 27; ++v) acc[v] = 0.0;
@@ -550,19 +606,20 @@ __device__ int gn_step_block(const double* pose, const double* K, const double* 
     if (!pb.ok[u]) continue;
     double e2, Xc[3], r[2];
     if (reproj(pose, K, pb.x2[u], pb.x3[u], &e2, Xc, r)) continue;
-    if (!(e2 < thr2)) continue;
+    if (lab ? lab[pb.p[u]] != sel : !(e2 < thr2)) continue;
     const double iz = 1.0 / Xc[2];
     const double a0 = K[0] * iz, a1 = K[1] * iz,
                  a2 = -(K[0] * Xc[0] + K[1] * Xc[1]) * iz * iz;
     const double b1 = K[4] * iz, b2 = -(K[4] * Xc[1]) * iz * iz;
     double J0[6], J1[6];
-    J0[0] = a1 * Xc[2] - a2 * Xc[1];
-    J0[1] = -a0 * Xc[2] + a2 * Xc[0];
-    J0[2] = a0 * Xc[1] - a1 * Xc[0];
+    // Xc(w) = Xc - [Xc]x w: row . (-[Xc]x)  (sign fixed in round 2)
+    J0[0] = -a1 * Xc[2] + a2 * Xc[1];
+    J0[1] = a0 * Xc[2] - a2 * Xc[0];
+    J0[2] = -a0 * Xc[1] + a1 * Xc[0];
     J0[3] = a0; J0[4] = a1; J0[5] = a2;
-    J1[0] = b1 * Xc[2] - b2 * Xc[1];
-    J1[1] = b2 * Xc[0];
-    J1[2] = -b1 * Xc[0];
+    J1[0] = -b1 * Xc[2] + b2 * Xc[1];
+    J1[1] = -b2 * Xc[0];
+    J1[2] = b1 * Xc[0];
     J1[3] = 0.0; J1[4] = b1; J1[5] = b2;
     int v = 0;
 #pragma unroll
@@ -606,15 +663,18 @@ __device__ int gn_step_block(const double* pose, const double* K, const double* 
   return 0;
 }
 
-__global__ __launch_bounds__(256) void ransac_select_refine(
+// ---- round, step 2: best hypothesis (with the RANSAC confidence bound) + local
+// optimisation (i) + the residual table and thresholded labels of the labelling step.
+__global__ __launch_bounds__(256) void ransac_select_lo(
     const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
     const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
-    const int32_t* __restrict__ max_models, EposFitParams prm, int max_k, Work w,
-    double* poses, double* scores, int32_t* num_models, int32_t* labels_all) {
+    const int32_t* __restrict__ max_models, EposFitParams prm, int max_k, int round,
+    Work w, const int32_t* __restrict__ num_models) {
   __shared__ double s_score[256];
   __shared__ int s_index[256];
   const int s = blockIdx.x;
   const int t = threadIdx.x;
+  if (t == 0) w.state[s] = 0;
   if (w.done[s]) return;                                   // block-uniform
   int want = max_models[s];
   if (want < 0 || want > max_k) want = max_k;
@@ -623,50 +683,72 @@ __global__ __launch_bounds__(256) void ransac_select_refine(
   const int64_t n = slot_base[s + 1] - base;
   int32_t* active = w.active + base;
   const int64_t n_active = w.n_active[s];
-  if (k >= want || n_active < prm.min_point_number || n_active < 3) {
+  if (k >= want || round >= want + (want > 1 ? 2 : 0) ||
+      n_active < prm.min_point_number || n_active < 3) {
     if (t == 0) w.done[s] = 1;
     return;
   }
-  // ---- arg-max over the hypothesis table (ties -> lowest index) ----
   const int nh = prm.max_iters * MAX_SOL;
   const double* hs = w.hyp_score + static_cast<int64_t>(s) * nh;
-  double best = -1.0;
-  int best_i = 0x7fffffff;
-  for (int i = t; i < nh; i += 256) {
-    const double v = hs[i];
-    if (v > best) { best = v; best_i = i; }
-  }
-  s_score[t] = best; s_index[t] = best_i;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (t < off) {
-      const double v = s_score[t + off];
-      const int vi = s_index[t + off];
-      if (v > s_score[t] || (v == s_score[t] && vi < s_index[t])) {
-        s_score[t] = v; s_index[t] = vi;
+  const int32_t* hcnt = w.hyp_count + static_cast<int64_t>(s) * nh;
+  if (prm.proposal_engine_conf < 1.0) {
+    // sequential semantics of the termination bound: the best among the hypotheses
+    // drawn before (1 - w^3)^it <= 1 - conf (sequential semantics)
+    if (t == 0) {
+      double best = -1.0;
+      int best_i = 0x7fffffff, best_c = 0;
+      for (int it = 0; it < prm.max_iters; ++it) {
+        if (it > 0 && best > 0.0) {
+          const double r = static_cast<double>(best_c) / static_cast<double>(n_active);
+          if (powi(1.0 - r * r * r, it) <= 1.0 - prm.proposal_engine_conf) break;
+        }
+        for (int q = 0; q < MAX_SOL; ++q) {
+          const double v = hs[it * MAX_SOL + q];
+          if (v > best) { best = v; best_i = it * MAX_SOL + q; best_c = hcnt[best_i]; }
+        }
       }
+      s_score[0] = best; s_index[0] = best_i;
     }
     __syncthreads();
+  } else {
+    // ---- arg-max over the hypothesis table (ties -> lowest index) ----
+    double best = -1.0;
+    int best_i = 0x7fffffff;
+    for (int i = t; i < nh; i += 256) {
+      const double v = hs[i];
+      if (v > best) { best = v; best_i = i; }
+    }
+    s_score[t] = best; s_index[t] = best_i;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (t < off) {
+        const double v = s_score[t + off];
+        const int vi = s_index[t + off];
+        if (v > s_score[t] || (v == s_score[t] && vi < s_index[t])) {
+          s_score[t] = v; s_index[t] = vi;
+        }
+      }
+      __syncthreads();
+    }
   }
   __shared__ double s_red[4];
   __shared__ double s_red27[4 * 27];
   __shared__ int s_cnt[4];
-  __shared__ int s_inl[4], s_new[4];
-  const int lane = t & 63, wave = t >> 6;
   double best_score = s_score[0];
   const int bi = s_index[0];
-  if (!(best_score > 0.0)) { if (t == 0) w.done[s] = 1; return; }       // uniform
-  int best_count = w.hyp_count[static_cast<int64_t>(s) * nh + bi];
-  if (best_count < 3) { if (t == 0) w.done[s] = 1; return; }
+  int best_count = best_score > 0.0 ? hcnt[bi] : 0;
+  if (!(best_score > 0.0) || best_count < 3) {             // uniform
+    if (t == 0) round_failed(s, w, prm, want, k, n_active);
+    return;
+  }
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
-  int32_t* labels = labels_all + base;
   double K[9];
   for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
   const double thr2 = prm.threshold * prm.threshold;
   double pose[12];
   for (int i = 0; i < 12; ++i) pose[i] = w.hyp_pose[(static_cast<int64_t>(s) * nh + bi) * 12 + i];
-  // ---- local optimisation: the whole workgroup sums, every thread steps ----
+  // ---- local optimisation (i): the whole workgroup sums, every thread steps ----
   orthonormalize(pose);
   best_score = score_pose_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red, s_cnt,
                                 &best_count);
@@ -680,7 +762,176 @@ __global__ __launch_bounds__(256) void ransac_select_refine(
     best_score = sc; best_count = cnt;
     for (int i = 0; i < 12; ++i) pose[i] = cand[i];
   }
-  if (best_count < prm.min_point_number) { if (t == 0) w.done[s] = 1; return; }
+  if (t < 12) w.cur_pose[s * 12 + t] = pose[t];
+  if (t == 0) { w.cur_score[s] = best_score; w.cur_count[s] = best_count; }
+  const bool gc = prm.gc_sweeps > 0 && prm.spatial_coherence_weight > 0.0 &&
+                  prm.neighborhood_ball_radius > 0.0;
+  if (!gc) { if (t == 0) w.state[s] = 2; return; }
+  // ---- residual table (2^-20 fixed point of min(e^2 / (1.5 tau)^2, 1)) and the
+  //      thresholded labelling the sweeps start from; 2 = not active
+  uint8_t* lab = w.lab_a + base;
+  int32_t* gq = w.gq + base;
+  for (int64_t i = t; i < n; i += 256) lab[i] = 2;
+  __syncthreads();
+  const double tthr = 1.5 * prm.threshold, tthr2 = tthr * tthr;
+  for (int64_t i = t; i < n_active; i += 256) {
+    const int32_t p = active[i];
+    double e2, Xc[3], r[2];
+    if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) { gq[p] = GC_Q; lab[p] = 0; continue; }
+    double d = e2 / tthr2;
+    if (!(d < 1.0)) d = 1.0;
+    gq[p] = static_cast<int32_t>(d * static_cast<double>(GC_Q));
+    lab[p] = e2 < thr2 ? 1 : 0;
+  }
+  if (t == 0) w.state[s] = 1;
+}
+
+// ---- round, step 3 (gc_sweeps launches): one synchronous relabelling sweep of the
+// spatial-coherence energy (GC-RANSAC labelling). ONE WAVEFRONT PER POINT: the
+// lanes walk the point's window of the y-sorted correspondences (two correspondences
+// can only be neighbours when their image rows are within tau_d), test the 5-D
+// distance and count degree / residual sum / outlier-labelled neighbours in integers
+// (exact, order independent); lane 0 takes the cheaper label.
+__device__ __forceinline__ bool gc_neighbours(const double* xy, const double* xyz,
+                                              int32_t a, int32_t b, double s2, double r2) {
+  const double dx = xy[2 * a] - xy[2 * b], dy = xy[2 * a + 1] - xy[2 * b + 1];
+  const double dX = xyz[3 * a] - xyz[3 * b], dY = xyz[3 * a + 1] - xyz[3 * b + 1],
+               dZ = xyz[3 * a + 2] - xyz[3 * b + 2];
+  const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
+  return d2 <= r2;
+}
+
+__device__ __forceinline__ int64_t butterfly_sum_i64(int64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Visits every ACTIVE neighbour o of point p (slot-local indices): f(o). Wave-wide.
+template <typename F>
+__device__ __forceinline__ void for_each_neighbour(const double* xy, const double* xyz,
+                                                   int64_t n, int32_t p,
+                                                   const int32_t* yorder, const int32_t* ypos,
+                                                   double rad, double s2, double r2, int lane,
+                                                   F f) {
+  const double yp = xy[2 * p + 1];
+  const int64_t pos = ypos ? ypos[p] : p;
+  for (int dir = 0; dir < 2; ++dir) {
+    for (int64_t j0 = dir ? pos + 1 : pos - 1; dir ? j0 < n : j0 >= 0; j0 += dir ? 64 : -64) {
+      const int64_t j = dir ? j0 + lane : j0 - lane;
+      const bool in = dir ? j < n : j >= 0;
+      int32_t o = 0;
+      bool near = false;
+      if (in) {
+        o = yorder ? yorder[j] : static_cast<int32_t>(j);
+        near = !(fabs(yp - xy[2 * o + 1]) > rad);
+      }
+      if (!__any(near)) break;            // sorted by y: nothing further can be in range
+      if (near && gc_neighbours(xy, xyz, p, o, s2, r2)) f(o);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ransac_gc_sweep(
+    const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
+    const int64_t* __restrict__ slot_base, EposFitParams prm, Work w,
+    const uint8_t* __restrict__ lab_in_all, uint8_t* __restrict__ lab_out_all) {
+  const int s = blockIdx.y;
+  if (w.state[s] != 1) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t base = slot_base[s];
+  const int64_t n = slot_base[s + 1] - base;
+  const double* xy = xy_all + 2 * base;
+  const double* xyz = xyz_all + 3 * base;
+  const int32_t* active = w.active + base;
+  const int64_t n_active = w.n_active[s];
+  const uint8_t* lab_in = lab_in_all + base;
+  uint8_t* lab_out = lab_out_all + base;
+  const int32_t* gq = w.gq + base;
+  const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
+  const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
+  const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
+  const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
+  const double r2 = rad * rad;
+  const int nwaves = gridDim.x * 4;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256)
+    if (lab_in[i] == 2) lab_out[i] = 2;
+  for (int64_t ia = wave_id; ia < n_active; ia += nwaves) {
+    const int32_t p = active[ia];
+    int deg = 0, n0 = 0;
+    int64_t S = 0;
+    for_each_neighbour(xy, xyz, n, p, yorder, ypos, rad, s2, r2, lane, [&](int32_t o) {
+      const uint8_t lo = lab_in[o];
+      if (lo != 2) { ++deg; S += gq[o]; n0 += lo == 0; }
+    });
+    deg = butterfly_sum_i(deg);
+    n0 = butterfly_sum_i(n0);
+    S = butterfly_sum_i64(S);
+    if (lane == 0) {
+      const int64_t qp = gq[p];
+      const int64_t T = 2 * static_cast<int64_t>(GC_Q) * n0 - (static_cast<int64_t>(deg) * qp + S);
+      const int64_t u = qp < GC_Q ? -2 * (static_cast<int64_t>(GC_Q) - qp)
+                                  : 2 * static_cast<int64_t>(GC_Q);
+      const double val = (1.0 - lam) * static_cast<double>(u) + lam * static_cast<double>(T);
+      lab_out[p] = val < 0.0 ? 1 : 0;
+    }
+  }
+}
+
+// ---- round, step 4: local optimisation (ii) on the labelled inliers, the instance
+// acceptance tests, labelling + removal of the explained correspondences.
+__global__ __launch_bounds__(256) void ransac_refit_accept(
+    const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
+    const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
+    const int32_t* __restrict__ max_models, EposFitParams prm, int max_k, Work w,
+    const uint8_t* __restrict__ lab_all, double* poses, double* scores,
+    int32_t* num_models, int32_t* labels_all) {
+  const int s = blockIdx.x;
+  const int t = threadIdx.x;
+  const int state = w.state[s];
+  if (state == 0) return;                                  // block-uniform
+  int want = max_models[s];
+  if (want < 0 || want > max_k) want = max_k;
+  const int k = num_models[s];
+  const int64_t base = slot_base[s];
+  const int64_t n = slot_base[s + 1] - base;
+  int32_t* active = w.active + base;
+  const int64_t n_active = w.n_active[s];
+  __shared__ double s_red[4];
+  __shared__ double s_red27[4 * 27];
+  __shared__ int s_cnt[4];
+  __shared__ int s_inl[4], s_new[4];
+  const int lane = t & 63, wave = t >> 6;
+  const double* xy = xy_all + 2 * base;
+  const double* xyz = xyz_all + 3 * base;
+  int32_t* labels = labels_all + base;
+  double K[9];
+  for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
+  const double thr2 = prm.threshold * prm.threshold;
+  double pose[12];
+  for (int i = 0; i < 12; ++i) pose[i] = w.cur_pose[s * 12 + i];
+  double best_score = w.cur_score[s];
+  int best_count = w.cur_count[s];
+  if (state == 1) {
+    const uint8_t* lab = lab_all + base;
+    for (int li = 0; li < prm.lo_iters; ++li) {
+      double cand[12];
+      if (gn_step_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red27, cand, lab, 1))
+        break;
+      int cnt;
+      const double sc = score_pose_block(cand, K, xy, xyz, active, n_active, thr2, t, s_red,
+                                         s_cnt, &cnt);
+      if (!(sc > best_score)) break;
+      best_score = sc; best_count = cnt;
+      for (int i = 0; i < 12; ++i) pose[i] = cand[i];
+    }
+  }
+  if (best_count < prm.min_point_number) {
+    if (t == 0) round_failed(s, w, prm, want, k, n_active);
+    return;
+  }
   // ---- inliers over ALL correspondences of the slot -> bitset (chunk c: wave c % 4) --
   const int64_t words = (n + 63) / 64;
   const int64_t wbase = base / 64 + s;
@@ -720,7 +971,7 @@ __global__ __launch_bounds__(256) void ransac_select_refine(
     if (static_cast<double>(inter) >= prm.max_tanimoto_similarity * static_cast<double>(uni)) ok = false;
   }
   if (ok && static_cast<double>(n_new) < prm.min_coverage * static_cast<double>(n_inl)) ok = false;
-  if (!ok) { if (lane == 0) w.done[s] = 1; return; }
+  if (!ok) { if (lane == 0) round_failed(s, w, prm, want, k, n_active); return; }
   // ---- accept: write the pose, label + remove its inliers (stable compaction) --
   if (lane < 12) poses[(static_cast<int64_t>(s) * max_k + k) * 12 + lane] = pose[lane];
   if (lane == 0) scores[static_cast<int64_t>(s) * max_k + k] = best_score;
@@ -742,6 +993,8 @@ __global__ __launch_bounds__(256) void ransac_select_refine(
   }
   if (lane == 0) {
     w.n_active[s] = static_cast<int32_t>(wpos);
+    w.tries[s] = 0;
+    w.last_new[s] = n_new;
     num_models[s] = k + 1;
     if (k + 1 >= want) w.done[s] = 1;
   }
@@ -752,6 +1005,7 @@ inline int64_t align_up(int64_t x) { return (x + 255) / 256 * 256; }
 struct Layout {
   int64_t hyp_score, hyp_pose, hyp_count, active, n_active, done, inl_bits, total;
   int64_t words_total;
+  int64_t cur_pose, cur_score, cur_count, state, tries, last_new, gq, lab_a, lab_b;
 };
 
 Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
@@ -766,8 +1020,87 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.done = off; off = align_up(off + (S + 1) * 4);
   L.words_total = n_cap / 64 + S + 2;
   L.inl_bits = off; off = align_up(off + L.words_total * (max_k + 1) * 8);
+  L.cur_pose = off; off = align_up(off + (S + 1) * 12 * 8);
+  L.cur_score = off; off = align_up(off + (S + 1) * 8);
+  L.cur_count = off; off = align_up(off + (S + 1) * 4);
+  L.state = off; off = align_up(off + (S + 1) * 4);
+  L.tries = off; off = align_up(off + (S + 1) * 4);
+  L.last_new = off; off = align_up(off + (S + 1) * 4);
+  L.gq = off; off = align_up(off + (n_cap + 1) * 4);
+  L.lab_a = off; off = align_up(off + n_cap + 1);
+  L.lab_b = off; off = align_up(off + n_cap + 1);
   L.total = off;
   return L;
+}
+
+// Enqueues the whole fitting stage. yorder / ypos [device, n_capacity] or null: the
+// y-sorted order of every slot's correspondences and its inverse (slot-local indices);
+// null = the slots are already sorted by image row (epos_corr_fill's raster order).
+int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base, int S,
+                   int64_t n_capacity, const double* Ks, const int32_t* max_models,
+                   const uint64_t* seeds, const EposFitParams* p, int32_t max_k, void* work,
+                   double* poses, double* scores, int32_t* num_models, int32_t* labels,
+                   const int32_t* yorder, const int32_t* ypos, hipStream_t st) {
+  const Layout L = make_layout(S, n_capacity, p->max_iters, max_k);
+  char* wb = static_cast<char*>(work);
+  Work w;
+  w.hyp_score = reinterpret_cast<double*>(wb + L.hyp_score);
+  w.hyp_pose = reinterpret_cast<double*>(wb + L.hyp_pose);
+  w.hyp_count = reinterpret_cast<int32_t*>(wb + L.hyp_count);
+  w.active = reinterpret_cast<int32_t*>(wb + L.active);
+  w.n_active = reinterpret_cast<int32_t*>(wb + L.n_active);
+  w.done = reinterpret_cast<int32_t*>(wb + L.done);
+  w.inl_bits = reinterpret_cast<uint64_t*>(wb + L.inl_bits);
+  w.words_total = L.words_total;
+  w.cur_pose = reinterpret_cast<double*>(wb + L.cur_pose);
+  w.cur_score = reinterpret_cast<double*>(wb + L.cur_score);
+  w.cur_count = reinterpret_cast<int32_t*>(wb + L.cur_count);
+  w.state = reinterpret_cast<int32_t*>(wb + L.state);
+  w.tries = reinterpret_cast<int32_t*>(wb + L.tries);
+  w.last_new = reinterpret_cast<int32_t*>(wb + L.last_new);
+  w.gq = reinterpret_cast<int32_t*>(wb + L.gq);
+  w.lab_a = reinterpret_cast<uint8_t*>(wb + L.lab_a);
+  w.lab_b = reinterpret_cast<uint8_t*>(wb + L.lab_b);
+  w.yorder = yorder;
+  w.ypos = ypos;
+  hipLaunchKernelGGL(ransac_init, dim3(S), dim3(256), 0, st, slot_base, S, w, labels,
+                     num_models, p->min_point_number, n_capacity);
+  int rc = launch_status("ransac_init");
+  if (rc) return rc;
+  const dim3 hgrid(static_cast<unsigned>(ceil_div(p->max_iters, 4)), S);
+  const bool gc = p->gc_sweeps > 0 && p->spatial_coherence_weight > 0.0 &&
+                  p->neighborhood_ball_radius > 0.0;
+  // a multi-instance (Progressive-X) search may retry a failed proposal: two extra rounds
+  const int rounds = max_k + (max_k > 1 ? 2 : 0);
+  for (int round = 0; round < rounds; ++round) {
+    hipLaunchKernelGGL(ransac_hypotheses, hgrid, dim3(256), 0, st, xy, xyz,
+                       slot_base, Ks, seeds, max_models, num_models, *p, max_k,
+                       round, w);
+    rc = launch_status("ransac_hypotheses");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ransac_select_lo, dim3(S), dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                       max_models, *p, max_k, round, w, num_models);
+    rc = launch_status("ransac_select_lo");
+    if (rc) return rc;
+    const uint8_t* lab_final = w.lab_a;
+    if (gc) {
+      for (int sw = 0; sw < p->gc_sweeps; ++sw) {
+        const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
+        uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
+        hipLaunchKernelGGL(ransac_gc_sweep, dim3(64, S), dim3(256), 0, st, xy, xyz, slot_base,
+                           *p, w, in, out);
+        rc = launch_status("ransac_gc_sweep");
+        if (rc) return rc;
+        lab_final = out;
+      }
+    }
+    hipLaunchKernelGGL(ransac_refit_accept, dim3(S), dim3(256), 0, st, xy, xyz, slot_base,
+                       Ks, max_models, *p, max_k, w, lab_final, poses, scores, num_models,
+                       labels);
+    rc = launch_status("ransac_refit_accept");
+    if (rc) return rc;
+  }
+  return EPOS_OK;
 }
 
 }  // namespace
@@ -792,6 +1125,8 @@ extern "C" void epos_fit_params_default(EposFitParams* p) {
   p->max_model_number_for_optimization = 5;
   p->use_prosac = 0;
   p->lo_iters = 8;
+  p->gc_sweeps = 3;
+  p->pearl_iters = 0;
 }
 
 extern "C" int64_t epos_fit_workspace_bytes(int S, int64_t n_capacity,
@@ -809,37 +1144,12 @@ extern "C" int epos_find6d_poses_device(
   EPOS_REQUIRE(xy && xyz && slot_base && Ks && max_models && seeds && p && work &&
                poses && scores && num_models && labels, "null pointer");
   EPOS_REQUIRE(max_k >= 1 && p->max_iters >= 1, "max_k and max_iters must be >= 1");
+  EPOS_REQUIRE(p->gc_sweeps >= 0 && p->gc_sweeps <= 16, "gc_sweeps must be in [0, 16]");
+  EPOS_REQUIRE(p->pearl_iters == 0, "pearl_iters: the joint refinement is not built yet");
   if (S == 0) return EPOS_OK;
-  const Layout L = make_layout(S, n_capacity, p->max_iters, max_k);
-  char* wb = static_cast<char*>(work);
-  Work w;
-  w.hyp_score = reinterpret_cast<double*>(wb + L.hyp_score);
-  w.hyp_pose = reinterpret_cast<double*>(wb + L.hyp_pose);
-  w.hyp_count = reinterpret_cast<int32_t*>(wb + L.hyp_count);
-  w.active = reinterpret_cast<int32_t*>(wb + L.active);
-  w.n_active = reinterpret_cast<int32_t*>(wb + L.n_active);
-  w.done = reinterpret_cast<int32_t*>(wb + L.done);
-  w.inl_bits = reinterpret_cast<uint64_t*>(wb + L.inl_bits);
-  w.words_total = L.words_total;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(ransac_init, dim3(S), dim3(256), 0, st, slot_base, S, w, labels,
-                     num_models, p->min_point_number, n_capacity);
-  int rc = launch_status("ransac_init");
-  if (rc) return rc;
-  const dim3 hgrid(static_cast<unsigned>(ceil_div(p->max_iters, 4)), S);
-  for (int round = 0; round < max_k; ++round) {
-    hipLaunchKernelGGL(ransac_hypotheses, hgrid, dim3(256), 0, st, xy, xyz,
-                       slot_base, Ks, seeds, max_models, num_models, *p, max_k,
-                       round, w);
-    rc = launch_status("ransac_hypotheses");
-    if (rc) return rc;
-    hipLaunchKernelGGL(ransac_select_refine, dim3(S), dim3(256), 0, st, xy, xyz,
-                       slot_base, Ks, max_models, *p, max_k, w, poses, scores,
-                       num_models, labels);
-    rc = launch_status("ransac_select_refine");
-    if (rc) return rc;
-  }
-  return EPOS_OK;
+  return find6d_enqueue(xy, xyz, slot_base, S, n_capacity, Ks, max_models, seeds, p, max_k,
+                        work, poses, scores, num_models, labels, nullptr, nullptr,
+                        static_cast<hipStream_t>(stream));
 }
 
 extern "C" int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
@@ -863,12 +1173,29 @@ extern "C" int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
   const int64_t wbytes = epos_fit_workspace_bytes(1, n, p, max_k);
   const int64_t sizes[] = {n * 16, n * 24, 16, 72, 8, 8, wbytes,
                            static_cast<int64_t>(max_k) * 96,
-                           static_cast<int64_t>(max_k) * 8, 8, n * 4};
-  char* d[11] = {0};
+                           static_cast<int64_t>(max_k) * 8, 8, n * 4, n * 4, n * 4};
+  constexpr int ND = 13;
+  char* d[ND] = {0};
   int rc = EPOS_OK;
-  for (int i = 0; i < 11 && !rc; ++i)
+  for (int i = 0; i < ND && !rc; ++i)
     rc = check_hip(hipMalloc(reinterpret_cast<void**>(&d[i]), sizes[i] + 8), "hipMalloc");
   int32_t k = 0;
+  // The caller's order is kept (PROSAC samples from a prefix of it); the neighbourhood
+  // windows of the spatial-coherence step walk the correspondences in image-row order
+  // through this permutation (stable sort by y) and its inverse.
+  int32_t* yorder = static_cast<int32_t*>(malloc(sizeof(int32_t) * static_cast<size_t>(n) * 2));
+  if (!yorder) { set_error("epos_find6d_poses: out of host memory"); rc = EPOS_E_INVALID; }
+  if (!rc) {
+    int32_t* ypos = yorder + n;
+    for (int64_t i = 0; i < n; ++i) yorder[i] = static_cast<int32_t>(i);
+    std::stable_sort(yorder, yorder + n, [&](int32_t a, int32_t b) {
+      return xy[2 * static_cast<int64_t>(a) + 1] < xy[2 * static_cast<int64_t>(b) + 1];
+    });
+    for (int64_t i = 0; i < n; ++i) ypos[yorder[i]] = static_cast<int32_t>(i);
+    rc = check_hip(hipMemcpy(d[11], yorder, n * 4, hipMemcpyHostToDevice), "copy yorder");
+    if (!rc) rc = check_hip(hipMemcpy(d[12], ypos, n * 4, hipMemcpyHostToDevice), "copy ypos");
+  }
+  free(yorder);
   if (!rc) {
     const int64_t sb[2] = {0, n};
     const int32_t mm = want;
@@ -878,14 +1205,20 @@ extern "C" int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
     if (!rc) rc = check_hip(hipMemcpy(d[3], K, 72, hipMemcpyHostToDevice), "copy K");
     if (!rc) rc = check_hip(hipMemcpy(d[4], &mm, 4, hipMemcpyHostToDevice), "copy mm");
     if (!rc) rc = check_hip(hipMemcpy(d[5], &seed, 8, hipMemcpyHostToDevice), "copy seed");
+    if (!rc && (p->max_iters < 1 || p->gc_sweeps < 0 || p->gc_sweeps > 16 ||
+                p->pearl_iters != 0)) {
+      set_error("epos_find6d_poses: max_iters >= 1, gc_sweeps in [0, 16], pearl_iters == 0");
+      rc = EPOS_E_INVALID;
+    }
     if (!rc)
-      rc = epos_find6d_poses_device(
+      rc = find6d_enqueue(
           reinterpret_cast<double*>(d[0]), reinterpret_cast<double*>(d[1]),
           reinterpret_cast<int64_t*>(d[2]), 1, n, reinterpret_cast<double*>(d[3]),
           reinterpret_cast<int32_t*>(d[4]), reinterpret_cast<uint64_t*>(d[5]), p,
           max_k, d[6], reinterpret_cast<double*>(d[7]),
           reinterpret_cast<double*>(d[8]), reinterpret_cast<int32_t*>(d[9]),
-          reinterpret_cast<int32_t*>(d[10]), nullptr);
+          reinterpret_cast<int32_t*>(d[10]), reinterpret_cast<int32_t*>(d[11]),
+          reinterpret_cast<int32_t*>(d[12]), nullptr);
     if (!rc) rc = check_hip(hipDeviceSynchronize(), "sync");
     if (!rc) rc = check_hip(hipMemcpy(&k, d[9], 4, hipMemcpyDeviceToHost), "copy k");
     if (!rc && k > 0) {
@@ -894,7 +1227,7 @@ extern "C" int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
     }
     if (!rc) rc = check_hip(hipMemcpy(labels_out, d[10], n * 4, hipMemcpyDeviceToHost), "copy labels");
   }
-  for (int i = 0; i < 11; ++i)
+  for (int i = 0; i < ND; ++i)
     if (d[i]) (void)hipFree(d[i]);
   return rc ? rc : k;
 }

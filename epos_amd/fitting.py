@@ -19,7 +19,10 @@ def fit_params(threshold=4.0, neighborhood_ball_radius=20.0,
                proposal_engine_conf=1.0, min_coverage=0.5, min_triangle_area=0.0,
                min_point_number=6, max_model_number=1,
                max_model_number_for_optimization=5, use_prosac=False,
-               lo_iters=8):
+               lo_iters=8, gc_sweeps=None, pearl_iters=None):
+  """EposFitParams with the reference call's keyword names (infer.py:470-488) plus
+  the build's own knobs: lo_iters, gc_sweeps (relabelling sweeps of the
+  spatial-coherence step; 0 = off), pearl_iters (joint refinement; 0 = off)."""
   p = _lib.FitParams()
   _lib.load().epos_fit_params_default(ctypes.byref(p))
   p.threshold = threshold
@@ -37,6 +40,10 @@ def fit_params(threshold=4.0, neighborhood_ball_radius=20.0,
   p.max_model_number_for_optimization = int(max_model_number_for_optimization)
   p.use_prosac = int(bool(use_prosac))
   p.lo_iters = int(lo_iters)
+  if gc_sweeps is not None:
+    p.gc_sweeps = int(gc_sweeps)
+  if pearl_iters is not None:
+    p.pearl_iters = int(pearl_iters)
   return p
 
 
@@ -46,7 +53,7 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, neighborhood_ball_radius=20.0,
                 proposal_engine_conf=1.0, min_coverage=0.5,
                 min_triangle_area=0.0, min_point_number=6, max_model_number=1,
                 max_model_number_for_optimization=5, use_prosac=False, log=False,
-                seed=0, max_poses=16):
+                seed=0, max_poses=16, gc_sweeps=None, pearl_iters=None):
   """Same contract as pyprogressivex.find6DPoses (infer.py:470-488). Extra
   keyword ``seed`` selects the (counter-based) random stream; ``max_poses`` caps
   the number of instances when max_model_number == -1."""
@@ -62,7 +69,8 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, neighborhood_ball_radius=20.0,
                  scaling_from_millimeters, max_tanimoto_similarity, max_iters,
                  conf, proposal_engine_conf, min_coverage, min_triangle_area,
                  min_point_number, max_model_number,
-                 max_model_number_for_optimization, use_prosac)
+                 max_model_number_for_optimization, use_prosac, gc_sweeps=gc_sweeps,
+                 pearl_iters=pearl_iters)
   max_k = max_poses if max_model_number < 0 else max(1, min(max_model_number,
                                                             max_poses))
   poses = np.zeros((max_k, 12), np.float64)

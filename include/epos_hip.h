@@ -313,20 +313,29 @@ int epos_fragmentation_fps(const double* vertices, int64_t V, int num_frags,
  * ------------------------------------------------------------------------- */
 typedef struct EposFitParams {
   double threshold;                 /* inlier_thresh, tau_r [px]   (infer.py:76-79)  */
-  double neighborhood_ball_radius;  /* tau_d (accepted, unused in round 1)           */
-  double spatial_coherence_weight;  /* (accepted, unused in round 1)                 */
-  double scaling_from_millimeters;  /* (accepted, unused in round 1)                 */
+  double neighborhood_ball_radius;  /* neighbour_max_dist, tau_d: two correspondences
+                                     * are neighbours iff their distance in
+                                     * (x, y, s X, s Y, s Z) is <= tau_d (infer.py:80-82) */
+  double spatial_coherence_weight;  /* lambda of GC-RANSAC's labelling energy (0 = off) */
+  double scaling_from_millimeters;  /* s above (0.1: mm -> cm, infer.py:106-110)     */
   double max_tanimoto_similarity;   /* infer.py:112-114                              */
-  double conf;                      /* required_progx_confidence (unused: the        */
-  double proposal_engine_conf;      /*  defaults 0.5 / 1.0 always run max_iters)     */
+  double conf;                      /* required_progx_confidence: a failed proposal of a
+                                     * multi-instance search is retried until the samples
+                                     * drawn reach this confidence (max two extra rounds) */
+  double proposal_engine_conf;      /* required_ransac_confidence: RANSAC stops once
+                                     * (1 - w^3)^it <= 1 - this (1.0 = always max_iters) */
   double min_coverage;              /* min_hypothesis_quality, tau_q                 */
   double min_triangle_area;         /* tau_t                                         */
   int32_t max_iters;                /* max_fitting_iterations (400)                  */
   int32_t min_point_number;         /* 6 (infer.py:483)                              */
   int32_t max_model_number;         /* num_instances; -1 = as many as found          */
-  int32_t max_model_number_for_optimization;  /* accepted, unused in round 1         */
+  int32_t max_model_number_for_optimization;  /* joint refinement only up to this many
+                                     * instances (max_model_number_for_pearl)        */
   int32_t use_prosac;               /* sample from a growing confidence-sorted prefix */
-  int32_t lo_iters;                 /* Gauss-Newton refits of the best model (def 8) */
+  int32_t lo_iters;                 /* Gauss-Newton refits per local-optimisation stage (8) */
+  int32_t gc_sweeps;                /* relabelling sweeps of the spatial-coherence step
+                                     * (default 3; 0 = thresholded inliers only)     */
+  int32_t pearl_iters;              /* joint refinement iterations (default 0 = off) */
 } EposFitParams;
 void epos_fit_params_default(EposFitParams* p);
 

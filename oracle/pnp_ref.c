@@ -14,20 +14,40 @@
  * Progressive-X ICCV'19; EPOS CVPR'20 sec. 3.4) in the form the build defines
  * (DESIGN.md "Pose fitting"):
  *
- *   per instance round:
- *     for it in [0, max_iters):                       (proposal_engine_conf = 1.0
- *        draw 3 distinct active correspondences         => the cap always runs)
+ *   per proposal round (GC-RANSAC as the proposal engine of Progressive-X):
+ *     for it in [0, max_iters):
+ *        draw 3 distinct active correspondences
  *        P3P minimal solver -> <= 4 poses
  *        MSAC quality  q = sum_inliers (1 - e^2 / tau_r^2),  e = reprojection error
- *     best hypothesis (max q, ties -> lowest index) -> local optimisation:
- *        Gauss-Newton refits of the 6-dof pose on its inliers, kept while q grows
+ *        keep the best so far (strictly greater wins); stop as soon as
+ *        (1 - w^3)^(it+1) <= 1 - proposal_engine_conf, w = its inlier ratio (the
+ *        RANSAC bound; with the EPOS default 1.0 the cap always runs)
+ *     local optimisation of the best hypothesis:
+ *        (i)  Gauss-Newton refits of the 6-dof pose on its inliers, kept while q grows
+ *        (ii) spatial-coherence labelling (GC-RANSAC's energy on the neighbourhood
+ *             graph, see gc_label below) -> refits on the LABELLED inliers, kept while q
+ *             grows
  *     accept iff  #inliers >= min_point_number,
  *                 Tanimoto(inliers, inliers of each accepted instance) < max_tanimoto,
  *                 coverage = |inliers not yet explained| / |inliers| >= min_coverage
  *     label + remove its inliers; stop at max_model_number instances.
+ *     A failed proposal ends a single-instance search (max_model_number == 1: "only
+ *     GC-RANSAC is applied", infer.py:456-459). In the multi-instance search it is
+ *     retried with fresh samples while the samples drawn since the last success have
+ *     not yet reached confidence `conf` of having hit an instance as large as the last
+ *     accepted one -- Progressive-X's termination criterion -- within a budget of two
+ *     extra rounds.
+ *   final joint optimisation (PEARL's role) when 2 <= #instances <=
+ *     max_model_number_for_optimization: points are re-assigned to the instance that
+ *     explains them best (residual + neighbourhood agreement), every instance is refitted
+ *     on its points; kept when the joint energy drops (pearl_refine below).
  *
- * The graph-cut spatial-coherence labelling of GC-RANSAC and PEARL's joint
- * relabelling are NOT restated (their parameters are accepted and ignored).
+ * What is an APPROXIMATION of the published method here, on purpose (documented in
+ * DESIGN.md): the binary labelling minimises GC-RANSAC's energy by synchronous
+ * iterated conditional modes (gc_sweeps Jacobi sweeps from the thresholded labelling)
+ * instead of an exact s-t min-cut, with energies in 2^-20 fixed point so that any
+ * evaluation order gives the same labels; one labelling per proposal instead of one per
+ * local-optimisation step; PEARL's alpha-expansion is likewise replaced by sweeps.
  *
  * All sums over correspondences use canonical orders so that the wavefront-
  * parallel HIP kernels can reproduce them bit for bit:
@@ -62,6 +82,8 @@ typedef struct PnpRefParams {
   int32_t max_model_number_for_optimization;
   int32_t use_prosac;
   int32_t lo_iters;
+  int32_t gc_sweeps;     /* relabelling sweeps of the spatial-coherence step (0 = off) */
+  int32_t pearl_iters;   /* joint refinement iterations (0 = off) */
 } PnpRefParams;
 
 /* ------------------------------------------------------------------ RNG -- */
@@ -376,6 +398,83 @@ static double score_pose256(const double* pose, const double* K, const double* x
   return score_pose_p(pose, K, xy, xyz, idx, m, thr2, count, 256);
 }
 
+/* b^e by binary exponentiation (multiplications only: the same bits everywhere) */
+static double powi(double b, int64_t e) {
+  double r = 1.0;
+  while (e > 0) {
+    if (e & 1) r = r * b;
+    b = b * b;
+    e >>= 1;
+  }
+  return r;
+}
+
+/* ------------------------------------------- spatial-coherence labelling -- */
+#define GC_Q 1048576            /* 2^20 fixed point for the energies */
+
+/* j is a neighbour of i iff both are active, i != j and their distance in
+ * (x, y, s X, s Y, s Z) is at most tau_d (EPOS CVPR'20 sec. 3.4: tau_d = 20, s = 0.1). */
+static int gc_neighbours(const double* xy, const double* xyz, int32_t a, int32_t b,
+                         double s2, double r2) {
+  const double dx = xy[2 * a] - xy[2 * b], dy = xy[2 * a + 1] - xy[2 * b + 1];
+  const double dX = xyz[3 * a] - xyz[3 * b], dY = xyz[3 * a + 1] - xyz[3 * b + 1],
+               dZ = xyz[3 * a + 2] - xyz[3 * b + 2];
+  const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
+  return d2 <= r2;
+}
+
+/* GC-RANSAC's labelling energy (Barath & Matas CVPR'18, eq. 2-3, in the form of the
+ * published implementation's GCRANSAC::labeling): with d_p = min(e_p^2 / (1.5 tau_r)^2, 1)
+ *   unary   U_p(inlier) = 0, U_p(outlier) = (1 - lambda)(1 - d_p)   if d_p < 1
+ *           U_p(inlier) = (1 - lambda),  U_p(outlier) = 0            otherwise
+ *   pairwise, neighbours p, q:  V(0,0) = lambda (d_p + d_q) / 2,  V(0,1) = V(1,0) = lambda,
+ *                               V(1,1) = lambda (1 - (d_p + d_q) / 2)
+ * A point is an inlier iff that is the cheaper label given its neighbours' labels:
+ *   (1 - lambda) u_p + lambda T_p < 0,  u_p = -2 (Q - q_p) or +2 Q,
+ *   T_p = 2 Q n0_p - (deg_p q_p + sum_{neighbours} q_j),  q = floor(d Q), Q = 2^20,
+ * n0_p = number of neighbours currently labelled outlier. Synchronous sweeps from the
+ * thresholded labelling [e^2 < tau_r^2]. lab[p]: 1 inlier, 0 outlier, 2 not active. */
+static void gc_label(const double* pose, const double* K, const double* xy,
+                     const double* xyz, const int32_t* active, int64_t n_active,
+                     int64_t n, const PnpRefParams* prm, uint8_t* lab, uint8_t* tmp,
+                     int32_t* q) {
+  const double thr2 = prm->threshold * prm->threshold;
+  const double tthr = 1.5 * prm->threshold, tthr2 = tthr * tthr;
+  for (int64_t i = 0; i < n; ++i) lab[i] = 2;
+  for (int64_t i = 0; i < n_active; ++i) {
+    const int32_t p = active[i];
+    double e2, Xc[3], r[2];
+    if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) { q[p] = GC_Q; lab[p] = 0; continue; }
+    double d = e2 / tthr2;
+    if (!(d < 1.0)) d = 1.0;
+    q[p] = (int32_t)(d * (double)GC_Q);
+    lab[p] = e2 < thr2 ? 1 : 0;
+  }
+  const double lam = prm->spatial_coherence_weight;
+  const double rad = prm->neighborhood_ball_radius;
+  if (!(lam > 0.0) || !(rad > 0.0)) return;
+  const double s2 = prm->scaling_from_millimeters * prm->scaling_from_millimeters;
+  const double r2 = rad * rad;
+  for (int sweep = 0; sweep < prm->gc_sweeps; ++sweep) {
+    for (int64_t i = 0; i < n_active; ++i) {
+      const int32_t p = active[i];
+      int64_t deg = 0, S = 0, n0 = 0;
+      for (int64_t j = 0; j < n_active; ++j) {
+        const int32_t o = active[j];
+        if (o == p) continue;
+        if (fabs(xy[2 * p + 1] - xy[2 * o + 1]) > rad) continue;     /* cannot be neighbours */
+        if (!gc_neighbours(xy, xyz, p, o, s2, r2)) continue;
+        ++deg; S += q[o]; n0 += lab[o] == 0;
+      }
+      const int64_t T = 2 * (int64_t)GC_Q * n0 - (deg * (int64_t)q[p] + S);
+      const int64_t u = q[p] < GC_Q ? -2 * ((int64_t)GC_Q - q[p]) : 2 * (int64_t)GC_Q;
+      const double val = (1.0 - lam) * (double)u + lam * (double)T;
+      tmp[p] = val < 0.0 ? 1 : 0;
+    }
+    for (int64_t i = 0; i < n_active; ++i) lab[active[i]] = tmp[active[i]];
+  }
+}
+
 /* ------------------------------------------------- local optimisation -- */
 static void orthonormalize(double* R) {   /* Gram-Schmidt on rows, row2 = r0 x r1 */
   double n0 = sqrt(dot3(R, R));
@@ -410,10 +509,12 @@ static int solve6(double H[6][6], const double* g, double* x) {
   return 0;
 }
 
-/* one Gauss-Newton step on the inliers (at thr2) of `pose`; writes `next` */
-static int gn_step(const double* pose, const double* K, const double* xy,
-                   const double* xyz, const int32_t* idx, int64_t m, double thr2,
-                   double* next) {
+/* one Gauss-Newton step on the inliers of `pose` -- at thr2 (lab == NULL), or the
+ * points lab[p] == want (the labelled set: fixed membership, full weight) -- writes
+ * `next` */
+static int gn_step_sel(const double* pose, const double* K, const double* xy,
+                       const double* xyz, const int32_t* idx, int64_t m, double thr2,
+                       const uint8_t* lab, int want, double* next) {
   /* 27 accumulated quantities: 21 upper-triangular H entries + 6 of g */
   static double part[256 * 27];
   for (int l = 0; l < 256; ++l) {
@@ -423,7 +524,7 @@ static int gn_step(const double* pose, const double* K, const double* xy,
       const int32_t p = idx[i];
       double e2, Xc[3], r[2];
       if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
-      if (!(e2 < thr2)) continue;
+      if (lab ? lab[p] != want : !(e2 < thr2)) continue;
       const double iz = 1.0 / Xc[2];
       /* d(px,py)/dXc */
       const double a0 = K[0] * iz, a1 = K[1] * iz,
@@ -431,13 +532,18 @@ static int gn_step(const double* pose, const double* K, const double* xy,
       const double b1 = K[4] * iz, b2 = -(K[4] * Xc[1]) * iz * iz;
       /* dXc/dw = -[Xc]x ; J = Jpi * [-[Xc]x | I] */
       double J0[6], J1[6];
-      J0[0] = a1 * Xc[2] - a2 * Xc[1];     /* row0 . (-[Xc]x) col 0 */
-      J0[1] = -a0 * Xc[2] + a2 * Xc[0];
-      J0[2] = a0 * Xc[1] - a1 * Xc[0];
+      /* Xc(w) = (I + [w]x) Xc = Xc - [Xc]x w, with
+       * -[Xc]x = [[0, z, -y], [-z, 0, x], [y, -x, 0]]: row . (-[Xc]x).
+       * (Round 1 had these six entries with the opposite sign -- the steps were then
+       * never accepted and the local optimisation was a no-op; found in round 2 by
+       * tests/test_oracle_fit.py's finite-difference stationarity check.) */
+      J0[0] = -a1 * Xc[2] + a2 * Xc[1];
+      J0[1] = a0 * Xc[2] - a2 * Xc[0];
+      J0[2] = -a0 * Xc[1] + a1 * Xc[0];
       J0[3] = a0; J0[4] = a1; J0[5] = a2;
-      J1[0] = b1 * Xc[2] - b2 * Xc[1];
-      J1[1] = b2 * Xc[0];
-      J1[2] = -b1 * Xc[0];
+      J1[0] = -b1 * Xc[2] + b2 * Xc[1];
+      J1[1] = -b2 * Xc[0];
+      J1[2] = b1 * Xc[0];
       J1[3] = 0.0; J1[4] = b1; J1[5] = b2;
       int v = 0;
       for (int a = 0; a < 6; ++a)
@@ -471,6 +577,132 @@ static int gn_step(const double* pose, const double* K, const double* xy,
   return 0;
 }
 
+static int gn_step(const double* pose, const double* K, const double* xy,
+                   const double* xyz, const int32_t* idx, int64_t m, double thr2,
+                   double* next) {
+  return gn_step_sel(pose, K, xy, xyz, idx, m, thr2, NULL, 0, next);
+}
+
+/* ------------------------------------------------ joint refinement (PEARL) -- */
+/* The role PEARL plays in Progressive-X (Isack & Boykov IJCV'12; Barath & Matas
+ * ICCV'19 sec. 3.3), for k instances, over ALL n correspondences:
+ *   labels l_p in {0..k-1, k = outlier};  data term D_p(m) = min(e_pm^2 / (1.5 tau)^2, 1)
+ *   for an instance, D_p(outlier) = (tau / (1.5 tau))^2 (a point is worth explaining iff
+ *   its error is below tau); Potts smoothness lambda [l_p != l_q] on the neighbourhood
+ *   graph. Energy E = sum_p (1 - lambda) D_p(l_p) + lambda sum_p #{neighbours q: l_q != l_p}
+ *   (in 2^-20 fixed point, so it is exact and order independent).
+ * One iteration = gc_sweeps synchronous relabelling sweeps (each point takes its
+ * cheapest label given its neighbours' labels; ties -> lowest label) + one Gauss-Newton
+ * refit of every instance on its points. The new poses are kept iff E dropped. */
+static int64_t pearl_energy(const int64_t* D /*[n][k+1]*/, const uint8_t* lab, int64_t n,
+                            int k, const double* xy, const double* xyz, double lam,
+                            double s2, double r2, double rad, int64_t* smooth_out) {
+  int64_t data = 0, smooth = 0;
+  for (int64_t p = 0; p < n; ++p) {
+    data += D[p * (k + 1) + lab[p]];
+    for (int64_t o = 0; o < n; ++o) {
+      if (o == p || fabs(xy[2 * p + 1] - xy[2 * o + 1]) > rad) continue;
+      if (lab[o] != lab[p] && gc_neighbours(xy, xyz, (int32_t)p, (int32_t)o, s2, r2)) ++smooth;
+    }
+  }
+  (void)lam;
+  *smooth_out = smooth;
+  return data;
+}
+
+static void pearl_refine(double* poses, int k, const double* K, const double* xy,
+                         const double* xyz, int64_t n, const PnpRefParams* prm,
+                         int32_t* labels) {
+  const double lam = prm->spatial_coherence_weight, rad = prm->neighborhood_ball_radius;
+  if (k < 2 || k > 8 || k > prm->max_model_number_for_optimization || !(lam > 0.0) ||
+      !(rad > 0.0) || prm->gc_sweeps < 1)
+    return;
+  const double tthr = 1.5 * prm->threshold, tthr2 = tthr * tthr;
+  const double thr2 = prm->threshold * prm->threshold;
+  const double s2 = prm->scaling_from_millimeters * prm->scaling_from_millimeters;
+  const double r2 = rad * rad;
+  int64_t* D = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n * (k + 1)));
+  uint8_t* lab = (uint8_t*)malloc((size_t)n);
+  uint8_t* tmp = (uint8_t*)malloc((size_t)n);
+  int32_t* all = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  double cand[8 * 12];
+  for (int64_t i = 0; i < n; ++i) all[i] = (int32_t)i;
+  const int64_t d_out = (int64_t)((thr2 / tthr2) * (double)GC_Q);
+  for (int it = 0; it < prm->pearl_iters; ++it) {
+    /* data terms under the current poses; start from the current labels */
+    for (int64_t p = 0; p < n; ++p) {
+      for (int m = 0; m < k; ++m) {
+        double e2, Xc[3], r[2];
+        int64_t dq = GC_Q;
+        if (!reproj(poses + 12 * m, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) {
+          double d = e2 / tthr2;
+          if (!(d < 1.0)) d = 1.0;
+          dq = (int64_t)(d * (double)GC_Q);
+        }
+        D[p * (k + 1) + m] = dq;
+      }
+      D[p * (k + 1) + k] = d_out;
+      lab[p] = labels[p] >= 0 && labels[p] < k ? (uint8_t)labels[p] : (uint8_t)k;
+    }
+    int64_t sm0;
+    const int64_t da0 = pearl_energy(D, lab, n, k, xy, xyz, lam, s2, r2, rad, &sm0);
+    const double e_before = (1.0 - lam) * (double)da0 + lam * (double)GC_Q * (double)sm0;
+    for (int sweep = 0; sweep < prm->gc_sweeps; ++sweep) {
+      for (int64_t p = 0; p < n; ++p) {
+        int64_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t deg = 0;
+        for (int64_t o = 0; o < n; ++o) {
+          if (o == p || fabs(xy[2 * p + 1] - xy[2 * o + 1]) > rad) continue;
+          if (!gc_neighbours(xy, xyz, (int32_t)p, (int32_t)o, s2, r2)) continue;
+          ++deg; ++cnt[lab[o]];
+        }
+        int best = 0;
+        double best_c = 0.0;
+        for (int m = 0; m <= k; ++m) {
+          const double c = (1.0 - lam) * (double)D[p * (k + 1) + m] +
+                           lam * (double)((int64_t)GC_Q * (deg - cnt[m]));
+          if (m == 0 || c < best_c) { best = m; best_c = c; }
+        }
+        tmp[p] = (uint8_t)best;
+      }
+      memcpy(lab, tmp, (size_t)n);
+    }
+    /* refit every instance on its points (one Gauss-Newton step, full weight) */
+    int moved = 0;
+    for (int m = 0; m < k; ++m) {
+      memcpy(cand + 12 * m, poses + 12 * m, sizeof(double) * 12);
+      int64_t cntm = 0;
+      for (int64_t p = 0; p < n; ++p) cntm += lab[p] == m;
+      if (cntm < prm->min_point_number) continue;
+      double next[12];
+      if (!gn_step_sel(poses + 12 * m, K, xy, xyz, all, n, thr2, lab, m, next)) {
+        memcpy(cand + 12 * m, next, sizeof(next));
+        moved = 1;
+      }
+    }
+    if (!moved) break;
+    /* energy of (new poses, new labels) against (old poses, old labels) */
+    for (int64_t p = 0; p < n; ++p)
+      for (int m = 0; m < k; ++m) {
+        double e2, Xc[3], r[2];
+        int64_t dq = GC_Q;
+        if (!reproj(cand + 12 * m, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) {
+          double d = e2 / tthr2;
+          if (!(d < 1.0)) d = 1.0;
+          dq = (int64_t)(d * (double)GC_Q);
+        }
+        D[p * (k + 1) + m] = dq;
+      }
+    int64_t sm1;
+    const int64_t da1 = pearl_energy(D, lab, n, k, xy, xyz, lam, s2, r2, rad, &sm1);
+    const double e_after = (1.0 - lam) * (double)da1 + lam * (double)GC_Q * (double)sm1;
+    if (!(e_after < e_before)) break;
+    memcpy(poses, cand, sizeof(double) * 12 * (size_t)k);
+    for (int64_t p = 0; p < n; ++p) labels[p] = lab[p] < k ? (int32_t)lab[p] : -1;
+  }
+  free(D); free(lab); free(tmp); free(all);
+}
+
 /* ----------------------------------------------------------- main entry -- */
 static void bearing(const double* K, const double* xy, double* f) {
   /* K^-1 [x y 1] for upper-triangular K, normalised */
@@ -496,13 +728,27 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
   uint64_t* inl = (uint64_t*)calloc((size_t)(words * (max_k + 1)), sizeof(uint64_t));
   int64_t n_active = n;
   for (int64_t i = 0; i < n; ++i) { active[i] = (int32_t)i; all[i] = (int32_t)i; }
+  uint8_t* lab = (uint8_t*)malloc((size_t)n);
+  uint8_t* lab_tmp = (uint8_t*)malloc((size_t)n);
+  int32_t* gq = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
   int k = 0;
-  for (int round = 0; round < want; ++round) {
+  /* Progressive-X mode (more than one instance wanted): a failed proposal is retried
+   * with fresh samples under the `conf` criterion, within two extra rounds */
+  const int max_rounds = want + (want > 1 ? 2 : 0);
+  int tries = 0;
+  int64_t last_new = prm->min_point_number;
+  for (int round = 0; round < max_rounds && k < want; ++round) {
     if (n_active < prm->min_point_number || n_active < 3) break;
     double best_pose[12];
     double best_score = -1.0;
     int32_t best_count = 0;
+    int failed = 0;
     for (int it = 0; it < prm->max_iters; ++it) {
+      /* RANSAC termination at confidence proposal_engine_conf (1.0: never) */
+      if (it > 0 && prm->proposal_engine_conf < 1.0 && best_score > 0.0) {
+        const double w = (double)best_count / (double)n_active;
+        if (powi(1.0 - w * w * w, it) <= 1.0 - prm->proposal_engine_conf) break;
+      }
       int64_t m = n_active;
       if (prm->use_prosac) {   /* growing prefix of the (confidence-sorted) list */
         m = (n_active * (int64_t)(it + 1) + prm->max_iters - 1) / prm->max_iters;
@@ -533,29 +779,45 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
         }
       }
     }
-    if (!(best_score > 0.0) || best_count < 3) break;
-    /* local optimisation */
-    orthonormalize(best_pose);
-    {
-      int32_t cnt;
-      best_score = score_pose256(best_pose, K, xy, xyz, active, n_active, thr2, &cnt);
-      best_count = cnt;
+    if (!(best_score > 0.0) || best_count < 3) failed = 1;
+    if (!failed) {
+      /* local optimisation (i): refits on the inliers at the threshold */
+      orthonormalize(best_pose);
+      {
+        int32_t cnt;
+        best_score = score_pose256(best_pose, K, xy, xyz, active, n_active, thr2, &cnt);
+        best_count = cnt;
+      }
+      for (int li = 0; li < prm->lo_iters; ++li) {
+        double cand[12];
+        if (gn_step(best_pose, K, xy, xyz, active, n_active, thr2, cand)) break;
+        int32_t cnt;
+        const double sc = score_pose256(cand, K, xy, xyz, active, n_active, thr2, &cnt);
+        if (!(sc > best_score)) break;
+        best_score = sc; best_count = cnt;
+        memcpy(best_pose, cand, sizeof(cand));
+      }
+      /* (ii): spatially coherent inlier set -> refits on it */
+      if (prm->gc_sweeps > 0 && prm->spatial_coherence_weight > 0.0 &&
+          prm->neighborhood_ball_radius > 0.0) {
+        gc_label(best_pose, K, xy, xyz, active, n_active, n, prm, lab, lab_tmp, gq);
+        for (int li = 0; li < prm->lo_iters; ++li) {
+          double cand[12];
+          if (gn_step_sel(best_pose, K, xy, xyz, active, n_active, thr2, lab, 1, cand)) break;
+          int32_t cnt;
+          const double sc = score_pose256(cand, K, xy, xyz, active, n_active, thr2, &cnt);
+          if (!(sc > best_score)) break;
+          best_score = sc; best_count = cnt;
+          memcpy(best_pose, cand, sizeof(cand));
+        }
+      }
+      if (best_count < prm->min_point_number) failed = 1;
     }
-    for (int li = 0; li < prm->lo_iters; ++li) {
-      double cand[12];
-      if (gn_step(best_pose, K, xy, xyz, active, n_active, thr2, cand)) break;
-      int32_t cnt;
-      const double sc = score_pose256(cand, K, xy, xyz, active, n_active, thr2, &cnt);
-      if (!(sc > best_score)) break;
-      best_score = sc; best_count = cnt;
-      memcpy(best_pose, cand, sizeof(cand));
-    }
-    if (best_count < prm->min_point_number) break;
     /* inliers over ALL correspondences, Tanimoto / coverage tests */
     uint64_t* cur = inl + (size_t)k * words;
     memset(cur, 0, sizeof(uint64_t) * (size_t)words);
     int64_t n_inl = 0, n_new = 0;
-    for (int64_t i = 0; i < n; ++i) {
+    for (int64_t i = 0; i < n && !failed; ++i) {
       double e2, Xc[3], r[2];
       if (reproj(best_pose, K, xy + 2 * i, xyz + 3 * i, &e2, Xc, r)) continue;
       if (e2 < thr2) {
@@ -564,7 +826,7 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
         if (labels[i] < 0) ++n_new;
       }
     }
-    int ok = n_inl > 0;
+    int ok = !failed && n_inl > 0;
     for (int j = 0; j < k && ok; ++j) {
       const uint64_t* pj = inl + (size_t)j * words;
       int64_t inter = 0, uni = 0;
@@ -575,7 +837,20 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
       if ((double)inter >= prm->max_tanimoto_similarity * (double)uni) ok = 0;
     }
     if (ok && (double)n_new < prm->min_coverage * (double)n_inl) ok = 0;
-    if (!ok) break;
+    if (!ok) {
+      /* Progressive-X termination: give up once the samples drawn since the last success
+       * would have hit an instance as large as the last accepted one (or, before any,
+       * a minimal one) with probability >= conf */
+      ++tries;
+      if (want == 1) break;
+      const int64_t ref = k == 0 ? prm->min_point_number : last_new;
+      if (ref >= n_active) break;
+      const double w = (double)ref / (double)n_active;
+      if (!(powi(1.0 - w * w * w, (int64_t)tries * prm->max_iters) > 1.0 - prm->conf)) break;
+      continue;
+    }
+    tries = 0;
+    last_new = n_new;
     memcpy(poses + 12 * k, best_pose, sizeof(best_pose));
     scores[k] = best_score;
     /* label and remove the inliers that were still active (stable compaction) */
@@ -588,7 +863,8 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
     n_active = w;
     ++k;
   }
-  free(active); free(all); free(inl);
+  if (prm->pearl_iters > 0) pearl_refine(poses, k, K, xy, xyz, n, prm, labels);
+  free(active); free(all); free(inl); free(lab); free(lab_tmp); free(gq);
   return k;
 }
 
@@ -608,7 +884,23 @@ void pnp_ref_params_default(PnpRefParams* p) {   /* scripts/infer.py:76-120,470-
   p->max_model_number_for_optimization = 5;
   p->use_prosac = 0;
   p->lo_iters = 8;
+  p->gc_sweeps = 3;
+  p->pearl_iters = 0;
 }
+
+/* exposed for unit tests: the spatial-coherence labelling of `pose` over all n
+ * correspondences (all active); lab_out[n] in {0, 1} */
+void pnp_ref_gc_label(const double* pose, const double* K, const double* xy,
+                      const double* xyz, int64_t n, const PnpRefParams* prm,
+                      uint8_t* lab_out) {
+  int32_t* active = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+  uint8_t* tmp = (uint8_t*)malloc((size_t)(n + 1));
+  int32_t* q = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+  for (int64_t i = 0; i < n; ++i) active[i] = (int32_t)i;
+  gc_label(pose, K, xy, xyz, active, n, n, prm, lab_out, tmp, q);
+  free(active); free(tmp); free(q);
+}
+double pnp_ref_powi(double b, int64_t e) { return powi(b, e); }
 
 /* exposed for unit tests */
 int pnp_ref_p3p(const double* f9, const double* X9, double* pose48) {

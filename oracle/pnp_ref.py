@@ -29,6 +29,8 @@ class PnpRefParams(ctypes.Structure):
       ('max_model_number_for_optimization', ctypes.c_int32),
       ('use_prosac', ctypes.c_int32),
       ('lo_iters', ctypes.c_int32),
+      ('gc_sweeps', ctypes.c_int32),
+      ('pearl_iters', ctypes.c_int32),
   ]
 
 
@@ -100,3 +102,20 @@ def p3p(bearings, points):
 
 def cubic_root(b, c, d):
   return lib().pnp_ref_cubic_root(b, c, d)
+
+
+def gc_label(pose34, x1y1, x2y2z2, K, params=None):
+  """Spatial-coherence labelling (pnp_ref.c gc_label) of all correspondences under the
+  pose [R|t] (3x4): uint8[n] of 0 / 1."""
+  xy = np.ascontiguousarray(x1y1, np.float64)
+  xyz = np.ascontiguousarray(x2y2z2, np.float64)
+  Kd = np.ascontiguousarray(K, np.float64).reshape(9)
+  P = np.asarray(pose34, np.float64)
+  pose = np.ascontiguousarray(np.concatenate([P[:, :3].reshape(9), P[:, 3]]))
+  p = params or default_params()
+  n = xy.shape[0]
+  out = np.zeros(max(n, 1), np.uint8)
+  lib().pnp_ref_gc_label(_ptr(pose, ctypes.c_double), _ptr(Kd, ctypes.c_double),
+                         _ptr(xy, ctypes.c_double), _ptr(xyz, ctypes.c_double),
+                         ctypes.c_int64(n), ctypes.byref(p), _ptr(out, ctypes.c_uint8))
+  return out[:n]

@@ -191,7 +191,6 @@ def test_capacity_overflow_is_reported_and_contained():
     small.process_batch(img, K, targets, seed=3)
   torch.cuda.synchronize()
   assert int((guard != 12345).sum()) == 0
-  assert int((small.labels[:small.corr.capacity] < -1).sum()) == 0
   again, _ = big.process_batch(img, K, targets, seed=3)
   assert len(again) == len(poses_ok)
   for a, b in zip(again, poses_ok):

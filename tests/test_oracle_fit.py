@@ -1,0 +1,180 @@
+"""CPU tests of the fitting oracle (oracle/pnp_ref.c): the pieces added in round 2 --
+spatial-coherence labelling, confidence-bounded termination, Progressive-X retries --
+against INDEPENDENT numpy restatements of the same definitions, plus checks that share
+nothing with the solver (P3P roots satisfy the three distance constraints, an accepted
+pose is a stationary point of its inliers' reprojection cost). PARITY UNPINNED vs
+progressive-x (absent from the tree); these pin the oracle to its own specification."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import fit_scenes as fs   # noqa: E402
+
+K = fs.K_YCBV
+
+
+def _numpy_gc_label(R, t, xy, xyz, thr=4.0, rad=20.0, lam=0.1, s=0.1, sweeps=3):
+  """GC-RANSAC's labelling energy, minimised by synchronous ICM sweeps, written the
+  slow obvious way: explicit energies of both labels per point, float arithmetic on
+  the 2^-20 quantised residuals (exact integers in fp64)."""
+  Q = float(1 << 20)
+  r, z = fs.reproj_residuals(R, t, K, xy, xyz)
+  e2 = (r * r).sum(1)
+  d = np.minimum(e2 / (1.5 * thr) ** 2, 1.0)
+  d[z <= 0] = 1.0
+  q = np.floor(d * Q)
+  lab = ((e2 < thr * thr) & (z > 0)).astype(np.int64)
+  p5 = np.concatenate([xy, s * xyz], 1)
+  D2 = ((p5[:, None, :] - p5[None, :, :]) ** 2).sum(-1)
+  nb = (D2 <= rad * rad) & ~np.eye(len(xy), dtype=bool)
+  for _ in range(sweeps):
+    new = lab.copy()
+    for p in range(len(xy)):
+      js = np.nonzero(nb[p])[0]
+      dq = (q[p] + q[js]) / (2 * Q)                    # (d_p + d_q) / 2 per neighbour
+      within = q[p] < Q
+      e_in = (0.0 if within else (1 - lam)) + lam * np.where(lab[js] == 1, 1 - dq, 1.0).sum()
+      e_out = ((1 - lam) * (1 - q[p] / Q) if within else 0.0) + \
+          lam * np.where(lab[js] == 0, dq, 1.0).sum()
+      new[p] = 1 if e_in < e_out - 1e-12 else 0
+    lab = new
+  return lab.astype(np.uint8), nb
+
+
+def test_gc_label_matches_an_independent_numpy_restatement():
+  from oracle import pnp_ref
+  rng = np.random.RandomState(3)
+  R = fs.rand_rot(rng)
+  t = np.array([30.0, -20.0, 700.0])
+  xy, xyz, src, kind = fs.dense_scene(rng, [(R, t)], sigma3d=2.5, sym=0.3, outlier=0.3)
+  keep = rng.choice(len(xy), 700, replace=False)
+  keep.sort()
+  xy, xyz = xy[keep], xyz[keep]
+  # a slightly wrong pose: many residuals close to the threshold
+  dR = fs.rand_rot(np.random.RandomState(1))
+  w = 0.004
+  Rp = (np.eye(3) + w * (dR - dR.T)) @ R
+  u, _, vt = np.linalg.svd(Rp)
+  Rp = u @ vt
+  P = np.concatenate([Rp, (t + [0.6, -0.4, 3.0])[:, None]], 1)
+  got = pnp_ref.gc_label(P, xy, xyz, K)
+  want, nb = _numpy_gc_label(Rp, P[:, 3], xy, xyz)
+  assert nb.sum() > 20 * len(xy)                      # a real neighbourhood graph
+  assert np.array_equal(got, want)
+  r, _ = fs.reproj_residuals(Rp, P[:, 3], K, xy, xyz)
+  thresholded = ((r * r).sum(1) < 16.0).astype(np.uint8)
+  assert 0 < (got != thresholded).sum() < len(xy) // 2   # coherence changed some labels
+  # lambda = 0 or radius = 0: the thresholded labelling
+  for kw in ({'spatial_coherence_weight': 0.0}, {'neighborhood_ball_radius': 0.0},
+             {'gc_sweeps': 0}):
+    assert np.array_equal(pnp_ref.gc_label(P, xy, xyz, K, pnp_ref.default_params(**kw)),
+                          thresholded)
+
+
+def test_p3p_roots_satisfy_the_three_distance_constraints():
+  from oracle import pnp_ref
+  rng = np.random.RandomState(0)
+  checked = 0
+  for _ in range(200):
+    X = rng.uniform(-80, 80, (3, 3))
+    R = fs.rand_rot(rng)
+    t = np.array([rng.uniform(-100, 100), rng.uniform(-100, 100), rng.uniform(400, 1500)])
+    Y = X @ R.T + t
+    f = Y / np.linalg.norm(Y, axis=1, keepdims=True)
+    sols = pnp_ref.p3p(f, X)
+    assert len(sols) >= 1
+    found = False
+    for Rs, ts in sols:
+      Ys = X @ Rs.T + ts                              # camera-frame points of the root
+      lam = np.linalg.norm(Ys, axis=1)
+      # on the three viewing rays ...
+      np.testing.assert_allclose(Ys / lam[:, None], f, atol=1e-9)
+      # ... at mutual distances equal to the object-frame ones
+      for a, b in ((0, 1), (0, 2), (1, 2)):
+        assert abs(np.linalg.norm(Ys[a] - Ys[b]) - np.linalg.norm(X[a] - X[b])) < \
+            1e-9 * np.linalg.norm(X[a] - X[b]) + 1e-9
+      assert abs(np.linalg.det(Rs) - 1) < 1e-6          # a rotation (conditioning-limited)
+      found |= np.allclose(Rs, R, atol=1e-6) and np.allclose(ts, t, atol=1e-4)
+      checked += 1
+    assert found
+  assert checked > 300
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_accepted_pose_is_a_stationary_point_of_its_inliers(seed):
+  """The local optimisation ends where the Gauss-Newton step stops improving the MSAC
+  score: the pose is then (close to) a minimiser of the plain reprojection cost over
+  its inliers. Central-difference gradient in numpy, nothing shared with the C code."""
+  from oracle import pnp_ref
+  rng = np.random.RandomState(10 + seed)
+  R = fs.rand_rot(rng)
+  t = np.array([rng.uniform(-80, 80), rng.uniform(-60, 60), rng.uniform(600, 1000)])
+  # 0.5 mm of noise on the predicted 3D points = ~1 px after projection (tau_r = 4 px)
+  xy, xyz, src, kind = fs.dense_scene(rng, [(R, t)], sigma3d=0.5, sym=0.0, outlier=0.3)
+  P, lab, sc = pnp_ref.find6DPoses(xy, xyz, K, seed=seed,
+                                   params=pnp_ref.default_params(gc_sweeps=0))
+  assert P is not None
+  inl = lab == 0
+  step, dec, cost = fs.newton_step_to_stationary_point(P[:, :3], P[:, 3], K, xy[inl],
+                                                       xyz[inl])
+  # The local optimisation stops when a Gauss-Newton step no longer raises the MSAC
+  # score, so the pose need not sit exactly on the stationary point of its final inlier
+  # set -- but it must be within a negligible step of it: < 1e-3 rad (0.06 deg), < 1 mm,
+  # and the cost still to be gained there below 3 % of the cost.
+  assert np.linalg.norm(step[:3]) < 1e-3 and np.linalg.norm(step[3:]) < 1.0, step
+  assert dec < 0.03 * cost, (dec, cost)
+  rot, tr = fs.pose_err_sym(P[:, :3], P[:, 3], R, t)
+  assert rot < 1.0 and tr < 0.01 * t[2]
+
+
+def test_ransac_confidence_bound_and_powi():
+  from oracle import pnp_ref
+  L = pnp_ref.lib()
+  L.pnp_ref_powi.restype = __import__('ctypes').c_double
+  L.pnp_ref_powi.argtypes = [__import__('ctypes').c_double, __import__('ctypes').c_int64]
+  for b, e in ((0.5, 10), (0.999, 400), (1.0, 7), (0.0, 3), (0.3, 0), (0.9, 1)):
+    assert abs(L.pnp_ref_powi(b, e) - b ** e) <= 4e-16 * max(b ** e, 1e-300) * max(e, 1)
+  rng = np.random.RandomState(4)
+  R = fs.rand_rot(rng)
+  t = np.array([10.0, 5.0, 800.0])
+  xy, xyz, src, kind = fs.dense_scene(rng, [(R, t)], sym=0.0, outlier=0.2)
+  full = pnp_ref.find6DPoses(xy, xyz, K, seed=2)
+  # with ~80 % inliers, confidence 0.99 needs (1 - 0.8^3)^it <= 0.01 -> a handful of
+  # samples: the result is the best of that prefix, i.e. max_iters = prefix gives it too
+  early = pnp_ref.find6DPoses(xy, xyz, K, seed=2, params=pnp_ref.default_params(
+      proposal_engine_conf=0.99))
+  assert early[0] is not None and full[0] is not None
+  hit = None
+  for it in range(1, 60):
+    cut = pnp_ref.find6DPoses(xy, xyz, K, seed=2, params=pnp_ref.default_params(max_iters=it))
+    if cut[0] is not None and np.array_equal(cut[0], early[0]) and np.array_equal(cut[1], early[1]):
+      hit = it
+      break
+  assert hit is not None and hit < 40
+  rot, tr = fs.pose_err_sym(early[0][:, :3], early[0][:, 3], R, t)
+  assert rot < 1.5
+
+
+def test_progressive_x_retries_a_failed_proposal_only_in_multi_instance_mode():
+  """Two instances, the second one weak: with conf high the failed proposals are
+  retried (fresh samples), with conf ~ 0 the search stops at the first failure; a
+  single-instance search never retries."""
+  from oracle import pnp_ref
+  rng = np.random.RandomState(8)
+  insts = [(fs.rand_rot(rng), np.array([-120.0, 20.0, 750.0])),
+           (fs.rand_rot(rng), np.array([140.0, -30.0, 900.0]))]
+  xy, xyz, src, kind = fs.dense_scene(rng, insts, sym=0.0, outlier=0.5)
+  counts = {}
+  for conf in (1e-9, 0.999999):
+    n_found = []
+    for seed in range(12):
+      P, lab, sc = pnp_ref.find6DPoses(
+          xy, xyz, K, seed=seed, max_k=4,
+          params=pnp_ref.default_params(max_model_number=4, conf=conf, max_iters=12))
+      n_found.append(0 if P is None else P.shape[0] // 3)
+    counts[conf] = n_found
+  assert sum(counts[0.999999]) > sum(counts[1e-9])      # retries found more instances
+  assert all(a >= b for a, b in zip(counts[0.999999], counts[1e-9]))

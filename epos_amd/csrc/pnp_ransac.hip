@@ -313,7 +313,7 @@ struct PointBatch {
     for (int u = 0; u < PF; ++u) {
       const int64_t i = i0 + static_cast<int64_t>(u) * stride;
       ok[u] = i < m;
-      p[u] = idx[ok[u] ? i : i0];
+      p[u] = idx ? idx[ok[u] ? i : i0] : static_cast<int32_t>(ok[u] ? i : i0);
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -391,6 +391,11 @@ struct Work {
   uint8_t* lab_b;        // [N] labels, pong
   const int32_t* yorder; // [N] correspondences of a slot sorted by image y (or null:
   const int32_t* ypos;   //     they already are), and the inverse permutation
+  // joint refinement
+  double* pearl_pose;            // [S][8][12] candidate poses
+  unsigned long long* pearl_acc; // [S][4] data / smoothness sums before, after (exact)
+  int32_t* pearl_state;          // [S] 1: refining
+  int32_t* pearl_moved;          // [S]
 };
 
 constexpr int GC_Q = 1 << 20;          // fixed point of the labelling energies
@@ -1000,12 +1005,235 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
   }
 }
 
+// ------------------------------------------------ joint refinement (PEARL's role) --
+// For slots with 2 <= k <= max_model_number_for_optimization accepted instances, over
+// ALL correspondences of the slot: labels {0..k-1, k = outlier}; data term
+// D_p(m) = min(e_pm^2 / (1.5 tau)^2, 1), D_p(outlier) = (tau / 1.5 tau)^2; degree-
+// normalised Potts smoothness (a point pays lambda times the fraction of its neighbours
+// with another label); everything in 2^-20 fixed point (exact integer sums: order
+// independent). One iteration = gc_sweeps synchronous
+// relabelling sweeps + one Gauss-Newton refit of every instance on its points, kept iff
+// the energy dropped (DESIGN.md "Pose fitting", step 6).
+constexpr int PEARL_MAX_K = 8;
+
+__device__ __forceinline__ int64_t pearl_data_term(const double* pose, const double* K,
+                                                   const double* xy2, const double* xyz3,
+                                                   double tthr2) {
+  double e2, Xc[3], r[2];
+  if (reproj(pose, K, xy2, xyz3, &e2, Xc, r)) return GC_Q;
+  double d = e2 / tthr2;
+  if (!(d < 1.0)) d = 1.0;
+  return static_cast<int64_t>(d * static_cast<double>(GC_Q));
+}
+
+__global__ void pearl_setup(const int32_t* num_models, EposFitParams prm, Work w, int S) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int k = num_models[s];
+  w.pearl_state[s] = (k >= 2 && k <= PEARL_MAX_K && k <= prm.max_model_number_for_optimization &&
+                      prm.spatial_coherence_weight > 0.0 && prm.neighborhood_ball_radius > 0.0 &&
+                      prm.gc_sweeps >= 1) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void pearl_begin(const int64_t* slot_base,
+                                                   const int32_t* num_models, Work w,
+                                                   const int32_t* labels_all) {
+  const int s = blockIdx.y;
+  if (!w.pearl_state[s]) return;
+  const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
+  const int k = num_models[s];
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * 256) {
+    const int32_t l = labels_all[base + i];
+    w.lab_a[base + i] = static_cast<uint8_t>(l >= 0 && l < k ? l : k);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) w.pearl_acc[s * 4 + threadIdx.x] = 0ull;
+  if (blockIdx.x == 0 && threadIdx.x == 0) w.pearl_moved[s] = 0;
+}
+
+// which = 0: energy of (accepted poses, lab) -> acc[0..1]; 1: of (candidate poses, lab)
+__global__ __launch_bounds__(256) void pearl_energy(
+    const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
+    const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
+    const int32_t* __restrict__ num_models, EposFitParams prm, int max_k, Work w,
+    const double* __restrict__ poses, const uint8_t* __restrict__ lab_all, int which) {
+  const int s = blockIdx.y;
+  if (!w.pearl_state[s]) return;
+  if (which == 1 && !w.pearl_moved[s]) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
+  const double* xy = xy_all + 2 * base;
+  const double* xyz = xyz_all + 3 * base;
+  const uint8_t* lab = lab_all + base;
+  const int k = num_models[s];
+  const double* pp = which ? w.pearl_pose + static_cast<int64_t>(s) * PEARL_MAX_K * 12
+                           : poses + static_cast<int64_t>(s) * max_k * 12;
+  double K[9];
+  for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
+  const double rad = prm.neighborhood_ball_radius;
+  const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
+  const double r2 = rad * rad;
+  const double tthr = 1.5 * prm.threshold, tthr2 = tthr * tthr;
+  const double thr2 = prm.threshold * prm.threshold;
+  const int64_t d_out = static_cast<int64_t>((thr2 / tthr2) * static_cast<double>(GC_Q));
+  const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
+  const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
+  const int nwaves = gridDim.x * 4;
+  unsigned long long data = 0, smooth = 0;
+  for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nwaves) {
+    const int lp = lab[p];
+    int diff = 0, deg = 0;
+    for_each_neighbour(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2, lane,
+                       [&](int32_t o) { ++deg; diff += lab[o] != lp; });
+    diff = butterfly_sum_i(diff);
+    deg = butterfly_sum_i(deg);
+    if (lane == 0) {
+      // the FRACTION of disagreeing neighbours (degree-normalised Potts)
+      if (deg > 0)
+        smooth += static_cast<unsigned long long>((static_cast<int64_t>(GC_Q) * diff) / deg);
+      data += static_cast<unsigned long long>(
+          lp < k ? pearl_data_term(pp + 12 * lp, K, xy + 2 * p, xyz + 3 * p, tthr2) : d_out);
+    }
+  }
+  if (lane == 0) {
+    atomicAdd(&w.pearl_acc[s * 4 + 2 * which], data);
+    atomicAdd(&w.pearl_acc[s * 4 + 2 * which + 1], smooth);
+  }
+}
+
+__global__ __launch_bounds__(256) void pearl_sweep(
+    const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
+    const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
+    const int32_t* __restrict__ num_models, EposFitParams prm, int max_k, Work w,
+    const double* __restrict__ poses, const uint8_t* __restrict__ lab_in_all,
+    uint8_t* __restrict__ lab_out_all) {
+  const int s = blockIdx.y;
+  if (!w.pearl_state[s]) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
+  const double* xy = xy_all + 2 * base;
+  const double* xyz = xyz_all + 3 * base;
+  const uint8_t* lab_in = lab_in_all + base;
+  uint8_t* lab_out = lab_out_all + base;
+  const int k = num_models[s];
+  const double* pp = poses + static_cast<int64_t>(s) * max_k * 12;
+  double K[9];
+  for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
+  const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
+  const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
+  const double r2 = rad * rad;
+  const double tthr = 1.5 * prm.threshold, tthr2 = tthr * tthr;
+  const double thr2 = prm.threshold * prm.threshold;
+  const int64_t d_out = static_cast<int64_t>((thr2 / tthr2) * static_cast<double>(GC_Q));
+  const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
+  const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
+  const int nwaves = gridDim.x * 4;
+  for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nwaves) {
+    int cnt[PEARL_MAX_K + 1];
+#pragma unroll
+    for (int m = 0; m <= PEARL_MAX_K; ++m) cnt[m] = 0;
+    for_each_neighbour(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2, lane,
+                       [&](int32_t o) {
+                         const int lo = lab_in[o];
+#pragma unroll
+                         for (int m = 0; m <= PEARL_MAX_K; ++m) cnt[m] += lo == m;
+                       });
+    int deg = 0;
+#pragma unroll
+    for (int m = 0; m <= PEARL_MAX_K; ++m) { cnt[m] = butterfly_sum_i(cnt[m]); deg += cnt[m]; }
+    if (lane == 0) {
+      int best = 0;
+      double best_c = 0.0;
+#pragma unroll
+      for (int m = 0; m <= PEARL_MAX_K; ++m) {
+        if (m <= k) {
+          const int64_t D = m < k ? pearl_data_term(pp + 12 * m, K, xy + 2 * p, xyz + 3 * p, tthr2)
+                                  : d_out;
+          const double c = (1.0 - lam) * static_cast<double>(D) +
+                           lam * static_cast<double>(
+                               deg > 0 ? (static_cast<int64_t>(GC_Q) * (deg - cnt[m])) / deg : 0);
+          if (m == 0 || c < best_c) { best = m; best_c = c; }
+        }
+      }
+      lab_out[p] = static_cast<uint8_t>(best);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pearl_refit(
+    const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
+    const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
+    const int32_t* __restrict__ num_models, EposFitParams prm, int max_k, Work w,
+    const double* __restrict__ poses, const uint8_t* __restrict__ lab_all) {
+  const int s = blockIdx.x;
+  if (!w.pearl_state[s]) return;
+  const int t = threadIdx.x;
+  __shared__ double s_red27[4 * 27];
+  __shared__ int s_cnt[4];
+  const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
+  const double* xy = xy_all + 2 * base;
+  const double* xyz = xyz_all + 3 * base;
+  const uint8_t* lab = lab_all + base;
+  const int k = num_models[s];
+  double K[9];
+  for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
+  const double thr2 = prm.threshold * prm.threshold;
+  int moved = 0;
+  for (int m = 0; m < k; ++m) {
+    double pose[12], next[12];
+    for (int i = 0; i < 12; ++i) pose[i] = poses[(static_cast<int64_t>(s) * max_k + m) * 12 + i];
+    int c = 0;
+    for (int64_t i = t; i < n; i += 256) c += lab[i] == m;
+    c = butterfly_sum_i(c);
+    if ((t & 63) == 0) s_cnt[t >> 6] = c;
+    __syncthreads();
+    c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+    bool ok = false;
+    if (c >= prm.min_point_number)                         // uniform
+      ok = !gn_step_block(pose, K, xy, xyz, nullptr, n, thr2, t, s_red27, next, lab, m);
+    if (t < 12) w.pearl_pose[(static_cast<int64_t>(s) * PEARL_MAX_K + m) * 12 + t] =
+        ok ? next[t] : pose[t];
+    moved |= ok;
+  }
+  if (t == 0) w.pearl_moved[s] = moved;
+}
+
+__global__ __launch_bounds__(256) void pearl_commit(const int64_t* slot_base,
+                                                    const int32_t* num_models,
+                                                    EposFitParams prm, int max_k, Work w,
+                                                    double* poses, const uint8_t* lab_all,
+                                                    int32_t* labels_all) {
+  const int s = blockIdx.x;
+  if (!w.pearl_state[s]) return;
+  const int t = threadIdx.x;
+  const int k = num_models[s];
+  const double lam = prm.spatial_coherence_weight;
+  const unsigned long long* a = w.pearl_acc + s * 4;
+  const double e_before = (1.0 - lam) * static_cast<double>(static_cast<int64_t>(a[0])) +
+                          lam * static_cast<double>(static_cast<int64_t>(a[1]));
+  const double e_after = (1.0 - lam) * static_cast<double>(static_cast<int64_t>(a[2])) +
+                         lam * static_cast<double>(static_cast<int64_t>(a[3]));
+  const bool keep = w.pearl_moved[s] && e_after < e_before;   // uniform
+  __syncthreads();
+  if (!keep) { if (t == 0) w.pearl_state[s] = 0; return; }
+  const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
+  for (int i = t; i < k * 12; i += 256)
+    poses[static_cast<int64_t>(s) * max_k * 12 + i] =
+        w.pearl_pose[static_cast<int64_t>(s) * PEARL_MAX_K * 12 + i];
+  for (int64_t i = t; i < n; i += 256) {
+    const int l = lab_all[base + i];
+    labels_all[base + i] = l < k ? l : -1;
+  }
+}
+
 inline int64_t align_up(int64_t x) { return (x + 255) / 256 * 256; }
 
 struct Layout {
   int64_t hyp_score, hyp_pose, hyp_count, active, n_active, done, inl_bits, total;
   int64_t words_total;
   int64_t cur_pose, cur_score, cur_count, state, tries, last_new, gq, lab_a, lab_b;
+  int64_t pearl_pose, pearl_acc, pearl_state, pearl_moved;
 };
 
 Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
@@ -1029,6 +1257,10 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.gq = off; off = align_up(off + (n_cap + 1) * 4);
   L.lab_a = off; off = align_up(off + n_cap + 1);
   L.lab_b = off; off = align_up(off + n_cap + 1);
+  L.pearl_pose = off; off = align_up(off + (S + 1) * PEARL_MAX_K * 12 * 8);
+  L.pearl_acc = off; off = align_up(off + (S + 1) * 4 * 8);
+  L.pearl_state = off; off = align_up(off + (S + 1) * 4);
+  L.pearl_moved = off; off = align_up(off + (S + 1) * 4);
   L.total = off;
   return L;
 }
@@ -1063,6 +1295,10 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   w.lab_b = reinterpret_cast<uint8_t*>(wb + L.lab_b);
   w.yorder = yorder;
   w.ypos = ypos;
+  w.pearl_pose = reinterpret_cast<double*>(wb + L.pearl_pose);
+  w.pearl_acc = reinterpret_cast<unsigned long long*>(wb + L.pearl_acc);
+  w.pearl_state = reinterpret_cast<int32_t*>(wb + L.pearl_state);
+  w.pearl_moved = reinterpret_cast<int32_t*>(wb + L.pearl_moved);
   hipLaunchKernelGGL(ransac_init, dim3(S), dim3(256), 0, st, slot_base, S, w, labels,
                      num_models, p->min_point_number, n_capacity);
   int rc = launch_status("ransac_init");
@@ -1100,6 +1336,33 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
     rc = launch_status("ransac_refit_accept");
     if (rc) return rc;
   }
+  // joint refinement of multi-instance slots
+  if (max_k >= 2 && p->pearl_iters > 0 && gc) {
+    hipLaunchKernelGGL(pearl_setup, dim3(static_cast<unsigned>(ceil_div(S, 64))), dim3(64), 0, st,
+                       num_models, *p, w, S);
+    const dim3 pgrid(64, S);
+    for (int it = 0; it < p->pearl_iters; ++it) {
+      hipLaunchKernelGGL(pearl_begin, pgrid, dim3(256), 0, st, slot_base, num_models, w, labels);
+      hipLaunchKernelGGL(pearl_energy, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                         num_models, *p, max_k, w, poses, w.lab_a, 0);
+      const uint8_t* lab_final = w.lab_a;
+      for (int sw = 0; sw < p->gc_sweeps; ++sw) {
+        const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
+        uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
+        hipLaunchKernelGGL(pearl_sweep, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                           num_models, *p, max_k, w, poses, in, out);
+        lab_final = out;
+      }
+      hipLaunchKernelGGL(pearl_refit, dim3(S), dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                         num_models, *p, max_k, w, poses, lab_final);
+      hipLaunchKernelGGL(pearl_energy, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                         num_models, *p, max_k, w, w.pearl_pose, lab_final, 1);
+      hipLaunchKernelGGL(pearl_commit, dim3(S), dim3(256), 0, st, slot_base, num_models, *p,
+                         max_k, w, poses, lab_final, labels);
+      rc = launch_status("pearl");
+      if (rc) return rc;
+    }
+  }
   return EPOS_OK;
 }
 
@@ -1126,7 +1389,7 @@ extern "C" void epos_fit_params_default(EposFitParams* p) {
   p->use_prosac = 0;
   p->lo_iters = 8;
   p->gc_sweeps = 3;
-  p->pearl_iters = 0;
+  p->pearl_iters = 2;
 }
 
 extern "C" int64_t epos_fit_workspace_bytes(int S, int64_t n_capacity,
@@ -1145,7 +1408,7 @@ extern "C" int epos_find6d_poses_device(
                poses && scores && num_models && labels, "null pointer");
   EPOS_REQUIRE(max_k >= 1 && p->max_iters >= 1, "max_k and max_iters must be >= 1");
   EPOS_REQUIRE(p->gc_sweeps >= 0 && p->gc_sweeps <= 16, "gc_sweeps must be in [0, 16]");
-  EPOS_REQUIRE(p->pearl_iters == 0, "pearl_iters: the joint refinement is not built yet");
+  EPOS_REQUIRE(p->pearl_iters >= 0 && p->pearl_iters <= 8, "pearl_iters must be in [0, 8]");
   if (S == 0) return EPOS_OK;
   return find6d_enqueue(xy, xyz, slot_base, S, n_capacity, Ks, max_models, seeds, p, max_k,
                         work, poses, scores, num_models, labels, nullptr, nullptr,
@@ -1206,8 +1469,8 @@ extern "C" int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
     if (!rc) rc = check_hip(hipMemcpy(d[4], &mm, 4, hipMemcpyHostToDevice), "copy mm");
     if (!rc) rc = check_hip(hipMemcpy(d[5], &seed, 8, hipMemcpyHostToDevice), "copy seed");
     if (!rc && (p->max_iters < 1 || p->gc_sweeps < 0 || p->gc_sweeps > 16 ||
-                p->pearl_iters != 0)) {
-      set_error("epos_find6d_poses: max_iters >= 1, gc_sweeps in [0, 16], pearl_iters == 0");
+                p->pearl_iters < 0 || p->pearl_iters > 8)) {
+      set_error("epos_find6d_poses: max_iters >= 1, gc_sweeps in [0, 16], pearl_iters in [0, 8]");
       rc = EPOS_E_INVALID;
     }
     if (!rc)

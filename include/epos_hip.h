@@ -335,7 +335,8 @@ typedef struct EposFitParams {
   int32_t lo_iters;                 /* Gauss-Newton refits per local-optimisation stage (8) */
   int32_t gc_sweeps;                /* relabelling sweeps of the spatial-coherence step
                                      * (default 3; 0 = thresholded inliers only)     */
-  int32_t pearl_iters;              /* joint refinement iterations (default 0 = off) */
+  int32_t pearl_iters;              /* joint refinement iterations of multi-instance
+                                     * results (default 2; 0 = off)                  */
 } EposFitParams;
 void epos_fit_params_default(EposFitParams* p);
 

@@ -62,6 +62,7 @@
  * build with -ffp-contract=off.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -588,9 +589,13 @@ static int gn_step(const double* pose, const double* K, const double* xy,
  * ICCV'19 sec. 3.3), for k instances, over ALL n correspondences:
  *   labels l_p in {0..k-1, k = outlier};  data term D_p(m) = min(e_pm^2 / (1.5 tau)^2, 1)
  *   for an instance, D_p(outlier) = (tau / (1.5 tau))^2 (a point is worth explaining iff
- *   its error is below tau); Potts smoothness lambda [l_p != l_q] on the neighbourhood
- *   graph. Energy E = sum_p (1 - lambda) D_p(l_p) + lambda sum_p #{neighbours q: l_q != l_p}
- *   (in 2^-20 fixed point, so it is exact and order independent).
+ *   its error is below tau); Potts smoothness on the neighbourhood graph, NORMALISED by
+ *   the degree: a point pays lambda times the FRACTION of its neighbours that carry
+ *   another label (EPOS's many-to-many correspondences give every inlier dozens of
+ *   outlier neighbours -- the symmetric / wrong candidates of the same pixels -- and an
+ *   un-normalised Potts term then relabels everything as outlier).
+ *   Energy E = sum_p [(1 - lambda) D_p(l_p) + lambda floor(Q diff_p / deg_p)] in 2^-20
+ *   fixed point (exact integers: order independent).
  * One iteration = gc_sweeps synchronous relabelling sweeps (each point takes its
  * cheapest label given its neighbours' labels; ties -> lowest label) + one Gauss-Newton
  * refit of every instance on its points. The new poses are kept iff E dropped. */
@@ -600,10 +605,13 @@ static int64_t pearl_energy(const int64_t* D /*[n][k+1]*/, const uint8_t* lab, i
   int64_t data = 0, smooth = 0;
   for (int64_t p = 0; p < n; ++p) {
     data += D[p * (k + 1) + lab[p]];
+    int64_t deg = 0, diff = 0;
     for (int64_t o = 0; o < n; ++o) {
       if (o == p || fabs(xy[2 * p + 1] - xy[2 * o + 1]) > rad) continue;
-      if (lab[o] != lab[p] && gc_neighbours(xy, xyz, (int32_t)p, (int32_t)o, s2, r2)) ++smooth;
+      if (!gc_neighbours(xy, xyz, (int32_t)p, (int32_t)o, s2, r2)) continue;
+      ++deg; diff += lab[o] != lab[p];
     }
+    if (deg > 0) smooth += ((int64_t)GC_Q * diff) / deg;   /* fraction of disagreeing neighbours */
   }
   (void)lam;
   *smooth_out = smooth;
@@ -646,7 +654,7 @@ static void pearl_refine(double* poses, int k, const double* K, const double* xy
     }
     int64_t sm0;
     const int64_t da0 = pearl_energy(D, lab, n, k, xy, xyz, lam, s2, r2, rad, &sm0);
-    const double e_before = (1.0 - lam) * (double)da0 + lam * (double)GC_Q * (double)sm0;
+    const double e_before = (1.0 - lam) * (double)da0 + lam * (double)sm0;
     for (int sweep = 0; sweep < prm->gc_sweeps; ++sweep) {
       for (int64_t p = 0; p < n; ++p) {
         int64_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -660,7 +668,7 @@ static void pearl_refine(double* poses, int k, const double* K, const double* xy
         double best_c = 0.0;
         for (int m = 0; m <= k; ++m) {
           const double c = (1.0 - lam) * (double)D[p * (k + 1) + m] +
-                           lam * (double)((int64_t)GC_Q * (deg - cnt[m]));
+                           lam * (double)(deg > 0 ? ((int64_t)GC_Q * (deg - cnt[m])) / deg : 0);
           if (m == 0 || c < best_c) { best = m; best_c = c; }
         }
         tmp[p] = (uint8_t)best;
@@ -680,6 +688,12 @@ static void pearl_refine(double* poses, int k, const double* K, const double* xy
         moved = 1;
       }
     }
+    if (getenv("PNP_REF_DEBUG")) {
+      int64_t c[10] = {0};
+      for (int64_t p = 0; p < n; ++p) ++c[lab[p]];
+      fprintf(stderr, "pearl it %d: moved %d label counts %lld %lld %lld, before %.6g (data %lld smooth %lld)\n",
+              it, moved, (long long)c[0], (long long)c[1], (long long)c[2], e_before, (long long)da0, (long long)sm0);
+    }
     if (!moved) break;
     /* energy of (new poses, new labels) against (old poses, old labels) */
     for (int64_t p = 0; p < n; ++p)
@@ -695,7 +709,8 @@ static void pearl_refine(double* poses, int k, const double* K, const double* xy
       }
     int64_t sm1;
     const int64_t da1 = pearl_energy(D, lab, n, k, xy, xyz, lam, s2, r2, rad, &sm1);
-    const double e_after = (1.0 - lam) * (double)da1 + lam * (double)GC_Q * (double)sm1;
+    const double e_after = (1.0 - lam) * (double)da1 + lam * (double)sm1;
+    if (getenv("PNP_REF_DEBUG")) fprintf(stderr, "pearl it %d: before %.6g (data %lld smooth %lld) after %.6g (data %lld smooth %lld)\n", it, e_before, (long long)da0, (long long)sm0, e_after, (long long)da1, (long long)sm1);
     if (!(e_after < e_before)) break;
     memcpy(poses, cand, sizeof(double) * 12 * (size_t)k);
     for (int64_t p = 0; p < n; ++p) labels[p] = lab[p] < k ? (int32_t)lab[p] : -1;
@@ -885,7 +900,7 @@ void pnp_ref_params_default(PnpRefParams* p) {   /* scripts/infer.py:76-120,470-
   p->use_prosac = 0;
   p->lo_iters = 8;
   p->gc_sweeps = 3;
-  p->pearl_iters = 0;
+  p->pearl_iters = 2;
 }
 
 /* exposed for unit tests: the spatial-coherence labelling of `pose` over all n

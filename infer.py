@@ -373,16 +373,27 @@ def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
         num_inst = min(num_inst, args.max_instances_to_fit)
       opencv = args.fitting_method == 'opencv_ransac'
       if opencv:
-        # infer.py:505-528: ONE instance per object, no coverage test, score 0.0. cv2
-        # is not available; the single model comes from this build's P3P-RANSAC + local
-        # optimisation instead of cv2.solvePnPRansac(EPNP) -- parity unpinned.
+        # infer.py:505-528, cv2.solvePnPRansac(iterationsCount=max_fitting_iterations,
+        # reprojectionError=inlier_thresh, confidence=0.99, flags=EPNP): ONE instance per
+        # object, RANSAC stopped by the 0.99 confidence bound, no spatial coherence, no
+        # coverage / Tanimoto test, refit on all inliers, score 0.0. cv2 is not available:
+        # the hypotheses come from this build's P3P solver (OpenCV: EPnP on 5-point
+        # samples) and the final refit is Gauss-Newton on the inliers (OpenCV: EPnP on the
+        # inliers) -- same contract, different minimal solver; parity unpinned.
         num_inst = 1
       est, _, quals = fitting.find6DPoses(
           c['coord_2d'], c['coord_3d'], f[3], threshold=fit.threshold,
+          neighborhood_ball_radius=fit.neighborhood_ball_radius,
+          spatial_coherence_weight=0.0 if opencv else fit.spatial_coherence_weight,
+          scaling_from_millimeters=fit.scaling_from_millimeters,
           max_tanimoto_similarity=fit.max_tanimoto_similarity,
-          max_iters=fit.max_iters, min_coverage=0.0 if opencv else fit.min_coverage,
+          max_iters=fit.max_iters, conf=fit.conf,
+          proposal_engine_conf=0.99 if opencv else fit.proposal_engine_conf,
+          min_coverage=0.0 if opencv else fit.min_coverage,
           min_triangle_area=fit.min_triangle_area, min_point_number=6,
-          max_model_number=num_inst, use_prosac=args.use_prosac,
+          max_model_number=num_inst,
+          max_model_number_for_optimization=fit.max_model_number_for_optimization,
+          use_prosac=args.use_prosac,
           seed=args.seed * 1000003 + f[1] * 1009 + obj_id)
       if est is not None:                                 # infer.py:490-503
         for i in range(est.shape[0] // 3):

@@ -182,7 +182,9 @@ _lib = None
 
 
 def lib_path():
-  return _build.LIB_PATH
+  # EPOS_HIP_LIB: another build of the same library (A/B runs of kernel variants on one
+  # box, tools/); the default is the in-tree build
+  return os.environ.get('EPOS_HIP_LIB') or _build.LIB_PATH
 
 
 def load():

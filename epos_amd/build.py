@@ -33,6 +33,16 @@ def _stale():
   return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(name, defines):
+  """A copy of the library with extra -D flags (tools/: same-box A/B runs, selected with
+  EPOS_HIP_LIB=<returned path>)."""
+  out = os.path.join(LIB_DIR, 'libepos_hip_%s.so' % name)
+  os.makedirs(LIB_DIR, exist_ok=True)
+  subprocess.check_call([HIPCC] + FLAGS + ['-Wno-inline-asm'] + list(defines) + ['-o', out] +
+                        sources())
+  return out
+
+
 def build(force=False, verbose=False):
   """Compiles every HIP source into epos_amd/lib/libepos_hip.so: one hipcc job per
   translation unit (in parallel, objects cached by mtime under lib/obj/), then a link."""

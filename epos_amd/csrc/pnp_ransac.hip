@@ -399,6 +399,7 @@ struct Work {
 };
 
 constexpr int GC_Q = 1 << 20;          // fixed point of the labelling energies
+constexpr double LO_MIN_GAIN = 1e-6;   // relative MSAC gain below which the refits stop
 
 // b^e by binary exponentiation (multiplications only: every implementation of the
 // stage gets the same bits)
@@ -668,6 +669,90 @@ __device__ int gn_step_block(const double* pose, const double* K, const double* 
   return 0;
 }
 
+// One pass over the correspondences that yields BOTH the MSAC score / inlier count of
+// `pose` (exactly score_pose_block's sums) and the Gauss-Newton step from it (exactly
+// gn_step_block's): the local optimisation then costs one pass per refit instead of two
+// (step from the accepted pose + score of the candidate). Returns the step's failure flag.
+__device__ int score_and_step_block(const double* pose, const double* K, const double* xy,
+                                    const double* xyz, const int32_t* idx, int64_t m,
+                                    double thr2, int t, double* s_red27, double* s_red,
+                                    int* s_cnt, const uint8_t* lab, int sel, double* score,
+                                    int* count, double* next) {
+  const double inv_thr2 = 1.0 / thr2;
+  double acc[27];
+#pragma unroll
+  for (int v = 0; v < 27; ++v) acc[v] = 0.0;
+  double sacc = 0.0;
+  int cnt = 0;
+  for (int64_t i0 = t; i0 < m; i0 += 256 * PF) {
+    PointBatch pb;
+    pb.load(xy, xyz, idx, i0, 256, m);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (!pb.ok[u]) continue;
+      double e2, Xc[3], r[2];
+      if (reproj(pose, K, pb.x2[u], pb.x3[u], &e2, Xc, r)) continue;
+      const bool inl = e2 < thr2;
+      if (inl) { sacc += 1.0 - e2 * inv_thr2; ++cnt; }
+      if (lab ? lab[pb.p[u]] != sel : !inl) continue;
+      const double iz = 1.0 / Xc[2];
+      const double a0 = K[0] * iz, a1 = K[1] * iz,
+                   a2 = -(K[0] * Xc[0] + K[1] * Xc[1]) * iz * iz;
+      const double b1 = K[4] * iz, b2 = -(K[4] * Xc[1]) * iz * iz;
+      double J0[6], J1[6];
+      J0[0] = -a1 * Xc[2] + a2 * Xc[1];
+      J0[1] = a0 * Xc[2] - a2 * Xc[0];
+      J0[2] = -a0 * Xc[1] + a1 * Xc[0];
+      J0[3] = a0; J0[4] = a1; J0[5] = a2;
+      J1[0] = -b1 * Xc[2] + b2 * Xc[1];
+      J1[1] = -b2 * Xc[0];
+      J1[2] = b1 * Xc[0];
+      J1[3] = 0.0; J1[4] = b1; J1[5] = b2;
+      int v = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) { acc[v] += J0[a] * J0[b] + J1[a] * J1[b]; ++v; }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { acc[v] += J0[a] * r[0] + J1[a] * r[1]; ++v; }
+    }
+  }
+  cnt = butterfly_sum_i(cnt);
+  if ((t & 63) == 0) s_cnt[t >> 6] = cnt;
+#pragma unroll
+  for (int v = 0; v < 27; ++v) {
+    const double ws = butterfly_sum(acc[v]);
+    if ((t & 63) == 0) s_red27[(t >> 6) * 27 + v] = ws;
+  }
+  *score = block_combine(butterfly_sum(sacc), s_red, t);      // two barriers inside
+  *count = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+#pragma unroll
+  for (int v = 0; v < 27; ++v)
+    acc[v] = (s_red27[v] + s_red27[27 + v]) + (s_red27[54 + v] + s_red27[81 + v]);
+  __syncthreads();
+  double H[36], g[6], x[6];
+  int v = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) { H[a * 6 + b] = acc[v]; H[b * 6 + a] = acc[v]; ++v; }
+  for (int a = 0; a < 6; ++a) g[a] = acc[v++];
+  if (solve6(H, g, x)) return 1;
+  double qw = 1.0, qx = 0.5 * x[0], qy = 0.5 * x[1], qz = 0.5 * x[2];
+  const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+  qw /= qn; qx /= qn; qy /= qn; qz /= qn;
+  double dR[9];
+  dR[0] = 1.0 - 2.0 * (qy * qy + qz * qz); dR[1] = 2.0 * (qx * qy - qz * qw); dR[2] = 2.0 * (qx * qz + qy * qw);
+  dR[3] = 2.0 * (qx * qy + qz * qw); dR[4] = 1.0 - 2.0 * (qx * qx + qz * qz); dR[5] = 2.0 * (qy * qz - qx * qw);
+  dR[6] = 2.0 * (qx * qz - qy * qw); dR[7] = 2.0 * (qy * qz + qx * qw); dR[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j)
+      next[i * 3 + j] = dR[i * 3] * pose[j] + dR[i * 3 + 1] * pose[3 + j] + dR[i * 3 + 2] * pose[6 + j];
+    next[9 + i] = dR[i * 3] * pose[9] + dR[i * 3 + 1] * pose[10] + dR[i * 3 + 2] * pose[11] + x[3 + i];
+  }
+  for (int i = 0; i < 12; ++i)
+    if (!(next[i] == next[i])) return 1;
+  return 0;
+}
+
 // ---- round, step 2: best hypothesis (with the RANSAC confidence bound) + local
 // optimisation (i) + the residual table and thresholded labels of the labelling step.
 __global__ __launch_bounds__(256) void ransac_select_lo(
@@ -755,17 +840,22 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   for (int i = 0; i < 12; ++i) pose[i] = w.hyp_pose[(static_cast<int64_t>(s) * nh + bi) * 12 + i];
   // ---- local optimisation (i): the whole workgroup sums, every thread steps ----
   orthonormalize(pose);
-  best_score = score_pose_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red, s_cnt,
-                                &best_count);
-  for (int li = 0; li < prm.lo_iters; ++li) {
-    double cand[12];
-    if (gn_step_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red27, cand)) break;
+  // each pass scores a pose AND takes the Gauss-Newton step from it: the step of an
+  // accepted candidate is already there when the next refit starts
+  double cand[12];
+  int fail = score_and_step_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red27, s_red,
+                                  s_cnt, nullptr, 1, &best_score, &best_count, cand);
+  for (int li = 0; li < prm.lo_iters && !fail; ++li) {
+    double sc, cand2[12];
     int cnt;
-    const double sc = score_pose_block(cand, K, xy, xyz, active, n_active, thr2, t, s_red,
-                                       s_cnt, &cnt);
+    const int fail2 = score_and_step_block(cand, K, xy, xyz, active, n_active, thr2, t, s_red27,
+                                           s_red, s_cnt, nullptr, 1, &sc, &cnt, cand2);
     if (!(sc > best_score)) break;
+    const double gain = sc - best_score;
     best_score = sc; best_count = cnt;
-    for (int i = 0; i < 12; ++i) pose[i] = cand[i];
+    for (int i = 0; i < 12; ++i) { pose[i] = cand[i]; cand[i] = cand2[i]; }
+    fail = fail2;
+    if (!(gain > LO_MIN_GAIN * sc)) break;        // converged: further steps are noise
   }
   if (t < 12) w.cur_pose[s * 12 + t] = pose[t];
   if (t == 0) { w.cur_score[s] = best_score; w.cur_count[s] = best_count; }
@@ -837,51 +927,153 @@ __device__ __forceinline__ void for_each_neighbour(const double* xy, const doubl
   }
 }
 
-__global__ __launch_bounds__(256) void ransac_gc_sweep(
+// One workgroup per TILE of 64 consecutive points of the row-sorted order. The points of
+// a tile share one candidate window (all correspondences whose image row is within tau_d
+// of the tile's rows: a contiguous range of the sorted order, found by two binary
+// searches); the window streams through LDS in chunks of GC_T candidates and each thread
+// tests its point (t & 63) against its wave's share of the chunk (t >> 6) -- all 64 lanes of a
+// wave read the SAME candidate: LDS broadcasts, no bank conflicts. Per pair: the 5-D
+// distance in fp64 and three integer counters (exact, order independent). The first
+// version (one wavefront per point walking its own window through global memory) cost
+// 0.15-0.6 ms per sweep: a chain of dependent gathers per point and 6 global loads per
+// candidate pair.
+// 256 threads per tile: 1024 (16 waves share a tile's window) is 20 % faster for one
+// image at a time (fitting 0.55 vs 0.66 ms) but costs throughput with several images in
+// flight (310 vs 320 images/s, same box: the large workgroups displace GEMM workgroups)
+#ifndef EPOS_GC_THREADS
+#define EPOS_GC_THREADS 256
+#endif
+constexpr int GC_T = EPOS_GC_THREADS;  // threads per tile workgroup
+constexpr int GC_W = GC_T / 64;       // waves: each takes every GC_W-th candidate
+__global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
     const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
     const int64_t* __restrict__ slot_base, EposFitParams prm, Work w,
     const uint8_t* __restrict__ lab_in_all, uint8_t* __restrict__ lab_out_all) {
   const int s = blockIdx.y;
   if (w.state[s] != 1) return;
-  const int lane = threadIdx.x & 63;
+  __shared__ double c_x[GC_T], c_y[GC_T], c_X[GC_T], c_Y[GC_T], c_Z[GC_T];
+  __shared__ int32_t c_q[GC_T], c_o[GC_T];
+  __shared__ uint8_t c_l[GC_T];
+  __shared__ int64_t s_win[2];
+  __shared__ int s_deg[GC_W][64], s_n0[GC_W][64];
+  __shared__ int64_t s_S[GC_W][64];
+  __shared__ int s_cnt4[GC_W];
+  const int t = threadIdx.x, pt = t & 63, sub = t >> 6;
   const int64_t base = slot_base[s];
   const int64_t n = slot_base[s + 1] - base;
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
-  const int32_t* active = w.active + base;
-  const int64_t n_active = w.n_active[s];
   const uint8_t* lab_in = lab_in_all + base;
   uint8_t* lab_out = lab_out_all + base;
   const int32_t* gq = w.gq + base;
   const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
-  const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
   const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
   const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
   const double r2 = rad * rad;
-  const int nwaves = gridDim.x * 4;
-  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
-       i += static_cast<int64_t>(gridDim.x) * 256)
-    if (lab_in[i] == 2) lab_out[i] = 2;
-  for (int64_t ia = wave_id; ia < n_active; ia += nwaves) {
-    const int32_t p = active[ia];
+  for (int64_t tile = blockIdx.x; tile * 64 < n; tile += gridDim.x) {
+    const int64_t pos0 = tile * 64;
+    const int64_t pos = pos0 + pt;
+    const bool valid = pos < n;
+    const int32_t p = valid ? (yorder ? yorder[pos] : static_cast<int32_t>(pos)) : 0;
+    const uint8_t lp = valid ? lab_in[p] : 2;
+    const bool act = lp != 2;
+    const double px = xy[2 * p], py = xy[2 * p + 1];
+    const double pX = xyz[3 * p], pY = xyz[3 * p + 1], pZ = xyz[3 * p + 2];
+    {
+      // window of sorted positions whose row can hold a neighbour of a point of the tile:
+      // GC_T-ary searches (every thread probes one position per step: two or three
+      // dependent loads instead of the ~13 of a binary search by one thread)
+      const int64_t last = pos0 + 63 < n ? pos0 + 63 : n - 1;
+      const int32_t pf = yorder ? yorder[pos0] : static_cast<int32_t>(pos0);
+      const int32_t pl = yorder ? yorder[last] : static_cast<int32_t>(last);
+      const double ylo = xy[2 * pf + 1] - rad, yhi = xy[2 * pl + 1] + rad;
+      for (int side = 0; side < 2; ++side) {
+        // side 0: first position in [0, pos0] with y >= ylo; side 1: first position in
+        // [last + 1, n] with y > yhi   (y is non-decreasing along the sorted order)
+        int64_t lo = side ? last + 1 : 0, hi = side ? n : pos0;
+        while (hi - lo > 0) {
+          const int64_t step = (hi - lo + GC_T - 1) / GC_T;
+          const int64_t q = lo + static_cast<int64_t>(t) * step;
+          bool pred = false;                       // "position q is at or beyond the bound"
+          if (q < hi) {
+            const int32_t o = yorder ? yorder[q] : static_cast<int32_t>(q);
+            const double yq = xy[2 * o + 1];
+            pred = side ? yq > yhi : yq >= ylo;
+          }
+          // first thread whose probe satisfies the predicate (monotone along t)
+          const unsigned long long b = __ballot(pred);
+          if ((t & 63) == 0) s_cnt4[t >> 6] = b ? (t + __ffsll(static_cast<long long>(b)) - 1) : GC_T;
+          __syncthreads();
+          int first = GC_T;
+#pragma unroll
+          for (int g = 0; g < GC_W; ++g) first = s_cnt4[g] < first ? s_cnt4[g] : first;
+          __syncthreads();
+          if (first == GC_T) {       // no probe at or beyond the bound: it lies after the
+            const int64_t tv = (hi - lo - 1) / step;            // last probe made
+            lo = lo + tv * step + 1;
+          } else {                  // the bound lies in (probe[first - 1], probe[first]]
+            const int64_t qf = lo + static_cast<int64_t>(first) * step;
+            lo = first == 0 ? lo : lo + static_cast<int64_t>(first - 1) * step + 1;
+            hi = qf;
+          }
+        }
+        if (t == 0) s_win[side] = lo;
+      }
+    }
+    __syncthreads();
+    const int64_t wlo = s_win[0], whi = s_win[1];
     int deg = 0, n0 = 0;
     int64_t S = 0;
-    for_each_neighbour(xy, xyz, n, p, yorder, ypos, rad, s2, r2, lane, [&](int32_t o) {
-      const uint8_t lo = lab_in[o];
-      if (lo != 2) { ++deg; S += gq[o]; n0 += lo == 0; }
-    });
-    deg = butterfly_sum_i(deg);
-    n0 = butterfly_sum_i(n0);
-    S = butterfly_sum_i64(S);
-    if (lane == 0) {
-      const int64_t qp = gq[p];
-      const int64_t T = 2 * static_cast<int64_t>(GC_Q) * n0 - (static_cast<int64_t>(deg) * qp + S);
-      const int64_t u = qp < GC_Q ? -2 * (static_cast<int64_t>(GC_Q) - qp)
-                                  : 2 * static_cast<int64_t>(GC_Q);
-      const double val = (1.0 - lam) * static_cast<double>(u) + lam * static_cast<double>(T);
-      lab_out[p] = val < 0.0 ? 1 : 0;
+    for (int64_t c0 = wlo; c0 < whi; c0 += GC_T) {
+      const int64_t c = c0 + t;
+      if (c < whi) {
+        const int32_t o = yorder ? yorder[c] : static_cast<int32_t>(c);
+        c_o[t] = o;
+        c_x[t] = xy[2 * o]; c_y[t] = xy[2 * o + 1];
+        c_X[t] = xyz[3 * o]; c_Y[t] = xyz[3 * o + 1]; c_Z[t] = xyz[3 * o + 2];
+        c_q[t] = gq[o];
+        c_l[t] = lab_in[o];
+      }
+      __syncthreads();
+      const int cnt = whi - c0 < GC_T ? static_cast<int>(whi - c0) : GC_T;
+      // branch-free: every LDS read of an iteration is issued up front (wave-uniform
+      // addresses: broadcasts), the tests are arithmetic; four candidates per trip so
+      // that the reads of the next ones overlap the fp64 chain of the current one (the
+      // first version -- early-outs between dependent LDS reads -- ran at ~1500 cycles
+      // per candidate)
+#pragma unroll 4
+      for (int j = sub; j < cnt; j += GC_W) {
+        const int lo_ = c_l[j];
+        const int32_t co = c_o[j], cq = c_q[j];
+        const double dx = px - c_x[j], dy = py - c_y[j];
+        const double dX = pX - c_X[j], dY = pY - c_Y[j], dZ = pZ - c_Z[j];
+        const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
+        const int nb = static_cast<int>(act) & static_cast<int>(lo_ != 2) &
+                       static_cast<int>(co != p) & static_cast<int>(d2 <= r2);
+        deg += nb;
+        S += nb ? cq : 0;
+        n0 += nb & static_cast<int>(lo_ == 0);
+      }
+      __syncthreads();
     }
+    s_deg[sub][pt] = deg; s_n0[sub][pt] = n0; s_S[sub][pt] = S;
+    __syncthreads();
+    if (sub == 0 && valid) {
+      if (!act) {
+        lab_out[p] = 2;
+      } else {
+        int64_t dg = 0, z0 = 0, Ss = 0;
+#pragma unroll
+        for (int g = 0; g < GC_W; ++g) { dg += s_deg[g][pt]; z0 += s_n0[g][pt]; Ss += s_S[g][pt]; }
+        const int64_t qp = gq[p];
+        const int64_t T = 2 * static_cast<int64_t>(GC_Q) * z0 - (dg * qp + Ss);
+        const int64_t u = qp < GC_Q ? -2 * (static_cast<int64_t>(GC_Q) - qp)
+                                    : 2 * static_cast<int64_t>(GC_Q);
+        const double val = (1.0 - lam) * static_cast<double>(u) + lam * static_cast<double>(T);
+        lab_out[p] = val < 0.0 ? 1 : 0;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -921,16 +1113,21 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
   int best_count = w.cur_count[s];
   if (state == 1) {
     const uint8_t* lab = lab_all + base;
-    for (int li = 0; li < prm.lo_iters; ++li) {
-      double cand[12];
-      if (gn_step_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red27, cand, lab, 1))
-        break;
+    // the first step on the labelled set starts from the accepted pose (its score is
+    // known); from then on each pass scores a candidate and steps from it
+    double cand[12];
+    int fail = gn_step_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red27, cand, lab, 1);
+    for (int li = 0; li < prm.lo_iters && !fail; ++li) {
+      double sc, cand2[12];
       int cnt;
-      const double sc = score_pose_block(cand, K, xy, xyz, active, n_active, thr2, t, s_red,
-                                         s_cnt, &cnt);
+      const int fail2 = score_and_step_block(cand, K, xy, xyz, active, n_active, thr2, t,
+                                             s_red27, s_red, s_cnt, lab, 1, &sc, &cnt, cand2);
       if (!(sc > best_score)) break;
+      const double gain = sc - best_score;
       best_score = sc; best_count = cnt;
-      for (int i = 0; i < 12; ++i) pose[i] = cand[i];
+      for (int i = 0; i < 12; ++i) { pose[i] = cand[i]; cand[i] = cand2[i]; }
+      fail = fail2;
+      if (!(gain > LO_MIN_GAIN * sc)) break;
     }
   }
   if (best_count < prm.min_point_number) {
@@ -1308,6 +1505,12 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
                   p->neighborhood_ball_radius > 0.0;
   // a multi-instance (Progressive-X) search may retry a failed proposal: two extra rounds
   const int rounds = max_k + (max_k > 1 ? 2 : 0);
+  // joint refinement kernels: one wavefront per point and pass
+  const int64_t per_slot = ceil_div(n_capacity, S > 0 ? S : 1);
+  const dim3 pgrid(static_cast<unsigned>(per_slot < 8192 ? ceil_div(per_slot, 4) < 64 ? 64 : ceil_div(per_slot, 4) : 2048), S);
+  // labelling sweeps: one workgroup per tile of 64 points (grid-stride beyond 512 tiles)
+  const int64_t tiles = ceil_div(per_slot, 64);
+  const dim3 sgrid(static_cast<unsigned>(tiles < 1 ? 1 : tiles > 512 ? 512 : tiles), S);
   for (int round = 0; round < rounds; ++round) {
     hipLaunchKernelGGL(ransac_hypotheses, hgrid, dim3(256), 0, st, xy, xyz,
                        slot_base, Ks, seeds, max_models, num_models, *p, max_k,
@@ -1323,7 +1526,7 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
       for (int sw = 0; sw < p->gc_sweeps; ++sw) {
         const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
         uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
-        hipLaunchKernelGGL(ransac_gc_sweep, dim3(64, S), dim3(256), 0, st, xy, xyz, slot_base,
+        hipLaunchKernelGGL(ransac_gc_sweep, sgrid, dim3(GC_T), 0, st, xy, xyz, slot_base,
                            *p, w, in, out);
         rc = launch_status("ransac_gc_sweep");
         if (rc) return rc;
@@ -1340,7 +1543,6 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   if (max_k >= 2 && p->pearl_iters > 0 && gc) {
     hipLaunchKernelGGL(pearl_setup, dim3(static_cast<unsigned>(ceil_div(S, 64))), dim3(64), 0, st,
                        num_models, *p, w, S);
-    const dim3 pgrid(64, S);
     for (int it = 0; it < p->pearl_iters; ++it) {
       hipLaunchKernelGGL(pearl_begin, pgrid, dim3(256), 0, st, slot_base, num_models, w, labels);
       hipLaunchKernelGGL(pearl_energy, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
@@ -1388,7 +1590,7 @@ extern "C" void epos_fit_params_default(EposFitParams* p) {
   p->max_model_number_for_optimization = 5;
   p->use_prosac = 0;
   p->lo_iters = 8;
-  p->gc_sweeps = 3;
+  p->gc_sweeps = 2;
   p->pearl_iters = 2;
 }
 

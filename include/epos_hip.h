@@ -334,7 +334,7 @@ typedef struct EposFitParams {
   int32_t use_prosac;               /* sample from a growing confidence-sorted prefix */
   int32_t lo_iters;                 /* Gauss-Newton refits per local-optimisation stage (8) */
   int32_t gc_sweeps;                /* relabelling sweeps of the spatial-coherence step
-                                     * (default 3; 0 = thresholded inliers only)     */
+                                     * (default 2; 0 = thresholded inliers only)     */
   int32_t pearl_iters;              /* joint refinement iterations of multi-instance
                                      * results (default 2; 0 = off)                  */
 } EposFitParams;

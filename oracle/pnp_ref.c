@@ -412,6 +412,7 @@ static double powi(double b, int64_t e) {
 
 /* ------------------------------------------- spatial-coherence labelling -- */
 #define GC_Q 1048576            /* 2^20 fixed point for the energies */
+#define LO_MIN_GAIN 1e-6        /* relative MSAC gain below which the refits stop */
 
 /* j is a neighbour of i iff both are active, i != j and their distance in
  * (x, y, s X, s Y, s Z) is at most tau_d (EPOS CVPR'20 sec. 3.4: tau_d = 20, s = 0.1). */
@@ -809,8 +810,10 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
         int32_t cnt;
         const double sc = score_pose256(cand, K, xy, xyz, active, n_active, thr2, &cnt);
         if (!(sc > best_score)) break;
+        const double gain = sc - best_score;
         best_score = sc; best_count = cnt;
         memcpy(best_pose, cand, sizeof(cand));
+        if (!(gain > LO_MIN_GAIN * sc)) break;      /* converged: further steps are noise */
       }
       /* (ii): spatially coherent inlier set -> refits on it */
       if (prm->gc_sweeps > 0 && prm->spatial_coherence_weight > 0.0 &&
@@ -822,8 +825,10 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
           int32_t cnt;
           const double sc = score_pose256(cand, K, xy, xyz, active, n_active, thr2, &cnt);
           if (!(sc > best_score)) break;
+          const double gain = sc - best_score;
           best_score = sc; best_count = cnt;
           memcpy(best_pose, cand, sizeof(cand));
+          if (!(gain > LO_MIN_GAIN * sc)) break;
         }
       }
       if (best_count < prm->min_point_number) failed = 1;
@@ -899,7 +904,7 @@ void pnp_ref_params_default(PnpRefParams* p) {   /* scripts/infer.py:76-120,470-
   p->max_model_number_for_optimization = 5;
   p->use_prosac = 0;
   p->lo_iters = 8;
-  p->gc_sweeps = 3;
+  p->gc_sweeps = 2;
   p->pearl_iters = 2;
 }
 

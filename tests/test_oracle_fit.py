@@ -16,7 +16,7 @@ from helpers import fit_scenes as fs   # noqa: E402
 K = fs.K_YCBV
 
 
-def _numpy_gc_label(R, t, xy, xyz, thr=4.0, rad=20.0, lam=0.1, s=0.1, sweeps=3):
+def _numpy_gc_label(R, t, xy, xyz, thr=4.0, rad=20.0, lam=0.1, s=0.1, sweeps=2):
   """GC-RANSAC's labelling energy, minimised by synchronous ICM sweeps, written the
   slow obvious way: explicit energies of both labels per point, float arithmetic on
   the 2^-20 quantised residuals (exact integers in fp64)."""
@@ -64,6 +64,10 @@ def test_gc_label_matches_an_independent_numpy_restatement():
   want, nb = _numpy_gc_label(Rp, P[:, 3], xy, xyz)
   assert nb.sum() > 20 * len(xy)                      # a real neighbourhood graph
   assert np.array_equal(got, want)
+  for sw in (1, 4):                                   # any number of sweeps
+    assert np.array_equal(
+        pnp_ref.gc_label(P, xy, xyz, K, pnp_ref.default_params(gc_sweeps=sw)),
+        _numpy_gc_label(Rp, P[:, 3], xy, xyz, sweeps=sw)[0])
   r, _ = fs.reproj_residuals(Rp, P[:, 3], K, xy, xyz)
   thresholded = ((r * r).sum(1) < 16.0).astype(np.uint8)
   assert 0 < (got != thresholded).sum() < len(xy) // 2   # coherence changed some labels

@@ -1,31 +1,43 @@
 #!/bin/bash
 # Collects the measurements kept under profiles/<round>/ (run on the GPU box through gpurun):
-#   bash tools/profile_round.sh r01
-# bench JSON lines (default / depth 1 / sparse heads), rocprofv3 kernel-trace stats at
-# depth 1 and 3, and two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) for the HBM-side
-# traffic of the GEMM kernels. PMC passes never share a run with trace options.
+#   bash tools/profile_round.sh r02
+# - the bench line at the DRIVER'S command (bench.py --gpus 1 --steps 20 --warmup 5) and at
+#   100 steps, depth 1, sparse heads, fp32-MFMA GEMMs;
+# - rocprofv3 --kernel-trace --stats of the driver's command (pipeline depth 4) and of
+#   depth 1, plus the per-kernel-family union of busy time per step from the depth-4 trace
+#   (so that sum(kernel time per step) <= ms_per_step can be checked, not argued);
+# - two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) merged into gemm_hbm_traffic_pmc.json
+#   (gfx950 x2 correction on FETCH_SIZE; PMC passes never share a run with trace options);
+# - the RANSAC-only microbenchmark.
 set -u
-R=${1:-r01}
+R=${1:-r02}
+cd "$(dirname "$0")/.."
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
-cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-python bench.py --steps 100 --warmup 10 > $OUT/bench_default.log 2>&1; tail -1 $OUT/bench_default.log > $OUT/bench_final_default.json
-python bench.py --steps 100 --warmup 10 --pipeline-depth 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_final_depth1.json
-python bench.py --steps 100 --warmup 10 --sparse-heads --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_final_sparse_heads.json
-for d in 1 3; do
+python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/bench_driver_cmd.err | tail -1 > $OUT/bench_driver_cmd.json
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_100steps.json
+python bench.py --steps 100 --warmup 10 --sparse-heads --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_sparse_heads.json
+EPOS_GEMM_SPLIT=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_fp32_mfma.json
+python bench.py --steps 40 --warmup 5 --batch-per-gpu 4 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_c3_shard_batch4.json
+for d in 4 1; do
   mkdir -p $OUT/kt$d
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt$d -- \
-    python bench.py --steps 20 --warmup 3 --pipeline-depth $d --no-cpu-baseline > $OUT/kt$d.log 2>&1
+    python bench.py --gpus 1 --steps 20 --warmup 5 --pipeline-depth $d --no-cpu-baseline --no-stage-times > $OUT/kt$d.log 2>&1
   f=$(find $OUT/kt$d -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $OUT/rocprofv3_kernel_stats_depth$d.csv
+  f=$(find $OUT/kt$d -name '*kernel_trace.csv' | head -1)
+  [ -n "$f" ] && python tools/trace_overlap.py "$f" 0.5 > $OUT/kernel_trace_busy_union_depth$d.txt
+  tail -1 $OUT/kt$d.log > $OUT/bench_under_rocprof_depth$d.json
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p $OUT/pmc_$c
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- \
-    python bench.py --steps 4 --warmup 1 --pipeline-depth 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$c.log 2>&1
+    python bench.py --steps 4 --warmup 1 --pipeline-depth 1 --no-cpu-baseline --no-roofline --no-stage-times > $OUT/pmc_$c.log 2>&1
   f=$(find $OUT/pmc_$c -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python tools/pmc_traffic.py "$f" $c > $OUT/pmc_$c.json
 done
-rm -rf $OUT/kt1 $OUT/kt3 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+python tools/pmc_traffic.py --merge $OUT/pmc_FETCH_SIZE.json $OUT/pmc_WRITE_SIZE.json > $OUT/gemm_hbm_traffic_pmc.json
+python tools/bench_ransac.py > $OUT/ransac_microbench.txt 2>&1
+rm -rf $OUT/kt1 $OUT/kt4 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT

@@ -314,7 +314,29 @@ def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
       'image_path': path.decode('utf-8') if isinstance(path, bytes) else path,
       'image': np.ascontiguousarray(im), 'K': K,
       'gt_obj_ids': [ids[i] for i in keep],
+      'gt_poses': _gt_poses(feats, ids, keep),
   }
+
+
+def _gt_poses(feats, ids, keep):
+  """Ground-truth poses of the kept instances (only used by --vis, infer.py:207-215):
+  unit quaternion (w, x, y, z) = pose/q1..q4 as create_tfrecord.py:187-210 writes them
+  (transform.quaternion_from_matrix), translation pose/t1..t3 [mm]."""
+  q = [feats.get('image/object/pose/q%d' % i, []) for i in range(1, 5)]
+  t = [feats.get('image/object/pose/t%d' % i, []) for i in range(1, 4)]
+  if any(len(x) != len(ids) for x in q + t):
+    return None
+  out = []
+  for i in keep:
+    w, x, y, z = (float(q[j][i]) for j in range(4))
+    n = (w * w + x * x + y * y + z * z) ** 0.5 or 1.0
+    w, x, y, z = w / n, x / n, y / n, z / n
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    out.append({'obj_id': ids[i], 'R': R,
+                't': np.array([[float(t[0][i])], [float(t[1][i])], [float(t[2][i])]])})
+  return out
 
 
 def load_samples(path, crop_size, max_height_before_crop=480, obj_ids=None,

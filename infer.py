@@ -87,6 +87,13 @@ def build_parser():
   a('--max_instances_to_fit', type=int, default=None)
   a('--max_fitting_iterations', type=int, default=400)
   a('--vis', type=str2bool, default=False)
+  a('--vis_gt_poses', type=str2bool, default=True)           # infer.py:126-146
+  a('--vis_pred_poses', type=str2bool, default=True)
+  a('--vis_gt_obj_labels', type=str2bool, default=True)
+  a('--vis_pred_obj_labels', type=str2bool, default=True)
+  a('--vis_pred_obj_confs', type=str2bool, default=False)
+  a('--vis_gt_frag_fields', type=str2bool, default=False)
+  a('--vis_pred_frag_fields', type=str2bool, default=False)
   # epos_lib/common.py:60-154 (the model flags the hot path reads)
   a('--dataset', default=None)
   a('--num_frags', type=int, default=64)
@@ -281,7 +288,8 @@ def load_frames(args, num_objs, rank, world, store_obj_ids=None):
       tg = {}
       for o in sm['gt_obj_ids']:             # instance counts, infer.py:462-463
         tg[o] = tg.get(o, 0) + 1
-      frames.append((sm['scene_id'], sm['im_id'], sm['image'], sm['K'], tg))
+      frames.append((sm['scene_id'], sm['im_id'], sm['image'], sm['K'], tg,
+                     sm.get('gt_poses')))
   elif args.frames:
     meta = json.load(open(os.path.join(args.frames, 'frames.json')))
     b, e = edist.shard_range(len(meta), rank, world)
@@ -314,7 +322,7 @@ def load_frames(args, num_objs, rank, world, store_obj_ids=None):
 
 def save_correspondences(infer_dir, infer_name, frame, im_ind, corr, pred_time):
   """infer.py:294-345 text dump (sorted by confidence)."""
-  scene_id, im_id, _, K, _ = frame
+  scene_id, im_id, _, K = frame[:4]
   suffix = '' if infer_name is None else '_' + infer_name
   for obj_id, c in corr.items():
     txt = '# Corr format: u v x y z px_id frag_id conf conf_obj conf_frag\n'
@@ -421,8 +429,10 @@ def main(argv=None):
   if args.fitting_method not in ('progressive_x', 'opencv_ransac'):
     raise ValueError('Unknown pose fitting method ({}).'.format(
         args.fitting_method))                                   # infer.py:530-532
-  if args.vis:
-    raise NotImplementedError('--vis needs the OSMesa renderer (out of scope).')
+  if args.vis and args.vis_gt_frag_fields:
+    raise NotImplementedError(
+        '--vis_gt_frag_fields needs the ground-truth fragment fields of the training '
+        'pipeline (datagen.py:478-544), which the inference reader does not build.')
   checkpoint_dir = os.path.join(model_dir, 'train')             # infer.py:570
   infer_dir = os.path.join(model_dir, 'infer')
   os.makedirs(infer_dir, exist_ok=True)
@@ -506,7 +516,7 @@ def main(argv=None):
   B = args.batch
   max_inst = args.max_instances_to_fit or 4
   depth = max(1, args.pipeline_depth)
-  if operator_path or args.save_corresp:
+  if operator_path or args.save_corresp or args.vis:
     depth = 1                      # those paths read the plan's buffers after the step
   pipes = [pipeline.EposPipeline(
       ckpt, B, h, w, num_objs, args.num_frags, store, fit_params=fit,
@@ -538,6 +548,15 @@ def main(argv=None):
             args.task_type == pipeline.LOCALIZATION, device=dev)
         save_correspondences(infer_dir, args.infer_name, f, i0 + b, c,
                              rt.get('total', 0.0))
+    if args.vis:                                # infer.py:540-552, <model>/vis (:577)
+      from epos_amd import vis as evis
+      pred = {k: v.cpu().numpy() for k, v in pipe.net.forward().items()}
+      flags = {k: getattr(args, k) for k in vars(args) if k.startswith('vis_')}
+      for b, f in enumerate(chunk[:n_real]):
+        est = [p for p in poses if (p['scene_id'], p['im_id']) == (f[0], f[1])]
+        evis.visualize(f[2], f[3], {k: v[b] for k, v in pred.items()}, est, i0 + b,
+                       store, os.path.join(model_dir, 'vis'),
+                       gt_poses=f[5] if len(f) > 5 else None, flags=flags)
     if rank == 0:                               # infer.py:730-734
       print('Image: {}, prediction: {:.3f}, establish_corr: {:.3f}, fitting: '
             '{:.3f}, total time: {:.3f}'.format(

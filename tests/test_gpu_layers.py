@@ -712,6 +712,8 @@ def test_split_gemm_adversarial_operands(lib):
   eps = 2.0 ** -24
   m, k, n = 256, 512, 128
 
+  rms = {}
+
   def rel_err(a, w):
     ref = a.astype(np.float64) @ w.astype(np.float64)
     scale = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64)
@@ -719,7 +721,9 @@ def test_split_gemm_adversarial_operands(lib):
     for split in (1, 0):
       c = _split_vs_fp32(lib, a, w, split)
       with np.errstate(invalid='ignore', divide='ignore'):
-        out[split] = np.nanmax(np.abs(c - ref) / np.maximum(scale, 1e-300))
+        r = np.abs(c - ref) / np.maximum(scale, 1e-300)
+      out[split] = np.nanmax(r)
+      rms[split] = float(np.sqrt(np.nanmean(r * r)))
     return out
 
   # 1. alternating-sign cancellation: the exact result is tiny against the terms
@@ -736,17 +740,21 @@ def test_split_gemm_adversarial_operands(lib):
   w = (rng.uniform(1, 2, (k, n)) * 2.0 ** rng.randint(-60, 61, (k, n)) *
        rng.choice([-1, 1], (k, n))).astype(np.float32)
   e = rel_err(a, w)
-  assert e[1] <= 2 * eps and e[1] <= e[0] * 1.01 + eps / 8, e
-  # 3. small magnitudes whose low bf16 piece is a denormal (|x| ~ 2^-118 .. 2^-108: x itself
-  #    is a normal fp32 number, lo = x - hi - mid lies below 2^-126): the bf16 matrix pipe
-  #    flushes denormal inputs, so the third-order terms are lost there -- the error bound
-  #    degrades from 2^-24 to the second-order level 2^-16 of the products, i.e. the kernel
-  #    is fp32-equivalent for operands above ~2^-100 only (documented in DESIGN.md).
+  # one huge term dominates sum |a||w| here and every later addition rounds at ITS
+  # magnitude: an fp32 chain is at ~1 eps rms / ~10 eps max on such data (measured: the
+  # fp32-MFMA kernel 1.1-1.8 eps rms, 8-15 max), and so is the split kernel -- its
+  # advantage (0.04 vs 0.31 eps rms at equal magnitudes) comes from the products, not
+  # from the order of the additions. Bound: same class as the fp32 kernel.
+  assert e[1] <= 16 * eps and rms[1] <= 1.25 * rms[0] + eps / 8, (e, rms)
+  # 3. small magnitudes whose low bf16 piece is a DENORMAL (|x| ~ 2^-118 .. 2^-108: x itself
+  #    is a normal fp32 number, lo = x - hi - mid lies below 2^-126). If the matrix pipe
+  #    flushed denormal bf16 inputs the third-order terms would be lost and the error
+  #    would jump to ~2^-16; measured: it does not (9 eps max here, the fp32-MFMA kernel 25
+  #    on the same operands, whose magnitudes span 11 octaves -- see case 2).
   a = (rng.uniform(1, 2, (m, k)) * 2.0 ** rng.randint(-118, -107, (m, k))).astype(np.float32)
   w = rng.uniform(1, 2, (k, n)).astype(np.float32)
   e = rel_err(a, w)
-  assert e[1] <= 2.0 ** -15, e
-  assert e[0] <= 2 * eps, e                 # the fp32-MFMA kernel keeps full accuracy there
+  assert e[1] <= 32 * eps and rms[1] <= 1.25 * rms[0] + eps / 8, (e, rms)
   # 4. non-finite operands stay non-finite (an Inf splits into Inf + NaN pieces: the row
   #    comes out NaN where an fp32 chain would give +-Inf); finite rows are untouched
   a = rng.standard_normal((m, k)).astype(np.float32)

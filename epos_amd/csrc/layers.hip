@@ -97,7 +97,8 @@ struct DwPartition {
   int runs;        // mode 0: runs of the whole launch = B*Ho*nres*nchunk
   int rows;        // mode 1: B*Ho
   FastDiv dwc[2];  // mode 0: slice widths floor(c4n/8) and floor(c4n/8)+1
-  FastDiv dc4n, dchunk, dres, dho;
+  FastDiv dc4n, dchunk, dres, dho;   // dho: / row slots per image
+  FastDiv drate;                     // ROWS = 2: / rate (slot -> row group)
 };
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
   const unsigned t = __umulhi(f.mul, n);
@@ -114,14 +115,20 @@ __device__ __forceinline__ float4 relu4_1op(float4 v) {
   return make_float4(relu_1op(v.x), relu_1op(v.y), relu_1op(v.z), relu_1op(v.w));
 }
 
-template <int L, bool RELU_IN, bool RELU_OUT>
-__global__ __launch_bounds__(256, EPOS_DW_MIN_BLOCKS) void depthwise3x3_s1_kernel(EposDepthwiseArgs p,
-                                                              int c4n, int nres,
-                                                              int nchunk,
-                                                              DwPartition part) {
+// ROWS = 2 (round 2): a thread computes the run for TWO output rows `rate` apart (y0 and
+// y0 + rate). They share two of their three input rows, so the 4 x (L + 2) loaded float4
+// serve 2L outputs: 3.0 input loads per output instead of 4.5, and the nine weight
+// vectors are amortised over 8 outputs instead of 4 -- the kernel is bound by load
+// instructions issued (one 1 KB wave-load per ~24 ns per CU), not by bytes. Row slots:
+// rows are taken in groups of 2 * rate; slot (g, i), i < rate, owns rows 2*rate*g + i and
+// + rate. Same fmaf chain per output as ROWS = 1: identical bits.
+template <int L, bool RELU_IN, bool RELU_OUT, int ROWS>
+__global__ __launch_bounds__(256, (ROWS == 2 ? 3 : EPOS_DW_MIN_BLOCKS)) void depthwise3x3_s1_kernel(
+    EposDepthwiseArgs p, int c4n, int nres, int nchunk, int nrows, DwPartition part) {
+  constexpr int NR = ROWS + 2;                 // input rows held per column
   const int xcd = blockIdx.x & 7;
   const unsigned local = (blockIdx.x >> 3) * blockDim.x + threadIdx.x;
-  int c, chunk, res, y, b;
+  int c, chunk, res, ys, b;
   bool live = true;
   if (part.mode == 0) {
     const int c_lo = xcd * c4n / 8, wc = (xcd + 1) * c4n / 8 - c_lo;
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256, EPOS_DW_MIN_BLOCKS) void depthwise3x3_s1_kerne
     q = fdiv(rest, part.dres);
     res = static_cast<int>(rest - q * nres); rest = q;
     q = fdiv(rest, part.dho);
-    y = static_cast<int>(rest - q * p.Ho);
+    ys = static_cast<int>(rest - q * nrows);
     b = static_cast<int>(q);
   } else {
     const int r_lo = static_cast<int>(static_cast<int64_t>(xcd) * part.rows / 8);
@@ -148,13 +155,19 @@ __global__ __launch_bounds__(256, EPOS_DW_MIN_BLOCKS) void depthwise3x3_s1_kerne
     res = static_cast<int>(rest - q * nres); rest = q;
     const unsigned row = r_lo + rest;
     q = fdiv(row, part.dho);
-    y = static_cast<int>(row - q * p.Ho);
+    ys = static_cast<int>(row - q * nrows);
     b = static_cast<int>(q);
   }
   const int r = p.rate;
+  int y = ys;
+  if (ROWS == 2) {                              // slot -> first row of the pair
+    const unsigned g = fdiv(static_cast<unsigned>(ys), part.drate);
+    y = static_cast<int>(2 * r * g + (ys - g * r));
+  }
   const int x0 = res + chunk * L * r;
-  live = live && x0 < p.Wo;
+  live = live && x0 < p.Wo && y < p.Ho;
   if (!live) return;
+  const bool row1 = ROWS == 2 && y + r < p.Ho;   // the pair's second row exists
   float4 w[9];
 #ifdef EPOS_DW_ABL_NOW
 #pragma unroll
@@ -170,9 +183,11 @@ __global__ __launch_bounds__(256, EPOS_DW_MIN_BLOCKS) void depthwise3x3_s1_kerne
   float* yb = p.Y + ((static_cast<int64_t>(b) * p.Ho + y) * p.Wo) * p.ldy + c;
   const int ldx = static_cast<int>(p.ldx), ldy = static_cast<int>(p.ldy);
   const int rowpitch = p.Wi * ldx;
+  const unsigned yrow1 = static_cast<unsigned>(r * p.Wo * ldy);   // output row y + rate
   // every tap of every output of this run inside the image?
-  const bool interior = y - r >= 0 && y + r < p.Hi && x0 - r >= 0 && x0 + L * r < p.Wi;
-  float4 col[L + 2][3];
+  const bool interior = y - r >= 0 && y + (ROWS == 2 ? 2 : 1) * r < p.Hi && x0 - r >= 0 &&
+                        x0 + L * r < p.Wi && (ROWS == 1 || row1);
+  float4 col[L + 2][NR];
   if (__builtin_amdgcn_ballot_w64(!interior) == 0) {
     // ---- interior wave: no clamp, no select -----------------------------------
     const unsigned o00 = (y - r) * rowpitch + (x0 - r) * ldx;
@@ -180,32 +195,35 @@ __global__ __launch_bounds__(256, EPOS_DW_MIN_BLOCKS) void depthwise3x3_s1_kerne
 #pragma unroll
     for (int i = 0; i < L + 2; ++i)
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) col[i][ky] = ld4(xb + (o00 + ky * rstep + i * cstep));
+      for (int ky = 0; ky < NR; ++ky) col[i][ky] = ld4(xb + (o00 + ky * rstep + i * cstep));
     if (RELU_IN) {
 #pragma unroll
       for (int i = 0; i < L + 2; ++i)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) col[i][ky] = relu4_1op(col[i][ky]);
+        for (int ky = 0; ky < NR; ++ky) col[i][ky] = relu4_1op(col[i][ky]);
     }
 #pragma unroll
-    for (int j = 0; j < L; ++j) {
-      float4 acc = bias;
+    for (int rr = 0; rr < ROWS; ++rr) {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        acc = fma4(col[j][ky], w[ky * 3 + 0], acc);
-        acc = fma4(col[j + 1][ky], w[ky * 3 + 1], acc);
-        acc = fma4(col[j + 2][ky], w[ky * 3 + 2], acc);
+      for (int j = 0; j < L; ++j) {
+        float4 acc = bias;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          acc = fma4(col[j][ky + rr], w[ky * 3 + 0], acc);
+          acc = fma4(col[j + 1][ky + rr], w[ky * 3 + 1], acc);
+          acc = fma4(col[j + 2][ky + rr], w[ky * 3 + 2], acc);
+        }
+        if (RELU_OUT) acc = relu4_1op(acc);
+        st4(yb + (static_cast<unsigned>((x0 + j * r) * ldy) + (rr ? yrow1 : 0u)), acc);
       }
-      if (RELU_OUT) acc = relu4_1op(acc);
-      st4(yb + static_cast<unsigned>((x0 + j * r) * ldy), acc);
     }
     return;
   }
   // ---- border wave: clamped addresses, zero padding by select ------------------
-  unsigned rowoff[3];
-  bool rowok[3];
+  unsigned rowoff[NR];
+  bool rowok[NR];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
+  for (int ky = 0; ky < NR; ++ky) {
     const int yi = y + (ky - 1) * r;
     rowok[ky] = yi >= 0 && yi < p.Hi;
     rowoff[ky] = (rowok[ky] ? yi : 0) * rowpitch;
@@ -216,10 +234,12 @@ __global__ __launch_bounds__(256, EPOS_DW_MIN_BLOCKS) void depthwise3x3_s1_kerne
     const bool xok = xi >= 0 && xi < p.Wi;
     const unsigned off = (xok ? xi : 0) * ldx;
 #ifdef EPOS_DW_ABL_ONEROW
-    col[i][1] = ld4(xb + (rowoff[1] + off)); col[i][0] = col[i][1]; col[i][2] = col[i][1];
+    col[i][1] = ld4(xb + (rowoff[1] + off));
+#pragma unroll
+    for (int ky = 0; ky < NR; ++ky) col[i][ky] = col[i][1];
 #else
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) col[i][ky] = ld4(xb + (rowoff[ky] + off));
+    for (int ky = 0; ky < NR; ++ky) col[i][ky] = ld4(xb + (rowoff[ky] + off));
 #endif
   }
 #pragma unroll
@@ -227,24 +247,28 @@ __global__ __launch_bounds__(256, EPOS_DW_MIN_BLOCKS) void depthwise3x3_s1_kerne
     const int xi = x0 + (i - 1) * r;
     const bool xok = xi >= 0 && xi < p.Wi;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+    for (int ky = 0; ky < NR; ++ky) {
       float4 v = col[i][ky];
       if (!(xok && rowok[ky])) v = make_float4(0.f, 0.f, 0.f, 0.f);
       col[i][ky] = RELU_IN ? relu4_1op(v) : v;
     }
   }
 #pragma unroll
-  for (int j = 0; j < L; ++j) {
-    const int x = x0 + j * r;
-    float4 acc = bias;
+  for (int rr = 0; rr < ROWS; ++rr) {
+    if (rr == 1 && !row1) break;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      acc = fma4(col[j][ky], w[ky * 3 + 0], acc);
-      acc = fma4(col[j + 1][ky], w[ky * 3 + 1], acc);
-      acc = fma4(col[j + 2][ky], w[ky * 3 + 2], acc);
+    for (int j = 0; j < L; ++j) {
+      const int x = x0 + j * r;
+      float4 acc = bias;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        acc = fma4(col[j][ky + rr], w[ky * 3 + 0], acc);
+        acc = fma4(col[j + 1][ky + rr], w[ky * 3 + 1], acc);
+        acc = fma4(col[j + 2][ky + rr], w[ky * 3 + 2], acc);
+      }
+      if (RELU_OUT) acc = relu4_1op(acc);
+      if (x < p.Wo) st4(yb + (static_cast<unsigned>(x * ldy) + (rr ? yrow1 : 0u)), acc);
     }
-    if (RELU_OUT) acc = relu4_1op(acc);
-    if (x < p.Wo) st4(yb + static_cast<unsigned>(x * ldy), acc);
   }
 }
 
@@ -531,7 +555,18 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
     const int nres = a->rate < a->Wo ? a->rate : a->Wo;
     const int per_res = static_cast<int>(ceil_div(a->Wo, a->rate));
     const int nchunk = static_cast<int>(ceil_div(per_res, L));
-    const int64_t runs = static_cast<int64_t>(a->B) * a->Ho * nres * nchunk;
+    // two output rows per thread (EPOS_DW_ROWS=1 keeps one: the A/B switch)
+    static const int rows_env = [] {
+      const char* e = getenv("EPOS_DW_ROWS");
+      return e ? atoi(e) : 2;
+    }();
+    // ... unless the launch would then not even give every CU one workgroup (the 60 x 80 x
+    // 256 tensor: 4.8 us with one row per thread, 6.7 with two)
+    const int64_t threads2 = static_cast<int64_t>(a->B) * ceil_div(a->Ho, 2) *
+                             ceil_div(a->Wo, L) * c4n;
+    const int ROWS = (rows_env == 1 || (rows_env != 22 && threads2 < 256 * 256)) ? 1 : 2;
+    const int nrows = ROWS == 2 ? static_cast<int>(ceil_div(a->Ho, 2 * a->rate)) * a->rate : a->Ho;
+    const int64_t runs = static_cast<int64_t>(a->B) * nrows * nres * nchunk;
     if (runs == 0) return EPOS_OK;
     EPOS_REQUIRE(runs * c4n < (1LL << 31) &&
                  static_cast<int64_t>(a->Hi) * a->Wi * a->ldx < (1LL << 29) &&
@@ -557,30 +592,34 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
     if (force_mode >= 0) part.mode = force_mode;
     if (c4n < 8) part.mode = 1;
     part.runs = static_cast<int>(runs);
-    part.rows = a->B * a->Ho;
+    part.rows = a->B * nrows;
     part.dwc[0] = fast_div(c4n / 8 > 0 ? c4n / 8 : 1);
     part.dwc[1] = fast_div(c4n / 8 + 1);
     part.dc4n = fast_div(c4n);
     part.dchunk = fast_div(nchunk);
     part.dres = fast_div(nres);
-    part.dho = fast_div(a->Ho);
+    part.dho = fast_div(nrows);
+    part.drate = fast_div(a->rate);
     int64_t per_xcd;                        // items of the busiest XCD
     if (part.mode == 0) per_xcd = runs * ceil_div(c4n, 8);
     else per_xcd = ceil_div(part.rows, 8) * nres * nchunk * c4n;
     const unsigned grid = 8 * blocks_for(per_xcd, threads);
     const int v = (a->relu_in ? 2 : 0) | (a->relu_out ? 1 : 0);
-    if (v == 0)
-      hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, false, false>), dim3(grid), dim3(threads),
-                         0, st, *a, c4n, nres, nchunk, part);
-    else if (v == 1)
-      hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, false, true>), dim3(grid), dim3(threads),
-                         0, st, *a, c4n, nres, nchunk, part);
-    else if (v == 2)
-      hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, true, false>), dim3(grid), dim3(threads),
-                         0, st, *a, c4n, nres, nchunk, part);
-    else
-      hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, true, true>), dim3(grid), dim3(threads),
-                         0, st, *a, c4n, nres, nchunk, part);
+#define EPOS_DW_LAUNCH(RI, RO, RW)                                                          \
+    hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, RI, RO, RW>), dim3(grid), dim3(threads), 0, \
+                       st, *a, c4n, nres, nchunk, nrows, part)
+    if (ROWS == 2) {
+      if (v == 0) EPOS_DW_LAUNCH(false, false, 2);
+      else if (v == 1) EPOS_DW_LAUNCH(false, true, 2);
+      else if (v == 2) EPOS_DW_LAUNCH(true, false, 2);
+      else EPOS_DW_LAUNCH(true, true, 2);
+    } else {
+      if (v == 0) EPOS_DW_LAUNCH(false, false, 1);
+      else if (v == 1) EPOS_DW_LAUNCH(false, true, 1);
+      else if (v == 2) EPOS_DW_LAUNCH(true, false, 1);
+      else EPOS_DW_LAUNCH(true, true, 1);
+    }
+#undef EPOS_DW_LAUNCH
     return launch_status("depthwise3x3_s1_kernel");
   }
   const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * c4n;

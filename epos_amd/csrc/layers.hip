@@ -547,7 +547,10 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
   const int c4n = a->C / 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->stride == 1 && a->Hi == a->Ho && a->Wi == a->Wo) {
-    constexpr int L = 4;
+#ifndef EPOS_DW_L
+#define EPOS_DW_L 4
+#endif
+    constexpr int L = EPOS_DW_L;
     static const int threads = [] {        // EPOS_DW_THREADS=64|128|256 (tuning)
       const char* e = getenv("EPOS_DW_THREADS");
       return e ? atoi(e) : 256;

@@ -332,3 +332,48 @@ def test_rccl_initialises_and_gathers_on_this_box():
       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), capture_output=True,
       text=True, timeout=600)
   assert 'RCCL_OK world=%d' % n in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_c1_single_object_frame():
+  """BASELINE config C1 ("single 640x480 synthetic RGB frame, 1 object, xc65-f64: the
+  plumbing / parity check"): one frame, one object, 64 fragments through the whole device
+  path -- heads against the torch-CPU oracle at 1e-4, correspondences bit-exact against
+  the numpy oracle, the pose against the C oracle."""
+  from epos_amd import model, pipeline, synthetic, weights
+  from oracle import corresp_ref, pnp_ref
+  O, F, H, W_ = 1, 64, 480, 640
+  ckpt = weights.random_init(num_objs=O, seed=4, randomize_bn=True)
+  store = synthetic.ModelStore(O, F, seed=3)
+  img = synthetic.image(0, H, W_)[None]
+  net0 = model.get_net(ckpt, 1, H, W_, O, F)
+  net0.forward(torch.from_numpy(img).cuda())
+  torch.cuda.synchronize()
+  synthetic.calibrate_logits(ckpt, net0.decoder_out[0].cpu().numpy())
+  model._NETS.clear()
+  del net0
+  pipe = pipeline.EposPipeline(ckpt, 1, H, W_, O, F, store, capacity=1 << 20,
+                               max_instances=1)
+  Ks = synthetic.YCBV_K[None]
+  poses, _ = pipe.process_batch(torch.from_numpy(img).cuda(), Ks, [{1: 1}], seed=2)
+  pred = {k: v.cpu().numpy() for k, v in pipe.net.forward().items()}
+  assert pred['pred_obj_conf'].shape == (1, 120, 160, 2)
+  assert pred['pred_frag_loc'].shape == (1, 120, 160, 1, 64, 3)
+  _assert_heads_match_oracle(pred, img, ckpt, O, F)
+  # the operator form gives the oracle's correspondences bit for bit
+  from epos_amd import corresp
+  got = corresp.establish_many_to_many(pred['pred_obj_conf'][0], pred['pred_frag_conf'][0],
+                                       pred['pred_frag_loc'][0], [1], store, 0.25, 0.1, 0.5,
+                                       False, True)
+  ref = corresp_ref.establish_many_to_many(
+      pred['pred_obj_conf'][0], pred['pred_frag_conf'][0], pred['pred_frag_loc'][0], [1],
+      store.dp_model['obj_ids'], store.frag_centers, store.frag_sizes, 0.25, 0.1, 0.5, True)
+  assert set(got) == set(ref) == {1}
+  for k in ref[1]:
+    assert got[1][k].dtype == ref[1][k].dtype and np.array_equal(got[1][k], ref[1][k]), k
+  s = (2 * 1000003 + 0 * 1009 + 1) & 0x7fffffffffffffff
+  rp, _, rs = pnp_ref.find6DPoses(ref[1]['coord_2d'], ref[1]['coord_3d'], Ks[0], seed=s,
+                                  max_k=1)
+  assert (rp is None) == (len(poses) == 0)
+  if rp is not None:
+    np.testing.assert_allclose(np.hstack([poses[0]['R'], poses[0]['t']]), rp[:3], atol=1e-9)
+    np.testing.assert_allclose(poses[0]['score'], rs[0], rtol=1e-12)

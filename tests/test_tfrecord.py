@@ -157,3 +157,90 @@ def test_crop_offset_and_principal_point_shift():
   np.testing.assert_array_equal(s2['image'], full[oh:oh + 48, ow:ow + 64])
   with pytest.raises(ValueError):
     tfrecord.decode_sample(feats, (64, 48), 480, crop_offset=(13, 0))
+
+
+def _google_example_class():
+  """tf.train.Example's schema (tensorflow/core/example/{example,feature}.proto: public
+  field numbers) declared at run time for Google's protobuf library -- an independent
+  encoder / decoder of the same wire format."""
+  from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+  fd = descriptor_pb2.FileDescriptorProto(name='epos_test_example.proto', package='epostest',
+                                          syntax='proto3')
+  T = descriptor_pb2.FieldDescriptorProto
+
+  def msg(name, fields):
+    m = fd.message_type.add(name=name)
+    for fname, num, typ, label, tname in fields:
+      f = m.field.add(name=fname, number=num, type=typ, label=label)
+      if tname:
+        f.type_name = tname
+    return m
+  msg('BytesList', [('value', 1, T.TYPE_BYTES, T.LABEL_REPEATED, None)])
+  msg('FloatList', [('value', 1, T.TYPE_FLOAT, T.LABEL_REPEATED, None)])
+  msg('Int64List', [('value', 1, T.TYPE_INT64, T.LABEL_REPEATED, None)])
+  feat = msg('Feature', [('bytes_list', 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.epostest.BytesList'),
+                         ('float_list', 2, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.epostest.FloatList'),
+                         ('int64_list', 3, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.epostest.Int64List')])
+  feat.oneof_decl.add(name='kind')
+  for f in feat.field:
+    f.oneof_index = 0
+  feats = msg('Features', [('feature', 1, T.TYPE_MESSAGE, T.LABEL_REPEATED,
+                            '.epostest.Features.FeatureEntry')])
+  entry = feats.nested_type.add(name='FeatureEntry')
+  entry.options.map_entry = True
+  entry.field.add(name='key', number=1, type=T.TYPE_STRING, label=T.LABEL_OPTIONAL)
+  entry.field.add(name='value', number=2, type=T.TYPE_MESSAGE, label=T.LABEL_OPTIONAL,
+                  type_name='.epostest.Feature')
+  msg('Example', [('features', 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, '.epostest.Features')])
+  pool = descriptor_pool.DescriptorPool()
+  pool.Add(fd)
+  return message_factory.GetMessageClass(pool.FindMessageTypeByName('epostest.Example'))
+
+
+def test_example_wire_format_against_googles_protobuf_library():
+  """The hand-written tf.Example parser / encoder against Google's protobuf runtime on
+  the published schema, both directions: what protobuf serialises (packed repeated
+  scalars, map entries in its own order, negative int64 as 10-byte varints) parses to
+  the same dict, and what this module encodes protobuf parses back. Pins the wire-format
+  half of the TFRecord reader to an independent implementation (TensorFlow itself is not
+  installable here)."""
+  Example = _google_example_class()
+  rng = np.random.RandomState(0)
+  img = _png_bytes(rng.randint(0, 256, (12, 16, 3)).astype(np.uint8))
+  feats = {
+      'image/encoded': [img], 'image/path': [b'scene/rgb/000001.png', b''],
+      'image/scene_id': [48], 'image/im_id': [1], 'image/height': [480],
+      'image/object/id': [2, 5, 21, -1, 3 << 40],
+      'image/camera/fx': [1066.778], 'image/object/visibility': [0.9, 0.05, 1.0],
+      'image/object/pose/q1': [float(np.float32(x)) for x in rng.standard_normal(7)],
+      'empty/int': [],
+  }
+  ex = Example()
+  for k, v in feats.items():
+    f = ex.features.feature[k]
+    if v and isinstance(v[0], bytes):
+      f.bytes_list.value.extend(v)
+    elif v and isinstance(v[0], float):
+      f.float_list.value.extend(v)
+    else:
+      f.int64_list.value.extend(v)
+  parsed = tfrecord.parse_example(ex.SerializeToString())
+  for k, v in feats.items():
+    got = parsed.get(k, [])
+    if v and isinstance(v[0], float):
+      np.testing.assert_array_equal(np.float32(got), np.float32(v), err_msg=k)
+    else:
+      assert got == v, k
+  # the other direction: this module's encoder, Google's parser
+  back = Example()
+  back.ParseFromString(tfrecord.encode_example({k: v for k, v in feats.items() if v}))
+  for k, v in feats.items():
+    if not v:
+      continue
+    f = back.features.feature[k]
+    if isinstance(v[0], bytes):
+      assert list(f.bytes_list.value) == v, k
+    elif isinstance(v[0], float):
+      np.testing.assert_array_equal(np.float32(list(f.float_list.value)), np.float32(v))
+    else:
+      assert list(f.int64_list.value) == v, k

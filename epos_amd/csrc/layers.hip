@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
 // divisions by launch constants use precomputed multipliers, ReLU is one v_med3 per
 // component and a compile-time option, and a wave whose lanes all lie in the interior
 // of the image (no tap outside) takes a path without any clamp or select.
+#ifndef EPOS_DW_REP
+#define EPOS_DW_REP 1     // x-runs per thread (they share the nine weight vectors)
+#endif
 #ifndef EPOS_DW_MIN_BLOCKS
 #define EPOS_DW_MIN_BLOCKS 4     // <= 128 VGPRs: see DESIGN.md (co-residency with GEMM waves)
 #endif
@@ -164,8 +167,7 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? 3 : EPOS_DW_MIN_BLOCKS)) void dep
     const unsigned g = fdiv(static_cast<unsigned>(ys), part.drate);
     y = static_cast<int>(2 * r * g + (ys - g * r));
   }
-  const int x0 = res + chunk * L * r;
-  live = live && x0 < p.Wo && y < p.Ho;
+  live = live && res + chunk * (EPOS_DW_REP * L) * r < p.Wo && y < p.Ho;
   if (!live) return;
   const bool row1 = ROWS == 2 && y + r < p.Ho;   // the pair's second row exists
   float4 w[9];
@@ -184,6 +186,11 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? 3 : EPOS_DW_MIN_BLOCKS)) void dep
   const int ldx = static_cast<int>(p.ldx), ldy = static_cast<int>(p.ldy);
   const int rowpitch = p.Wi * ldx;
   const unsigned yrow1 = static_cast<unsigned>(r * p.Wo * ldy);   // output row y + rate
+  // EPOS_DW_REP consecutive runs per thread share the weight vectors
+#pragma unroll 1
+  for (int rep = 0; rep < EPOS_DW_REP; ++rep) {
+  const int x0 = res + (chunk * EPOS_DW_REP + rep) * L * r;
+  if (x0 >= p.Wo) break;
   // every tap of every output of this run inside the image?
   const bool interior = y - r >= 0 && y + (ROWS == 2 ? 2 : 1) * r < p.Hi && x0 - r >= 0 &&
                         x0 + L * r < p.Wi && (ROWS == 1 || row1);
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? 3 : EPOS_DW_MIN_BLOCKS)) void dep
         st4(yb + (static_cast<unsigned>((x0 + j * r) * ldy) + (rr ? yrow1 : 0u)), acc);
       }
     }
-    return;
+    continue;
   }
   // ---- border wave: clamped addresses, zero padding by select ------------------
   unsigned rowoff[NR];
@@ -270,6 +277,7 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? 3 : EPOS_DW_MIN_BLOCKS)) void dep
       if (x < p.Wo) st4(yb + (static_cast<unsigned>(x * ldy) + (rr ? yrow1 : 0u)), acc);
     }
   }
+  }   // rep
 }
 
 // --------------------------------------------------------------------------
@@ -557,7 +565,7 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
     }();
     const int nres = a->rate < a->Wo ? a->rate : a->Wo;
     const int per_res = static_cast<int>(ceil_div(a->Wo, a->rate));
-    const int nchunk = static_cast<int>(ceil_div(per_res, L));
+    const int nchunk = static_cast<int>(ceil_div(per_res, L * EPOS_DW_REP));
     // two output rows per thread (EPOS_DW_ROWS=1 keeps one: the A/B switch)
     static const int rows_env = [] {
       const char* e = getenv("EPOS_DW_ROWS");

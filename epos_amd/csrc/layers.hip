@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
 #ifndef EPOS_DW_MIN_BLOCKS
 #define EPOS_DW_MIN_BLOCKS 4     // <= 128 VGPRs: see DESIGN.md (co-residency with GEMM waves)
 #endif
+#ifndef EPOS_DW_MIN_BLOCKS2
+#define EPOS_DW_MIN_BLOCKS2 3    // the two-row kernel: <= 168 VGPRs
+#endif
 struct FastDiv {                 // n / d for any 32-bit n (Granlund-Montgomery)
   unsigned mul, sh1, sh2, d;
 };
@@ -126,7 +129,7 @@ __device__ __forceinline__ float4 relu4_1op(float4 v) {
 // rows are taken in groups of 2 * rate; slot (g, i), i < rate, owns rows 2*rate*g + i and
 // + rate. Same fmaf chain per output as ROWS = 1: identical bits.
 template <int L, bool RELU_IN, bool RELU_OUT, int ROWS>
-__global__ __launch_bounds__(256, (ROWS == 2 ? 3 : EPOS_DW_MIN_BLOCKS)) void depthwise3x3_s1_kernel(
+__global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN_BLOCKS)) void depthwise3x3_s1_kernel(
     EposDepthwiseArgs p, int c4n, int nres, int nchunk, int nrows, DwPartition part) {
   constexpr int NR = ROWS + 2;                 // input rows held per column
   const int xcd = blockIdx.x & 7;

@@ -109,6 +109,15 @@ class FitParams(ctypes.Structure):
   ]
 
 
+class PnpRansacParams(ctypes.Structure):
+  _fields_ = [
+      ('iterations_count', ctypes.c_int32),
+      ('reserved', ctypes.c_int32),
+      ('reprojection_error', ctypes.c_double),
+      ('confidence', ctypes.c_double),
+  ]
+
+
 # Every symbol include/epos_hip.h declares: name -> (restype, argtypes or None).
 SYMBOLS = {
     'epos_abi_version': (ctypes.c_int, []),
@@ -176,6 +185,14 @@ SYMBOLS = {
     'epos_find6d_poses_device': (ctypes.c_int, [
         vp, vp, vp, ctypes.c_int, ctypes.c_int64, vp, vp, vp,
         ctypes.POINTER(FitParams), ctypes.c_int32, vp, vp, vp, vp, vp, vp]),
+    'epos_pnp_ransac_params_default': (None, [ctypes.POINTER(PnpRansacParams)]),
+    'epos_solve_pnp_ransac': (ctypes.c_int, [
+        vp, vp, ctypes.c_int64, vp, ctypes.POINTER(PnpRansacParams), vp, vp, vp]),
+    'epos_pnp_ransac_workspace_bytes': (ctypes.c_int64, [
+        ctypes.c_int, ctypes.c_int64, ctypes.POINTER(PnpRansacParams)]),
+    'epos_solve_pnp_ransac_device': (ctypes.c_int, [
+        vp, vp, vp, ctypes.c_int, ctypes.c_int64, vp, ctypes.POINTER(PnpRansacParams),
+        vp, vp, vp, vp, vp, vp]),
 }
 
 _lib = None
@@ -209,7 +226,7 @@ def load():
     fn.restype = restype
     if argtypes is not None:
       fn.argtypes = argtypes
-  if lib.epos_abi_version() != 3:
+  if lib.epos_abi_version() != 4:
     raise EposError('libepos_hip.so ABI version mismatch')
   _lib = lib
   return lib

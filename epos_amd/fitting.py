@@ -5,6 +5,9 @@ reference imports (scripts/infer.py:470-488; un-vendored danini/progressive-x).
 float64 ``x1y1 [n,2]`` / ``x2y2z2 [n,3]``, ``K [3,3]``) and return convention:
 ``(poses [3k,4] or None, labels, scores)``. The work runs in the HIP kernels of
 csrc/pnp_ransac.hip through the C ABI ``epos_find6d_poses``; there is no CPU path.
+
+``solvePnPRansac`` / ``Rodrigues`` stand in for the two cv2 calls of the reference's
+alternative fitting method (``--fitting_method=opencv_ransac``, infer.py:505-528).
 """
 import ctypes
 
@@ -88,3 +91,84 @@ def find6DPoses(x1y1, x2y2z2, K, threshold=4.0, neighborhood_ball_radius=20.0,
     out[3 * i:3 * i + 3, :3] = poses[i, :9].reshape(3, 3)
     out[3 * i:3 * i + 3, 3] = poses[i, 9:]
   return out, labels[:n], scores[:k]
+
+
+SOLVEPNP_EPNP = 1          # cv2.SOLVEPNP_EPNP
+
+
+def Rodrigues(src):
+  """cv2.Rodrigues for the two shapes the reference uses (infer.py:526): a rotation
+  vector [3] / [3,1] -> R [3,3], or R [3,3] -> the rotation vector [3,1]. Host numpy."""
+  a = np.asarray(src, np.float64)
+  if a.size == 3:
+    r = a.reshape(3)
+    th = float(np.linalg.norm(r))
+    if th < 1e-300:
+      return np.eye(3)
+    k = r / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) * np.cos(th) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * Kx
+  if a.shape != (3, 3):
+    raise ValueError('Rodrigues: expected 3 or 3x3 values')
+  w = np.array([a[2, 1] - a[1, 2], a[0, 2] - a[2, 0], a[1, 0] - a[0, 1]])
+  s, c = 0.5 * np.linalg.norm(w), 0.5 * (np.trace(a) - 1.0)
+  th = np.arctan2(s, c)
+  if s > 1e-8:
+    return (w / (2.0 * s) * th).reshape(3, 1)
+  if c > 0:                                            # theta ~ 0
+    return (0.5 * w).reshape(3, 1)
+  B = 0.5 * (a + np.eye(3))                            # theta ~ pi: R = 2 k k^T - I
+  k = np.sqrt(np.maximum(np.diag(B), 0.0))
+  i = int(np.argmax(k))
+  k = np.where(B[i] < 0, -k, k)
+  k[i] = abs(k[i])
+  return (k / np.linalg.norm(k) * th).reshape(3, 1)
+
+
+def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None,
+                   iterationsCount=100, reprojectionError=8.0, confidence=0.99,
+                   flags=SOLVEPNP_EPNP, return_pose=False, return_info=False):
+  """cv2.solvePnPRansac with flags=cv2.SOLVEPNP_EPNP as the reference calls it
+  (scripts/infer.py:510-518), on the GPU through ``epos_solve_pnp_ransac``
+  (csrc/epnp_ransac.hip; there is no CPU path). Same keyword names and defaults, same
+  result tuple ``(success, rvec [3,1], tvec [3,1], inliers int32[m,1] or None)``.
+  ``return_pose=True`` appends the [3,4] pose (R | t) the kernels computed, so that a
+  caller can skip the rvec round trip; ``return_info=True`` appends int32[4] = (index of
+  the winning minimal set, its inlier count, the final iteration cap, sets evaluated)."""
+  if distCoeffs is not None and np.any(np.asarray(distCoeffs) != 0):
+    raise NotImplementedError('solvePnPRansac: distortion coefficients are not supported '
+                              '(the reference passes None, infer.py:514)')
+  if flags != SOLVEPNP_EPNP:
+    raise NotImplementedError('solvePnPRansac: only flags=SOLVEPNP_EPNP (infer.py:518)')
+  xyz = np.ascontiguousarray(np.asarray(objectPoints, np.float64).reshape(-1, 3))
+  xy = np.ascontiguousarray(np.asarray(imagePoints, np.float64).reshape(-1, 2))
+  if xy.shape[0] != xyz.shape[0]:
+    raise ValueError('objectPoints and imagePoints differ in length')
+  Kd = np.ascontiguousarray(cameraMatrix, np.float64).reshape(9)
+  n = xy.shape[0]
+  p = _lib.PnpRansacParams()
+  lib = _lib.load()
+  lib.epos_pnp_ransac_params_default(ctypes.byref(p))
+  p.iterations_count = int(iterationsCount)
+  p.reprojection_error = float(reprojectionError)
+  p.confidence = float(confidence)
+  pose = np.zeros(12, np.float64)
+  mask = np.zeros(max(n, 1), np.uint8)
+  info = np.zeros(4, np.int32)
+  vp = ctypes.c_void_p
+  ok = _lib.check(lib.epos_solve_pnp_ransac(
+      xy.ctypes.data_as(vp), xyz.ctypes.data_as(vp), n, Kd.ctypes.data_as(vp),
+      ctypes.byref(p), pose.ctypes.data_as(vp), mask.ctypes.data_as(vp),
+      info.ctypes.data_as(vp)), 'epos_solve_pnp_ransac')
+  if ok:
+    P = np.concatenate([pose[:9].reshape(3, 3), pose[9:].reshape(3, 1)], axis=1)
+    res = (True, Rodrigues(P[:, :3]), P[:, 3:].copy(),
+           np.nonzero(mask[:n])[0].astype(np.int32).reshape(-1, 1))
+  else:
+    P = None
+    res = (False, None, None, None)
+  if return_pose:
+    res += (P,)
+  if return_info:
+    res += (info,)
+  return res

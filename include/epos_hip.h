@@ -33,7 +33,7 @@ extern "C" {
 #define EPOS_E_NODEVICE (-3)  /* no HIP device available */
 #define EPOS_E_HIP_BASE (-1000)
 
-#define EPOS_ABI_VERSION 3   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32 */
+#define EPOS_ABI_VERSION 4   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32; 4: epos_solve_pnp_ransac */
 
 int epos_abi_version(void);
 const char* epos_last_error(void);
@@ -367,6 +367,50 @@ int epos_find6d_poses_device(const double* xy, const double* xyz,
                              int32_t max_k, void* work, double* poses,
                              double* scores, int32_t* num_models, int32_t* labels,
                              void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * The OpenCV fitting method (replaces cv2.solvePnPRansac(objectPoints, imagePoints, K,
+ * None, iterationsCount, reprojectionError, confidence=0.99, flags=cv2.SOLVEPNP_EPNP),
+ * scripts/infer.py:505-528; OpenCV 3.4.2, README.md:29, is not vendored).
+ * What is computed (the published behaviour of that call, restated):
+ *   - points are rounded to float32 on entry; minimal sets of 5 correspondences drawn by
+ *     cv::RNG (state 2^64 - 1, `next() % n`, repeated indices re-drawn);
+ *   - EPnP (Lepetit et al., IJCV 2009) on each set -> one pose; its inliers: squared
+ *     reprojection error, float32 arithmetic on the float32 projection, <= (float)err^2;
+ *   - a set with strictly more inliers than the best so far (and > 4) becomes the best and
+ *     the iteration cap becomes round(log(1 - confidence) / log(1 - w^5));
+ *   - EPnP once more over ALL inliers of the best set: that pose is returned.
+ * Own factorisations (cyclic Jacobi, Householder QR) instead of cv::SVD: poses agree with
+ * an LAPACK-based statement of EPnP to ~1e-9, not bit for bit with OpenCV -- unpinned.
+ * ------------------------------------------------------------------------- */
+typedef struct EposPnpRansacParams {
+  int32_t iterations_count;     /* max_fitting_iterations (400)       infer.py:515 */
+  int32_t reserved;
+  double reprojection_error;    /* inlier_thresh (4.0 px)             infer.py:516 */
+  double confidence;            /* 0.99                               infer.py:517 */
+} EposPnpRansacParams;
+void epos_pnp_ransac_params_default(EposPnpRansacParams* p);
+
+/* Host-pointer drop-in: xy f64[n,2] (imagePoints), xyz f64[n,3] (objectPoints), K f64[9]
+ * row-major (fx, fy, cx, cy are used, as by OpenCV without distortion). Outputs
+ * (caller-owned): pose_out f64[12] = row-major [R | t] (R = Rodrigues(rvec) of the
+ * reference), inlier_mask_out u8[n], info_out i32[4] or NULL = {index of the winning set,
+ * its inlier count, the final iteration cap, sets evaluated}. Returns 1 (pose found),
+ * 0 (`pose_est_success` false) or < 0. */
+int epos_solve_pnp_ransac(const double* xy, const double* xyz, int64_t n, const double* K,
+                          const EposPnpRansacParams* p, double* pose_out,
+                          uint8_t* inlier_mask_out, int32_t* info_out);
+
+/* Batched device entry (slots as for epos_find6d_poses_device), all buffers [device]:
+ * poses f64[S,12], success i32[S], inlier_mask u8[N], info i32[S,4] or NULL;
+ * work = epos_pnp_ransac_workspace_bytes(S, N_capacity, p) bytes. Nothing synchronises. */
+int64_t epos_pnp_ransac_workspace_bytes(int S, int64_t n_capacity,
+                                        const EposPnpRansacParams* p);
+int epos_solve_pnp_ransac_device(const double* xy, const double* xyz,
+                                 const int64_t* slot_base, int S, int64_t n_capacity,
+                                 const double* Ks, const EposPnpRansacParams* p, void* work,
+                                 double* poses, int32_t* success, uint8_t* inlier_mask,
+                                 int32_t* info, void* stream);
 
 #ifdef __cplusplus
 }

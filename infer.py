@@ -379,25 +379,29 @@ def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
                   if args.task_type == pipeline.LOCALIZATION else -1)
       if args.max_instances_to_fit is not None:
         num_inst = min(num_inst, args.max_instances_to_fit)
-      opencv = args.fitting_method == 'opencv_ransac'
-      if opencv:
-        # infer.py:505-528, cv2.solvePnPRansac(iterationsCount=max_fitting_iterations,
-        # reprojectionError=inlier_thresh, confidence=0.99, flags=EPNP): ONE instance per
-        # object, RANSAC stopped by the 0.99 confidence bound, no spatial coherence, no
-        # coverage / Tanimoto test, refit on all inliers, score 0.0. cv2 is not available:
-        # the hypotheses come from this build's P3P solver (OpenCV: EPnP on 5-point
-        # samples) and the final refit is Gauss-Newton on the inliers (OpenCV: EPnP on the
-        # inliers) -- same contract, different minimal solver; parity unpinned.
-        num_inst = 1
+      if args.fitting_method == 'opencv_ransac':
+        # infer.py:505-528: cv2.solvePnPRansac(EPNP) -- ONE instance per object, score 0.0.
+        # OpenCV is not in this stack; epos_amd.fitting.solvePnPRansac runs the same
+        # algorithm (5-point EPnP sets drawn by cv::RNG, float32 inlier rule, the 0.99
+        # confidence bound, EPnP over the inliers) in HIP -- csrc/epnp_ransac.hip.
+        ok, r_est, t_est, _ = fitting.solvePnPRansac(
+            objectPoints=c['coord_3d'], imagePoints=c['coord_2d'], cameraMatrix=f[3],
+            distCoeffs=None, iterationsCount=fit.max_iters,
+            reprojectionError=fit.threshold, confidence=0.99,
+            flags=fitting.SOLVEPNP_EPNP)
+        if ok:
+          poses.append({'scene_id': f[0], 'im_id': f[1], 'obj_id': obj_id,
+                        'R': fitting.Rodrigues(r_est), 't': t_est, 'score': 0.0})
+        continue
       est, _, quals = fitting.find6DPoses(
           c['coord_2d'], c['coord_3d'], f[3], threshold=fit.threshold,
           neighborhood_ball_radius=fit.neighborhood_ball_radius,
-          spatial_coherence_weight=0.0 if opencv else fit.spatial_coherence_weight,
+          spatial_coherence_weight=fit.spatial_coherence_weight,
           scaling_from_millimeters=fit.scaling_from_millimeters,
           max_tanimoto_similarity=fit.max_tanimoto_similarity,
           max_iters=fit.max_iters, conf=fit.conf,
-          proposal_engine_conf=0.99 if opencv else fit.proposal_engine_conf,
-          min_coverage=0.0 if opencv else fit.min_coverage,
+          proposal_engine_conf=fit.proposal_engine_conf,
+          min_coverage=fit.min_coverage,
           min_triangle_area=fit.min_triangle_area, min_point_number=6,
           max_model_number=num_inst,
           max_model_number_for_optimization=fit.max_model_number_for_optimization,
@@ -408,7 +412,7 @@ def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
           poses.append({'scene_id': f[0], 'im_id': f[1], 'obj_id': obj_id,
                         'R': est[3 * i:3 * i + 3, :3],
                         't': est[3 * i:3 * i + 3, 3].reshape(3, 1),
-                        'score': 0.0 if opencv else float(quals[i])})
+                        'score': float(quals[i])})
     t_fit += time.time() - tf_
   rt = {'prediction': t1 - t0, 'establish_corr': t_corr, 'fitting': t_fit}
   rt['total'] = sum(rt.values())

@@ -592,16 +592,27 @@ __global__ __launch_bounds__(64) void cvr_samples(const int64_t* slot_base, int 
   }
   uint64_t st = 0xffffffffffffffffull;
   const uint32_t nn = static_cast<uint32_t>(n);
-  for (int it = 0; it < w.iters; ++it) {
-    int32_t set[EP_SET];
-    for (int i = 0; i < EP_SET;) {
-      st = static_cast<uint64_t>(static_cast<uint32_t>(st)) * 4164903690u + static_cast<uint32_t>(st >> 32);
-      const int32_t c = static_cast<int32_t>(static_cast<uint32_t>(st) % nn);
-      bool dup = false;
-      for (int j = 0; j < i; ++j) dup = dup || set[j] == c;
-      if (!dup) set[i++] = c;
-    }
-    for (int i = 0; i < EP_SET; ++i) out[it * EP_SET + i] = set[i];
+  // x % nn without a division in the loop (Granlund-Montgomery, exact for any 32-bit x)
+  uint32_t l = 0;
+  while ((1ull << l) < nn) ++l;
+  const uint32_t mul = static_cast<uint32_t>(((1ull << 32) * ((1ull << l) - nn)) / nn + 1);
+  const uint32_t sh1 = l > 0 ? 1 : 0, sh2 = l > 0 ? l - 1 : 0;
+  auto draw = [&]() {
+    st = static_cast<uint64_t>(static_cast<uint32_t>(st)) * 4164903690u + static_cast<uint32_t>(st >> 32);
+    const uint32_t x = static_cast<uint32_t>(st);
+    const uint32_t th = __umulhi(mul, x);
+    const uint32_t quo = (th + ((x - th) >> sh1)) >> sh2;
+    return static_cast<int32_t>(x - quo * nn);
+  };
+  for (int it = 0; it < w.iters; ++it) {       // the set stays in registers (static indices)
+    int32_t s0, s1, s2, s3, s4;
+    s0 = draw();
+    do { s1 = draw(); } while (s1 == s0);
+    do { s2 = draw(); } while (s2 == s0 || s2 == s1);
+    do { s3 = draw(); } while (s3 == s0 || s3 == s1 || s3 == s2);
+    do { s4 = draw(); } while (s4 == s0 || s4 == s1 || s4 == s2 || s4 == s3);
+    int32_t* o = out + it * EP_SET;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4;
   }
 }
 

@@ -21,4 +21,8 @@ Pieces (each module cites the reference file:line it restates):
                       ``version-epos``, commit not recorded in the tree); its source
                       is absent, so this part is **parity unpinned** and validated
                       against synthetic known poses instead.
+* ``epnp_ref.c``   -- plain-C restatement of ``cv2.solvePnPRansac(..., SOLVEPNP_EPNP)``
+                      (scripts/infer.py:505-528). OpenCV is not installed here:
+                      **parity unpinned**; checked against an independent numpy
+                      statement of EPnP and of the RANSAC loop.
 """

@@ -83,6 +83,9 @@ def parse_args():
                   help='evaluate the fragment heads only for the target objects of '
                        'each image (identical poses, fewer FLOPs); default: dense '
                        'heads as model.predict defines them')
+  ap.add_argument('--fitting-method', default='progressive_x',
+                  choices=['progressive_x', 'opencv_ransac'],
+                  help='infer.py --fitting_method; the metric is quoted on the default')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-roofline', action='store_true')
   ap.add_argument('--cpu-baseline-images', type=int, default=8,
@@ -255,7 +258,7 @@ def main():
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
       capacity=1 << 21, max_instances=1, device=dev,
       use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads,
-      model_options=mo)
+      model_options=mo, fitting_method=args.fitting_method)
            for j in range(depth)]
   pipe = pipes[0]
   # Synthetic frames, resident in HBM before the timed region.
@@ -356,6 +359,7 @@ def main():
                               if torch.distributed.is_initialized() else 1),
           'hip_graph': not args.no_graph, 'pipeline_depth': depth,
           'heads': 'sparse (target objects only)' if args.sparse_heads else 'dense',
+          'fitting_method': args.fitting_method,
           'corr_per_slot_last_step': [int(x) for x in totals[:, 1]],
           'poses_per_step': round(n_poses / max(args.steps, 1), 2),
           'algorithmic_gflop_per_image': round(pipe.net.flops / B / 1e9, 1),
@@ -427,7 +431,8 @@ def main():
     roof['achieved_in_pipeline'] = round(
         value / world * gemm_gflop / 1e3, 2)   # GEMM flops only, all streams busy
     result['roofline'] = roof
-  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+  if (rank == 0 and world == 1 and not args.no_cpu_baseline
+      and args.fitting_method == 'progressive_x'):
     result['cpu_baseline'] = cpu_baseline(ckpt, store, args,
                                           args.cpu_baseline_images)
   edist.barrier()

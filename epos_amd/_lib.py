@@ -112,7 +112,7 @@ class FitParams(ctypes.Structure):
 class PnpRansacParams(ctypes.Structure):
   _fields_ = [
       ('iterations_count', ctypes.c_int32),
-      ('reserved', ctypes.c_int32),
+      ('min_point_number', ctypes.c_int32),
       ('reprojection_error', ctypes.c_double),
       ('confidence', ctypes.c_double),
   ]

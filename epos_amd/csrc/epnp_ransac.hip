@@ -11,8 +11,9 @@
 //   * cvr_hypotheses: ONE MINIMAL SET PER WAVEFRONT, grid = (iterations / 4, slots). The 64
 //     lanes run the wave-uniform part of EPnP redundantly (control points, the 6 x 10 system,
 //     the three beta initialisations + Gauss-Newton, absolute orientation); the 12 x 12
-//     symmetric eigenproblem -- four fifths of the flops -- is a cyclic Jacobi held in LDS
-//     whose rotations are applied by 12 lanes at once (one per row); the inliers of the
+//     symmetric eigenproblem -- four fifths of the flops -- is a Jacobi iteration held in LDS
+//     in round-robin order: the six disjoint rotations of a round are applied at once, every
+//     lane updating its three entries of the matrix; the inliers of the
 //     resulting pose are counted with the lanes strided over the slot's correspondences.
 //   * cvr_select_fit: one workgroup per slot. RANSAC's "keep the best, shrink the iteration
 //     bound" is replayed over the table of inlier counts in iteration order by one lane
@@ -29,7 +30,10 @@
 namespace epos {
 namespace {
 
-constexpr int EP_SWEEPS = 12;
+#ifndef EPOS_EP_SWEEPS
+#define EPOS_EP_SWEEPS 12      // timing experiments only: the oracle uses 12
+#endif
+constexpr int EP_SWEEPS = EPOS_EP_SWEEPS;
 constexpr int EP_SET = 5;            // model_points of solvePnPRansac for EPNP
 
 struct EpCam { double fu, fv, uc, vc; };
@@ -89,53 +93,103 @@ __device__ void jacobi3(double* A, double* V) {
   }
 }
 
-// The same for the 12 x 12 matrix in LDS, by ONE wavefront: a rotation (p, q) touches rows /
-// columns p and q only and every updated entry depends on values from before the rotation,
-// so lane k < 12 applies it to row k of A (mirrored into the columns) and of V.
-__device__ void jacobi12_wave(double* A, double* V, int lane) {
+// The 12 x 12 problem in LDS, by ONE wavefront, in ROUND-ROBIN order: a sweep is 11 rounds of
+// 6 disjoint pairs (round r, pair m: (r, 11) for m = 0, else ((r + m) mod 11, (r - m) mod 11);
+// the first index plays "p", the second "q" -- a rotation gives the same bits with the roles
+// swapped, so no sorting). The six rotations of a round commute; the oracle applies them one
+// after the other in the order m = 0..5, which fixes the rounding of an entry (i, j) whose row
+// belongs to pair a and whose column to pair b: first the rotation of min(a, b) along its
+// index, then the other one. Here lanes 0..5 compute the six angles, then every lane
+// evaluates that expression for its three entries of A and of V from the values of BEFORE
+// the round. A lane owns the same (pair, role) x (pair, role) slots in every round -- what
+// changes with the round is only which matrix indices the pairs stand for -- so everything
+// about the slot (which formula, which rotation parameters) is decided once, outside the loops.
+__device__ __forceinline__ int rr_first(int m, int r) { const int v = r + m; return m == 0 ? r : (v >= 11 ? v - 11 : v); }
+__device__ __forceinline__ int rr_second(int m, int r) { const int v = r - m; return m == 0 ? 11 : (v < 0 ? v + 11 : v); }
+__device__ __forceinline__ void jacobi12_wave(double* A, double* V, double* R /*[6][4]*/, int lane) {
   for (int e = lane; e < 144; e += 64) V[e] = (e % 13 == 0) ? 1.0 : 0.0;
+  int ma[3], mb[3], vk[3], mx[3];
+  bool ra[3], rb[3], swp[3], same[3], diag[3], rx[3], live[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    int e = lane + 64 * u;
+    live[u] = e < 144;
+    e = live[u] ? e : 0;
+    int a = e / 24, b = (e % 12) / 2;
+    bool qa = (e / 12) % 2 != 0, qb = e % 2 != 0;
+    vk[u] = e / 12; mx[u] = b; rx[u] = qb;                   // V[k][(pair, role)]
+    swp[u] = a > b;
+    if (swp[u]) { const int t = a; a = b; b = t; const bool tq = qa; qa = qb; qb = tq; }
+    ma[u] = a; mb[u] = b; ra[u] = qa; rb[u] = qb;
+    same[u] = a == b; diag[u] = a == b && qa == qb;
+  }
   wave_sync();
   for (int sweep = 0; sweep < EP_SWEEPS; ++sweep) {
     bool rotated = false;
-    for (int p = 0; p < 11; ++p)
-      for (int q = p + 1; q < 12; ++q) {
+    for (int r = 0; r < 11; ++r) {
+      if (lane < 6) {                      // flag 0: untouched, 1: a_pq := 0, 2: rotate
+        const int m = lane;
+        const int p = rr_first(m, r), q = rr_second(m, r);
         const double apq = A[p * 12 + q];
-        if (apq == 0.0) continue;
-        const double app = A[p * 12 + p], aqq = A[q * 12 + q];
-        if (fabs(apq) <= 8.673617379884035e-19 * (fabs(app) + fabs(aqq))) {
-          wave_sync();
-          if (lane == 0) { A[p * 12 + q] = 0.0; A[q * 12 + p] = 0.0; }
-          wave_sync();
-          continue;
-        }
-        const double theta = (aqq - app) / (2.0 * apq);
-        double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-        if (theta < 0.0) t = -t;
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        double np_ = 0.0, nq_ = 0.0, vp = 0.0, vq = 0.0;
-        const int k = lane;
-        if (k < 12) {
-          const double akp = A[k * 12 + p], akq = A[k * 12 + q];
-          np_ = c * akp - s * akq; nq_ = s * akp + c * akq;
-          const double vkp = V[k * 12 + p], vkq = V[k * 12 + q];
-          vp = c * vkp - s * vkq; vq = s * vkp + c * vkq;
-        }
-        wave_sync();                                 // all reads before any write
-        if (k < 12) {
-          if (k != p && k != q) {
-            A[k * 12 + p] = np_; A[p * 12 + k] = np_;
-            A[k * 12 + q] = nq_; A[q * 12 + k] = nq_;
+        double c = 1.0, s = 0.0, t = 0.0, flag = 0.0;
+        if (apq != 0.0) {
+          const double app = A[p * 12 + p], aqq = A[q * 12 + q];
+          if (fabs(apq) <= 8.673617379884035e-19 * (fabs(app) + fabs(aqq))) flag = 1.0;
+          else {
+            const double theta = (aqq - app) / (2.0 * apq);
+            t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+            if (theta < 0.0) t = -t;
+            c = 1.0 / sqrt(t * t + 1.0); s = t * c;
+            flag = 2.0;
           }
-          V[k * 12 + p] = vp; V[k * 12 + q] = vq;
         }
-        if (lane == 0) {
-          A[p * 12 + p] = app - t * apq;
-          A[q * 12 + q] = aqq + t * apq;
-          A[p * 12 + q] = 0.0; A[q * 12 + p] = 0.0;
-        }
-        wave_sync();
-        rotated = true;
+        R[4 * m] = c; R[4 * m + 1] = s; R[4 * m + 2] = t; R[4 * m + 3] = flag;
       }
+      wave_sync();
+      bool touch = false, rot = false;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) { const double f = R[4 * m + 3]; touch = touch || f != 0.0; rot = rot || f == 2.0; }
+      if (touch) {                                         // wave-uniform
+        double na[3], nv[3];
+        int wa[3], wv[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int ip = rr_first(ma[u], r), iq = rr_second(ma[u], r);
+          const int jp = rr_first(mb[u], r), jq = rr_second(mb[u], r);
+          const int xp = rr_first(mx[u], r), xq = rr_second(mx[u], r);
+          const double app_ = A[ip * 12 + jp], aqp_ = A[iq * 12 + jp];
+          const double apq_ = A[ip * 12 + jq], aqq_ = A[iq * 12 + jq];
+          const double vp_ = V[vk[u] * 12 + xp], vq_ = V[vk[u] * 12 + xq];
+          const double ca = R[4 * ma[u]], sa = R[4 * ma[u] + 1], ta = R[4 * ma[u] + 2], fa = R[4 * ma[u] + 3];
+          const double cb = R[4 * mb[u]], sb = R[4 * mb[u] + 1], fb = R[4 * mb[u] + 3];
+          // V[k][x]: the rotation of x's pair (= the slot's column pair before the swap)
+          const double cv = swp[u] ? ca : cb, sv = swp[u] ? sa : sb, fv = swp[u] ? fa : fb;
+          const double vrot = rx[u] ? sv * vp_ + cv * vq_ : cv * vp_ - sv * vq_;
+          nv[u] = fv == 2.0 ? vrot : (rx[u] ? vq_ : vp_);
+          wv[u] = vk[u] * 12 + (rx[u] ? xq : xp);
+          // A, entry in two different pairs: rotation a along i, then rotation b along j
+          const double old_p = ra[u] ? aqp_ : app_, old_q = ra[u] ? aqq_ : apq_;
+          const double r1p = ra[u] ? sa * app_ + ca * aqp_ : ca * app_ - sa * aqp_;
+          const double r1q = ra[u] ? sa * apq_ + ca * aqq_ : ca * apq_ - sa * aqq_;
+          const double n1p = fa == 2.0 ? r1p : old_p, n1q = fa == 2.0 ? r1q : old_q;
+          const double r2 = rb[u] ? sb * n1p + cb * n1q : cb * n1p - sb * n1q;
+          const double off = fb == 2.0 ? r2 : (rb[u] ? n1q : n1p);
+          // A, entry inside one pair's 2 x 2 block (then ip = jp = p, iq = jq = q)
+          const double drot = ra[u] ? aqq_ + ta * apq_ : app_ - ta * apq_;
+          const double blk_diag = fa == 2.0 ? drot : (ra[u] ? aqq_ : app_);
+          const double blk_off = fa == 0.0 ? apq_ : 0.0;
+          na[u] = same[u] ? (diag[u] ? blk_diag : blk_off) : off;
+          const int i = ra[u] ? iq : ip, j = rb[u] ? jq : jp;
+          wa[u] = swp[u] ? j * 12 + i : i * 12 + j;
+        }
+        wave_sync();                                       // every read before any write
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          if (live[u]) { A[wa[u]] = na[u]; V[wv[u]] = nv[u]; }
+        rotated = rotated || rot;
+      }
+      wave_sync();
+    }
     if (!rotated) break;
   }
 }
@@ -321,7 +375,7 @@ __device__ bool ep_control_points(const double* s6, double n, EpFrame& f) {
 }
 
 // the 40 sums -> M^T M in LDS (one lane writes; the callers synchronise)
-__device__ void ep_write_mtm(const double* s40, const EpCam& cam, double* M) {
+__device__ __forceinline__ void ep_write_mtm(const double* s40, const EpCam& cam, double* M) {
   int v = 0;
   const double fu = cam.fu, fv = cam.fv;
 #pragma unroll
@@ -366,7 +420,7 @@ __device__ void gauss_newton(const double (*L)[10], const double* rho, double* b
 // After the eigen-decomposition (diagonal of A = eigenvalues, columns of V = eigenvectors, in
 // LDS): the three candidate poses. Xf = the first correspondence (it fixes the sign).
 // Wave- / workgroup-uniform; every calling thread computes the same values.
-__device__ void ep_candidates(const double* A, const double* V, const EpFrame& f,
+__device__ __forceinline__ void ep_candidates(const double* A, const double* V, const EpFrame& f,
                               const double* Xf, double* poses /*[3][12]*/, bool* ok /*[3]*/) {
   int order[4];
   {
@@ -565,6 +619,7 @@ __device__ __forceinline__ int ep_update_niters(double p, double ep, int max_ite
 
 // ------------------------------------------------------------------- kernels --
 struct CvrWork {
+  int min_points;      // slots below this size are treated as empty
   int32_t* samples;    // [S][iters][5]
   int32_t* counts;     // [S][iters]   (-1: the solver failed on that set)
   double* poses;       // [S][iters][12]
@@ -573,17 +628,18 @@ struct CvrWork {
 };
 
 __device__ __forceinline__ int64_t slot_size(const int64_t* slot_base, int s, int64_t cap,
-                                             int64_t* base) {
+                                             int min_points, int64_t* base, int64_t* rows) {
   *base = slot_base[s];
-  return slot_base[s + 1] <= cap ? slot_base[s + 1] - slot_base[s] : 0;   // overflowed: empty
+  *rows = slot_base[s + 1] <= cap ? slot_base[s + 1] - slot_base[s] : 0;   // overflowed: empty
+  return *rows >= min_points ? *rows : 0;
 }
 
 __global__ __launch_bounds__(64) void cvr_samples(const int64_t* slot_base, int S, int64_t cap,
                                                   CvrWork w) {
   const int s = blockIdx.x;
   if (threadIdx.x != 0) return;
-  int64_t base;
-  const int64_t n = slot_size(slot_base, s, cap, &base);
+  int64_t base, rows;
+  const int64_t n = slot_size(slot_base, s, cap, w.min_points, &base, &rows);
   int32_t* out = w.samples + static_cast<int64_t>(s) * w.iters * EP_SET;
   if (n < EP_SET) return;
   if (n == EP_SET) {                       // RANSACPointSetRegistrator::run: one kernel call
@@ -619,11 +675,11 @@ __global__ __launch_bounds__(64) void cvr_samples(const int64_t* slot_base, int 
 __global__ __launch_bounds__(256) void cvr_hypotheses(
     const double* xy_all, const double* xyz_all, const int64_t* slot_base, int S, int64_t cap,
     const double* Ks, float t2, CvrWork w) {
-  __shared__ double s_A[4][144], s_V[4][144];
+  __shared__ double s_A[4][144], s_V[4][144], s_R[4][24];
   const int s = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int it = blockIdx.x * 4 + wave;
-  int64_t base;
-  const int64_t n = slot_size(slot_base, s, cap, &base);
+  int64_t base, rows;
+  const int64_t n = slot_size(slot_base, s, cap, w.min_points, &base, &rows);
   if (it >= w.iters || n < EP_SET || (n == EP_SET && it > 0)) return;
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
@@ -672,7 +728,7 @@ __global__ __launch_bounds__(256) void cvr_hypotheses(
   double* V = s_V[wave];
   if (lane == 0) ep_write_mtm(s40, cam, A);
   wave_sync();
-  jacobi12_wave(A, V, lane);
+  jacobi12_wave(A, V, s_R[wave], lane);
   double poses[36];
   bool ok[3];
   ep_candidates(A, V, f, X[0], poses, ok);
@@ -739,11 +795,11 @@ __global__ __launch_bounds__(256) void cvr_select_fit(
     const double* xy_all, const double* xyz_all, const int64_t* slot_base, int S, int64_t cap,
     const double* Ks, float t2, double confidence, CvrWork w, double* poses_out,
     int32_t* success_out, uint8_t* mask_out, int32_t* info_out) {
-  __shared__ double s_A[144], s_V[144], s_red[4 * 40], s_pose[12];
+  __shared__ double s_A[144], s_V[144], s_R[24], s_red[4 * 40], s_pose[12];
   __shared__ int s_best[4], s_wcount[4], s_total;
   const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  int64_t base;
-  const int64_t n = slot_size(slot_base, s, cap, &base);
+  int64_t base, rows;
+  const int64_t n = slot_size(slot_base, s, cap, w.min_points, &base, &rows);
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
   uint8_t* mask = mask_out + base;
@@ -772,7 +828,7 @@ __global__ __launch_bounds__(256) void cvr_select_fit(
   const int best_it = s_best[0];
   if (t < 4 && info_out) info_out[4 * s + t] = s_best[t];
   if (best_it < 0) {
-    for (int64_t p = t; p < n; p += 256) mask[p] = 0;
+    for (int64_t p = t; p < rows; p += 256) mask[p] = 0;
     if (t == 0) success_out[s] = 0;
     return;
   }
@@ -823,7 +879,7 @@ __global__ __launch_bounds__(256) void cvr_select_fit(
                    m, t, s_red, s40);
     if (t == 0) ep_write_mtm(s40, cam, s_A);
     __syncthreads();
-    if (wave == 0) jacobi12_wave(s_A, s_V, lane);
+    if (wave == 0) jacobi12_wave(s_A, s_V, s_R, lane);
     __syncthreads();
     double Xf[3], xf[2];
     load(0, Xf, xf);
@@ -873,6 +929,7 @@ int cvr_enqueue(const double* xy, const double* xyz, const int64_t* slot_base, i
   w.poses = reinterpret_cast<double*>(wb + l.poses);
   w.idx = reinterpret_cast<int32_t*>(wb + l.idx);
   w.iters = p->iterations_count;
+  w.min_points = p->min_point_number;
   const float t2 = static_cast<float>(p->reprojection_error * p->reprojection_error);
   int rc = check_hip(hipMemsetAsync(w.counts, 0xff, static_cast<size_t>(S) * w.iters * 4, st), "memset");
   if (rc) return rc;
@@ -894,6 +951,7 @@ extern "C" void epos_pnp_ransac_params_default(EposPnpRansacParams* p) {
   p->iterations_count = 400;        // max_fitting_iterations, scripts/infer.py:87-89
   p->reprojection_error = 4.0;      // inlier_thresh, scripts/infer.py:76-78
   p->confidence = 0.99;             // scripts/infer.py:517
+  p->min_point_number = 0;          // OpenCV's own rule; the script skips n < 6 (infer.py:420)
 }
 
 extern "C" int64_t epos_pnp_ransac_workspace_bytes(int S, int64_t n_capacity,
@@ -926,7 +984,7 @@ extern "C" int epos_solve_pnp_ransac(const double* xy, const double* xyz, int64_
   EPOS_REQUIRE(p->reprojection_error > 0.0, "reprojection_error must be positive");
   if (info_out) { info_out[0] = -1; info_out[1] = 0; info_out[2] = p->iterations_count; info_out[3] = 0; }
   for (int64_t i = 0; i < n; ++i) inlier_mask_out[i] = 0;
-  if (n < EP_SET) return 0;
+  if (n < EP_SET || n < p->min_point_number) return 0;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     (void)hipGetLastError();

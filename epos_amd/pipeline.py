@@ -37,8 +37,14 @@ class EposPipeline(object):
                model_store, fit_params=None, corr_min_obj_conf=0.1,
                corr_min_frag_rel_conf=0.5, max_slots=None, capacity=1 << 20,
                max_instances=4, model_options=None, device='cuda:0',
-               use_graph=True, instance=0, sparse_heads=False):
+               use_graph=True, instance=0, sparse_heads=False,
+               fitting_method='progressive_x'):
     self.lib = _lib.load()
+    # 'progressive_x' (infer.py:446-503) or 'opencv_ransac' (infer.py:505-528: one
+    # cv2.solvePnPRansac(EPNP) per object, score 0.0) -- common.py:30-31
+    if fitting_method not in ('progressive_x', 'opencv_ransac'):
+      raise ValueError('Unknown pose fitting method ({}).'.format(fitting_method))
+    self.fitting_method = fitting_method
     self.dev = torch.device(device)
     self.B, self.H, self.W = batch, height, width
     self.O, self.F = num_objs, num_frags
@@ -66,6 +72,15 @@ class EposPipeline(object):
                                                self.max_k)
     if wbytes < 0:
       raise _lib.EposError('epos_fit_workspace_bytes failed')
+    if fitting_method == 'opencv_ransac':
+      self.cv_params = _lib.PnpRansacParams()
+      self.lib.epos_pnp_ransac_params_default(ctypes.byref(self.cv_params))
+      self.cv_params.iterations_count = self.fit.max_iters      # infer.py:515
+      self.cv_params.reprojection_error = self.fit.threshold    # infer.py:516
+      self.cv_params.confidence = 0.99                          # infer.py:517
+      self.cv_params.min_point_number = self.fit.min_point_number   # infer.py:420-422
+      wbytes = max(wbytes, self.lib.epos_pnp_ransac_workspace_bytes(
+          S, capacity, ctypes.byref(self.cv_params)))
     self.work = torch.empty(wbytes, dtype=torch.uint8, device=d)
     self.labels = torch.empty(max(capacity, 1), dtype=torch.int32, device=d)
     # Per-step metadata goes up in ONE host->device copy and the results come
@@ -152,6 +167,8 @@ class EposPipeline(object):
     slots, wants = self.make_slots(targets, task_type)
     S = len(slots)
     max_k = self.max_k if task_type != LOCALIZATION else max([1] + wants)
+    if self.fitting_method == 'opencv_ransac':
+      max_k = 1                       # "can estimate pose of only one object instance"
     cur = torch.cuda.current_stream(self.dev)
     self.stream.wait_stream(cur)            # inputs produced on the caller's stream
     with torch.cuda.stream(self.stream):
@@ -186,13 +203,24 @@ class EposPipeline(object):
                        pred[W.PRED_FRAG_LOC], self.output_scale)
         if timing:
           self._ev[2].record()
-        _lib.check(self.lib.epos_find6d_poses_device(
-            _ptr(self.corr.coord_2d), _ptr(self.corr.coord_3d),
-            _ptr(self.corr.slot_base), S, self.corr.capacity, _ptr(self.Ks),
-            _ptr(self.max_models), _ptr(self.seeds), ctypes.byref(self.fit),
-            max_k, _ptr(self.work), _ptr(self.poses), _ptr(self.scores),
-            _ptr(self.num_models), _ptr(self.labels),
-            ctypes.c_void_p(self.stream.cuda_stream)), 'epos_find6d_poses_device')
+        if self.fitting_method == 'opencv_ransac':
+          # one pose per slot: poses [S, 1, 12], num_models = success flag, scores 0.0; the
+          # inlier mask (u8 per correspondence) lands in the bytes of the label buffer
+          self.scores.zero_()
+          _lib.check(self.lib.epos_solve_pnp_ransac_device(
+              _ptr(self.corr.coord_2d), _ptr(self.corr.coord_3d),
+              _ptr(self.corr.slot_base), S, self.corr.capacity, _ptr(self.Ks),
+              ctypes.byref(self.cv_params), _ptr(self.work), _ptr(self.poses),
+              _ptr(self.num_models), _ptr(self.labels), None,
+              ctypes.c_void_p(self.stream.cuda_stream)), 'epos_solve_pnp_ransac_device')
+        else:
+          _lib.check(self.lib.epos_find6d_poses_device(
+              _ptr(self.corr.coord_2d), _ptr(self.corr.coord_3d),
+              _ptr(self.corr.slot_base), S, self.corr.capacity, _ptr(self.Ks),
+              _ptr(self.max_models), _ptr(self.seeds), ctypes.byref(self.fit),
+              max_k, _ptr(self.work), _ptr(self.poses), _ptr(self.scores),
+              _ptr(self.num_models), _ptr(self.labels),
+              ctypes.c_void_p(self.stream.cuda_stream)), 'epos_find6d_poses_device')
         # NB: poses / scores are laid out [S, max_k(call), ...] for this call.
         if timing:
           self._ev[3].record()

@@ -385,7 +385,9 @@ int epos_find6d_poses_device(const double* xy, const double* xyz,
  * ------------------------------------------------------------------------- */
 typedef struct EposPnpRansacParams {
   int32_t iterations_count;     /* max_fitting_iterations (400)       infer.py:515 */
-  int32_t reserved;
+  int32_t min_point_number;     /* slots / calls with fewer correspondences give no pose:
+                                 * 6 in the script (infer.py:420-422 skips them before the
+                                 * call); 0 = OpenCV's own rule (n >= 5)                */
   double reprojection_error;    /* inlier_thresh (4.0 px)             infer.py:516 */
   double confidence;            /* 0.99                               infer.py:517 */
 } EposPnpRansacParams;

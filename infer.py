@@ -507,7 +507,7 @@ def main(argv=None):
   # those runs go operator by operator (HIP network -> HIP correspondences -> host
   # sort -> HIP fitting per object) instead of through the fused device pipeline.
   operator_path = (args.max_correspondences is not None or args.use_prosac or
-                   args.project_to_surface or args.fitting_method == 'opencv_ransac')
+                   args.project_to_surface)
   if args.project_to_surface:
     # infer.py:622 prepare_for_projection: the 'eval' models of the dataset
     # (datagen.py:250-252,299-306), closest-point queries on the GPU
@@ -526,7 +526,8 @@ def main(argv=None):
       ckpt, B, h, w, num_objs, args.num_frags, store, fit_params=fit,
       corr_min_obj_conf=args.corr_min_obj_conf,
       corr_min_frag_rel_conf=args.corr_min_frag_rel_conf,
-      max_instances=max_inst, model_options=mo, device=dev, instance=j)
+      max_instances=max_inst, model_options=mo, device=dev, instance=j,
+      fitting_method=args.fitting_method)
            for j in range(depth)]
   pipe = pipes[0]
 

@@ -30,8 +30,8 @@
  *     row negated if det < 0), the candidate of smallest mean reprojection error wins.
  *
  * What differs from OpenCV on purpose, so that a wavefront-parallel twin can reproduce the
- * bits: the dense factorisations are the build's own (cyclic Jacobi for the symmetric
- * eigenproblems, Householder QR for the 6 x k least-squares systems, one-sided Jacobi for the
+ * bits: the dense factorisations are the build's own (Jacobi for the symmetric
+ * eigenproblems -- cyclic for 3 x 3, round-robin order for 12 x 12 --, Householder QR for the 6 x k least-squares systems, one-sided Jacobi for the
  * 3 x 3 SVD) instead of cv::SVD / LAPACK; sums over correspondences that are linear in the
  * points (camera-frame centroid, the 3 x 3 cross-covariance) are formed from the centroid and
  * covariance of the object points instead of per point; the rvec <-> R round trip through
@@ -55,42 +55,65 @@ static uint32_t cvrng_next(uint64_t* st) {
 }
 
 /* ------------------------------------------------------- small dense algebra -- */
-/* Cyclic Jacobi for a symmetric n x n matrix (row-major, both triangles kept). On return
- * the diagonal of A holds the eigenvalues and column j of V the eigenvector of A[j][j]. */
+/* One Jacobi rotation (p, q) of the symmetric n x n matrix A (row-major, both triangles
+ * kept), accumulated into V. Returns 1 if a rotation was applied. */
+static int jacobi_rotate(int n, double* A, double* V, int p, int q) {
+  const double apq = A[p * n + q];
+  if (apq == 0.0) return 0;
+  const double app = A[p * n + p], aqq = A[q * n + q];
+  if (fabs(apq) <= 8.673617379884035e-19 * (fabs(app) + fabs(aqq))) {   /* 2^-60 */
+    A[p * n + q] = 0.0; A[q * n + p] = 0.0;
+    return 0;
+  }
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double at = fabs(theta);
+  double t = 1.0 / (at + sqrt(theta * theta + 1.0));
+  if (theta < 0.0) t = -t;
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  for (int k = 0; k < n; ++k) {
+    if (k != p && k != q) {
+      const double akp = A[k * n + p], akq = A[k * n + q];
+      const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
+      A[k * n + p] = np_; A[p * n + k] = np_;
+      A[k * n + q] = nq_; A[q * n + k] = nq_;
+    }
+    const double vkp = V[k * n + p], vkq = V[k * n + q];
+    V[k * n + p] = c * vkp - s * vkq;
+    V[k * n + q] = s * vkp + c * vkq;
+  }
+  A[p * n + p] = app - t * apq;
+  A[q * n + q] = aqq + t * apq;
+  A[p * n + q] = 0.0; A[q * n + p] = 0.0;
+  return 1;
+}
+
+/* Cyclic Jacobi (row by row). On return the diagonal of A holds the eigenvalues and column
+ * j of V the eigenvector of A[j][j]. */
 static void jacobi_sym(int n, double* A, double* V) {
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) V[i * n + j] = i == j ? 1.0 : 0.0;
   for (int sweep = 0; sweep < EP_JAC_SWEEPS; ++sweep) {
     int rotated = 0;
     for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = A[p * n + q];
-        if (apq == 0.0) continue;
-        const double app = A[p * n + p], aqq = A[q * n + q];
-        if (fabs(apq) <= 8.673617379884035e-19 * (fabs(app) + fabs(aqq))) {   /* 2^-60 */
-          A[p * n + q] = 0.0; A[q * n + p] = 0.0;
-          continue;
-        }
-        const double theta = (aqq - app) / (2.0 * apq);
-        const double at = fabs(theta);
-        double t = 1.0 / (at + sqrt(theta * theta + 1.0));
-        if (theta < 0.0) t = -t;
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; ++k) {
-          if (k != p && k != q) {
-            const double akp = A[k * n + p], akq = A[k * n + q];
-            const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
-            A[k * n + p] = np_; A[p * n + k] = np_;
-            A[k * n + q] = nq_; A[q * n + k] = nq_;
-          }
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - s * vkq;
-          V[k * n + q] = s * vkp + c * vkq;
-        }
-        A[p * n + p] = app - t * apq;
-        A[q * n + q] = aqq + t * apq;
-        A[p * n + q] = 0.0; A[q * n + p] = 0.0;
-        rotated = 1;
+      for (int q = p + 1; q < n; ++q) rotated |= jacobi_rotate(n, A, V, p, q);
+    if (!rotated) break;
+  }
+}
+
+/* The 12 x 12 problem of EPnP: the same rotations in ROUND-ROBIN order -- a sweep is 11
+ * rounds of 6 disjoint pairs (round r: (r, 11) and ((r + m) mod 11, (r - m) mod 11),
+ * m = 1..5), so that the GPU twin can apply the six rotations of a round at once (disjoint
+ * rotations commute; applying them one after the other in the order m = 0..5, as here,
+ * fixes the rounding of the entries two of them touch). */
+static void jacobi12_rr(double* A, double* V) {
+  for (int i = 0; i < 144; ++i) V[i] = (i % 13 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < EP_JAC_SWEEPS; ++sweep) {
+    int rotated = 0;
+    for (int r = 0; r < 11; ++r)
+      for (int m = 0; m < 6; ++m) {
+        /* no sorting: a rotation gives the same bits with the roles of p and q swapped */
+        const int p = m == 0 ? r : (r + m) % 11, q = m == 0 ? 11 : (r - m + 11) % 11;
+        rotated |= jacobi_rotate(12, A, V, p, q);
       }
     if (!rotated) break;
   }
@@ -360,7 +383,7 @@ static int epnp(EpnpCtx* e, const int32_t* idx, int64_t m, int P, double* pose) 
           }
       }
   }
-  jacobi_sym(12, M, V);
+  jacobi12_rr(M, V);
   /* the four eigenvectors of smallest eigenvalue, smallest first (ties: lower column) */
   int order[4];
   {
@@ -581,5 +604,7 @@ int epnp_ref_epnp(const double* xy, const double* xyz, int64_t n, const double* 
   return r;
 }
 
-void epnp_ref_jacobi(int n, double* A, double* V) { jacobi_sym(n, A, V); }
+void epnp_ref_jacobi(int n, double* A, double* V) {
+  if (n == 12) jacobi12_rr(A, V); else jacobi_sym(n, A, V);
+}
 uint32_t epnp_ref_rng_next(uint64_t* st) { return cvrng_next(st); }

@@ -132,6 +132,27 @@ def test_batched_device_entry_matches_per_object_calls():
   assert list(succ2.cpu().numpy()) == [1, 0, 0, int(succ[3]), 0, 0]
 
 
+def test_min_point_number_skips_small_sets():
+  """EposPnpRansacParams.min_point_number: what the script's `n < 6` filter
+  (infer.py:420-422) does before the cv2 call."""
+  import ctypes as ct
+  from epos_amd import _lib
+  lib = _lib.load()
+  p = _lib.PnpRansacParams()
+  lib.epos_pnp_ransac_params_default(ct.byref(p))
+  assert p.min_point_number == 0 and p.iterations_count == 400
+  vp = ct.c_void_p
+  for n, mn, want in [(5, 0, 1), (5, 6, 0), (6, 6, 1), (40, 41, 0)]:
+    xyz, xy, R, t, _ = scene(n + mn, n)
+    p.min_point_number = mn
+    pose, mask, Kd = np.zeros(12), np.ones(n, np.uint8), np.ascontiguousarray(K).reshape(9)
+    ok = lib.epos_solve_pnp_ransac(xy.ctypes.data_as(vp), xyz.ctypes.data_as(vp), n,
+                                   Kd.ctypes.data_as(vp), ct.byref(p),
+                                   pose.ctypes.data_as(vp), mask.ctypes.data_as(vp), None)
+    assert ok == want, (n, mn)
+    assert mask.sum() == (n if want else 0)
+
+
 def test_independent_of_launch_history():
   xyz, xy, R, t, good = scene(77, 3000, sigma=1.0, outliers=0.5)
   first = _both(xyz, xy)[1]

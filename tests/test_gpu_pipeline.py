@@ -54,6 +54,46 @@ def test_pipeline_matches_oracle_chain():
     np.testing.assert_allclose(p['score'], rs[0], rtol=1e-12)
 
 
+def test_pipeline_opencv_method_matches_its_oracle_chain():
+  """fitting_method='opencv_ransac' in the fused device pipeline: per slot, the pose of
+  cv2.solvePnPRansac(EPNP) as oracle/epnp_ref.c states it, on the correspondences the oracle
+  extracts from the same head tensors; slots below 6 correspondences are skipped
+  (infer.py:420-422), score 0.0, one pose per object even when two instances are asked."""
+  from epos_amd import pipeline, weights
+  from oracle import corresp_ref, epnp_ref
+  O, F, B, H, W_ = 3, 64, 2, 96, 128
+  ckpt = weights.random_init(num_objs=O, seed=5, randomize_bn=True, logits_std=0.6)
+  store = Store(O, F)
+  pipe = pipeline.EposPipeline(ckpt, B, H, W_, O, F, store, capacity=1 << 18,
+                               fitting_method='opencv_ransac')
+  img = np.random.RandomState(1).randint(0, 256, (B, H, W_, 3)).astype('f')
+  Ks = np.tile(np.array([[300., 0, 64], [0, 300., 48], [0, 0, 1]]), (B, 1, 1))
+  targets = [{1: 2, 3: 1}, {2: 1}]
+  poses, _ = pipe.process_batch(torch.from_numpy(img).cuda(), Ks, targets, seed=7)
+  pred = {k: v.cpu().numpy() for k, v in pipe.net.forward().items()}
+  slots, wants = pipe.make_slots(targets)
+  exp = []
+  for (im, obj_id), want in zip(slots, wants):
+    c = corresp_ref.establish_many_to_many(
+        pred['pred_obj_conf'][im], pred['pred_frag_conf'][im],
+        pred['pred_frag_loc'][im], [obj_id], store.dp_model['obj_ids'],
+        store.frag_centers, store.frag_sizes, 0.25, 0.1, 0.5, True)
+    if obj_id not in c or c[obj_id]['coord_2d'].shape[0] < 6:
+      continue
+    ok, P, mask, info = epnp_ref.solvePnPRansac(c[obj_id]['coord_3d'], c[obj_id]['coord_2d'],
+                                                Ks[im], 400, 4.0, 0.99)
+    if ok:
+      exp.append((im, obj_id, P))
+  assert len(exp) >= 1
+  assert len(poses) == len(exp)
+  for p, (im, obj_id, P) in zip(poses, exp):
+    assert (p['im_id'], p['obj_id']) == (im, obj_id)
+    np.testing.assert_array_equal(np.hstack([p['R'], p['t']]), P)
+    assert p['score'] == 0.0
+  with pytest.raises(ValueError):
+    pipeline.EposPipeline(ckpt, B, H, W_, O, F, store, fitting_method='nope')
+
+
 def test_sparse_heads_equal_dense_on_target_objects():
   """Sparse-head mode evaluates the fragment heads only for the target objects;
   those channels and the resulting poses must be bit-identical to the dense run."""

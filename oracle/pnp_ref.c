@@ -48,6 +48,11 @@
  * instead of an exact s-t min-cut, with energies in 2^-20 fixed point so that any
  * evaluation order gives the same labels; one labelling per proposal instead of one per
  * local-optimisation step; PEARL's alpha-expansion is likewise replaced by sweeps.
+ * Against the exact s-t minimum cut of the same energy (tests/test_oracle_fit.py): two sweeps
+ * ARE the minimum cut on sparse neighbourhood graphs (<= 5 neighbours per point), within
+ * 0-1.6 % of its energy at 10-14 neighbours; beyond 2 (1 - lambda) / lambda = 18 neighbours
+ * the exact minimiser labels (nearly) everything an inlier and the sweeps are a bounded
+ * step towards it.
  *
  * All sums over correspondences use canonical orders so that the wavefront-
  * parallel HIP kernels can reproduce them bit for bit:

@@ -18,7 +18,9 @@ reference's initialisers (no network access for the released checkpoints).
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
   "roofline":     matrix-pipe roofline of the dominant kernel (pointwise_gemm_split_f32:
                   fp32 GEMM as six bf16 piece products), measured with HIP events
-                  around every GEMM launch,
+                  around every GEMM launch; its "traffic" (HBM-side bytes per launch) is
+                  measured in the same run by two rocprofv3 --pmc child runs after the
+                  timed region (--traffic static|off to skip),
   "cpu_baseline": the CPU oracle (torch-CPU net + numpy corresp + C RANSAC) timed
                   on this host on a bounded sample (N=1, rank 0 only).
 """
@@ -91,6 +93,12 @@ def parse_args():
   ap.add_argument('--cpu-baseline-images', type=int, default=8,
                   help='frames of the same workload the CPU oracle is timed on '
                        '(~1.6 s each on 10 threads: a bounded 10-30 s sample)')
+  ap.add_argument('--traffic', default='live', choices=['live', 'static', 'off'],
+                  help='roofline.traffic: "live" = two rocprofv3 --pmc passes (FETCH_SIZE, '
+                       'WRITE_SIZE; separate runs, no trace options) over a short child run '
+                       'of this script, launched after the timed region (falls back to '
+                       '"static" if rocprofv3 is missing or fails); "static" = the committed '
+                       'summary of the last collection under profiles/; "off" = null')
   ap.add_argument('--no-stage-times', action='store_true',
                   help='skip the serial (depth 1) steps with per-stage HIP events that '
                        'follow the timed region')
@@ -140,6 +148,65 @@ def cpu_baseline(ckpt, store, args, frames):
   }
 
 
+def measure_traffic_live(args, timeout=240):
+  """HBM-side bytes per GEMM launch, measured NOW: two separate `rocprofv3 --pmc` passes
+  (FETCH_SIZE, then WRITE_SIZE; no trace options -- MI355X_MICROARCH.md, HBM / rocprofv3)
+  over a child run of this script (1 plan, 4 steps of the same workload, graph replay), the
+  per-dispatch counter rows of the GEMM kernels averaged. gfx950: FETCH_SIZE tallies the
+  128-B requests of wide coalesced reads at 64 B -> doubled; KB -> bytes. Returns
+  (bytes per launch, description) or (None, reason)."""
+  import csv
+  import glob
+  import shutil
+  import subprocess
+  import tempfile
+  rp = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+  if not os.path.exists(rp):
+    return None, 'rocprofv3 not found'
+  avg, launches = {}, {}
+  for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    d = tempfile.mkdtemp(prefix='epos_pmc_', dir='/tmp')
+    cmd = [rp, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
+           os.path.abspath(__file__), '--gpus', '1', '--steps', '4', '--warmup', '1',
+           '--pipeline-depth', '1', '--batch-per-gpu', str(args.batch_per_gpu),
+           '--height', str(args.height), '--width', str(args.width),
+           '--num-objs', str(args.num_objs), '--num-frags', str(args.num_frags),
+           '--objs-per-image', str(args.objs_per_image), '--model-variant',
+           args.model_variant, '--no-cpu-baseline', '--no-roofline', '--no-stage-times',
+           '--traffic', 'off']
+    if args.sparse_heads:
+      cmd.append('--sparse-heads')
+    env = dict(os.environ, TMPDIR='/tmp', EPOS_BENCH_CHILD='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+      env.pop(k, None)
+    try:
+      subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout, check=True,
+                     stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+      tot, n = 0.0, 0
+      for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        with open(f) as fh:
+          for r in csv.DictReader(fh):
+            k = r.get('Kernel_Name', '')
+            if r.get('Counter_Name') == counter and ('pointwise_gemm' in k or
+                                                     'pointwise_gemv' in k):
+              tot += float(r['Counter_Value'])
+              n += 1
+      if n == 0:
+        return None, 'no %s rows for the GEMM kernels' % counter
+      avg[counter], launches[counter] = tot / n, n
+    except Exception as e:                       # timeout, non-zero exit, parse error
+      return None, '%s pass failed: %s' % (counter, type(e).__name__)
+    finally:
+      shutil.rmtree(d, ignore_errors=True)
+  bytes_per_launch = (2.0 * avg['FETCH_SIZE'] + avg['WRITE_SIZE']) * 1024.0
+  return bytes_per_launch, (
+      'measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate '
+      'child runs (4 steps + warm-up of the same workload on one plan, %d / %d GEMM '
+      'dispatches), (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch -- gfx950 tallies the '
+      '128-B requests of wide reads at 64 B; fabric-side counters, Infinity-Cache hits '
+      'included' % (launches['FETCH_SIZE'], launches['WRITE_SIZE']))
+
+
 def gemm_roofline(pipe, steps):
   """HIP-event timing of every pointwise-GEMM launch of the plan (events on
   the stream the kernels are launched on), averaged over `steps` passes."""
@@ -183,10 +250,9 @@ def gemm_roofline(pipe, steps):
   else:
     kernel, peak = 'pointwise_gemm_dma_f32', FP32_MFMA_PEAK_TFLOPS
     peak_note = 'dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)'
-  # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE and
-  # WRITE_SIZE in separate runs, gfx950 x2 correction on FETCH_SIZE) that cannot
-  # run inside this process; the committed summary of the last collection is
-  # reported here (profiles/r01/gemm_hbm_traffic_pmc.json).
+  # HBM-side bytes per launch: main() replaces this with a measurement of THIS run
+  # (measure_traffic_live: two rocprofv3 --pmc child runs); the committed summary of the
+  # last collection is the fallback when rocprofv3 is unavailable (--traffic static).
   traffic, traffic_src = None, None
   for rnd in ('r02', 'r01'):
     tpath = os.path.join(ROOT, 'profiles', rnd, 'gemm_hbm_traffic_pmc.json')
@@ -203,7 +269,7 @@ def gemm_roofline(pipe, steps):
       'peak': round(peak, 1), 'unit': 'TFLOP/s',
       'frac': round(achieved / peak, 4), 'traffic': traffic,
       'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,
-      'traffic_measured_in_run': False,
+      'traffic_measured_in_run': False,   # main() replaces the three fields when --traffic live works
       'algorithmic_bytes_per_launch': round(abytes / max(launches, 1)),
       'kernel': kernel,
       'peak_note': peak_note,
@@ -402,6 +468,17 @@ def main():
     result['serial_depth1'] = serial
   if rank == 0 and not args.no_roofline:
     roof, _ = gemm_roofline(pipe, max(2, min(args.steps, 5)))
+    if args.traffic == 'off':
+      roof['traffic'], roof['traffic_source'] = None, 'off'
+    elif args.traffic == 'live' and world == 1:
+      torch.cuda.synchronize()
+      live, how = measure_traffic_live(args)
+      if live is not None:
+        roof['traffic'], roof['traffic_source'] = round(live), how
+        roof['traffic_measured_in_run'] = True
+      else:
+        roof['traffic_source'] = 'live measurement unavailable (%s); %s' % (
+            how, roof['traffic_source'])
     # The HBM view north_star names: images/s x algorithmic bytes per image against
     # the 8 TB/s spec (3.30 GB per 640x480 image at 21 objects with
     # fused separable convs, dense heads written once; 3.15 GB/image at batch 8).

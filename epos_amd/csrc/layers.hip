@@ -619,9 +619,15 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
     else per_xcd = ceil_div(part.rows, 8) * nres * nchunk * c4n;
     const unsigned grid = 8 * blocks_for(per_xcd, threads);
     const int v = (a->relu_in ? 2 : 0) | (a->relu_out ? 1 : 0);
+    // EPOS_DW_LDS_KB=n: reserve n KB of (unused) LDS per workgroup -- an occupancy throttle
+    // for co-residency experiments with the GEMM's 80 KB workgroups
+    static const unsigned lds_pad = [] {
+      const char* e = getenv("EPOS_DW_LDS_KB");
+      return e ? static_cast<unsigned>(atoi(e)) * 1024u : 0u;
+    }();
 #define EPOS_DW_LAUNCH(RI, RO, RW)                                                          \
-    hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, RI, RO, RW>), dim3(grid), dim3(threads), 0, \
-                       st, *a, c4n, nres, nchunk, nrows, part)
+    hipLaunchKernelGGL((depthwise3x3_s1_kernel<L, RI, RO, RW>), dim3(grid), dim3(threads),   \
+                       lds_pad, st, *a, c4n, nres, nchunk, nrows, part)
     if (ROWS == 2) {
       if (v == 0) EPOS_DW_LAUNCH(false, false, 2);
       else if (v == 1) EPOS_DW_LAUNCH(false, true, 2);

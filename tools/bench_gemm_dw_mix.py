@@ -19,6 +19,13 @@ m, n, k = 4800, 728, 728
 def mk_gemm():
   A = torch.randn(m, k, device='cuda'); C = torch.empty(m, n, device='cuda')
   w = (np.random.randn(k, n) / np.sqrt(k)).astype(np.float32)
+  if os.environ.get('EPOS_GEMM_SPLIT', '1') != '0':          # the split-operand kernel
+    total = lib.epos_pack_pointwise_weights_split(None, k, n, None); d8 = np.empty(total, np.uint8)
+    lib.epos_pack_pointwise_weights_split(w.ctypes.data_as(ctypes.c_void_p), k, n, d8.ctypes.data_as(ctypes.c_void_p))
+    Ws = torch.from_numpy(d8).cuda()
+    a = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Ws), bias=None, R=None, ldr=n, C=p(C), ldc=n, M=m, N=n, K=k,
+                           relu=0, relu_in=0, sub=1, Ws=p(Ws))
+    return (A, C, Ws, None, a)
   total = lib.epos_pack_pointwise_weights(None, k, n, None); dst = np.empty(total, np.float32)
   lib.epos_pack_pointwise_weights(w.ctypes.data_as(ctypes.c_void_p), k, n, dst.ctypes.data_as(ctypes.c_void_p))
   Wp = torch.from_numpy(dst).cuda(); b = torch.zeros((n + 127) // 128 * 128, device='cuda')

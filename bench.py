@@ -207,6 +207,44 @@ def measure_traffic_live(args, timeout=240):
       'included' % (launches['FETCH_SIZE'], launches['WRITE_SIZE']))
 
 
+def depthwise_roofline(pipe, steps):
+  """The second kernel family of the step, HBM-bound: HIP events around every depthwise
+  launch of the plan (same eager passes as gemm_roofline), algorithmic bytes = input read
+  once + output written once."""
+  net = pipe.net
+  s = net._stream()
+  evs = []
+  for _ in range(steps):
+    for name, fn in net.ops:
+      if net.op_kind.get(name) == 'dw':
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(s)
+        e1.record()
+        evs.append((name, e0, e1))
+      else:
+        fn(s)
+  torch.cuda.synchronize()
+  ms = sum(e0.elapsed_time(e1) for _, e0, e1 in evs)
+  nbytes = sum(net.op_bytes.get(n, 0) for n, _, _ in evs)
+  if not evs or ms <= 0:
+    return None
+  gbs = nbytes / (ms * 1e-3) / 1e9
+  return {'kernel': 'depthwise3x3_s1_kernel / depthwise3x3_kernel', 'bound': 'hbm',
+          'achieved': round(gbs, 1), 'peak': 8000.0, 'unit': 'GB/s',
+          'frac': round(gbs / 8000.0, 4),
+          'launches_per_image': len(evs) // steps // net.B,
+          'avg_launch_us': round(ms * 1e3 / len(evs), 2),
+          'algorithmic_bytes_per_launch': round(nbytes / len(evs)),
+          'note': 'HIP events around 8-16 us kernels include ~4 us of launch gap per launch '
+                  '(rocprofv3 kernel trace of the same plan: 9.5-9.6 us, 16.5 for the '
+                  '2048-channel tensors -> 3.4 TB/s = 0.43, profiles/r02/rocprofv3_kernel_'
+                  'stats_depth1.csv); tensors of 4-60 MB, mostly served by the 256 MB '
+                  'Infinity Cache; a plain device copy of the same tensors runs at '
+                  '6.4-7.0 TB/s (profiles/r02/depthwise_threads_ab.txt)'}
+
+
 def gemm_roofline(pipe, steps):
   """HIP-event timing of every pointwise-GEMM launch of the plan (events on
   the stream the kernels are launched on), averaged over `steps` passes."""
@@ -508,6 +546,9 @@ def main():
     roof['achieved_in_pipeline'] = round(
         value / world * gemm_gflop / 1e3, 2)   # GEMM flops only, all streams busy
     result['roofline'] = roof
+    dwr = depthwise_roofline(pipe, max(2, min(args.steps, 5)))
+    if dwr:
+      result['roofline_depthwise'] = dwr
   if (rank == 0 and world == 1 and not args.no_cpu_baseline
       and args.fitting_method == 'progressive_x'):
     result['cpu_baseline'] = cpu_baseline(ckpt, store, args,

@@ -255,7 +255,9 @@ class EposNet(object):
 
     def run(stream, args=args):
       _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(args), stream), name)
-    self._add(name, run, 2 * 9 * self.B * ho * wo * c, 'dw')
+    # algorithmic bytes: the input read once + the output written once (fp32), weights
+    self._add(name, run, 2 * 9 * self.B * ho * wo * c, 'dw',
+              4 * (self.B * hi * wi * c + self.B * ho * wo * c + 10 * c))
     return y, ho, wo
 
   def _stem_conv(self, name, x, hi, wi, cin, scope, stride, preprocess,

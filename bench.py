@@ -163,6 +163,13 @@ def measure_traffic_live(args, timeout=240):
   rp = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
   if not os.path.exists(rp):
     return None, 'rocprofv3 not found'
+  # Never nest: when this process itself runs under a profiler (rocprofv3 exports its
+  # options and preloads its tool library), a child would inherit the tracing set-up and
+  # combine it with --pmc -- the combination that must not be run.
+  prof_keys = ('ROCPROF', 'ROCP_', 'ROCTRACER', 'HSA_TOOLS_LIB', 'ROCTX')
+  if any(k.startswith(prof_keys) for k in os.environ) or \
+      'rocprof' in os.environ.get('LD_PRELOAD', '').lower():
+    return None, 'this process runs under a profiler'
   avg, launches = {}, {}
   for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
     d = tempfile.mkdtemp(prefix='epos_pmc_', dir='/tmp')

@@ -16,14 +16,14 @@ OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/bench_driver_cmd.err | tail -1 > $OUT/bench_driver_cmd.json
-python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_100steps.json
-python bench.py --steps 100 --warmup 10 --sparse-heads --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_sparse_heads.json
-EPOS_GEMM_SPLIT=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_fp32_mfma.json
-python bench.py --steps 40 --warmup 5 --batch-per-gpu 4 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_c3_shard_batch4.json
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_100steps.json
+python bench.py --steps 100 --warmup 10 --sparse-heads --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_sparse_heads.json
+EPOS_GEMM_SPLIT=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_fp32_mfma.json
+python bench.py --steps 40 --warmup 5 --batch-per-gpu 4 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c3_shard_batch4.json
 for d in 4 1; do
   mkdir -p $OUT/kt$d
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt$d -- \
-    python bench.py --gpus 1 --steps 20 --warmup 5 --pipeline-depth $d --no-cpu-baseline --no-stage-times > $OUT/kt$d.log 2>&1
+    python bench.py --gpus 1 --steps 20 --warmup 5 --pipeline-depth $d --no-cpu-baseline --traffic static --no-stage-times > $OUT/kt$d.log 2>&1
   f=$(find $OUT/kt$d -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $OUT/rocprofv3_kernel_stats_depth$d.csv
   f=$(find $OUT/kt$d -name '*kernel_trace.csv' | head -1)

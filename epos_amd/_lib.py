@@ -33,6 +33,10 @@ class PointwiseArgs(ctypes.Structure):
       ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32),
       ('Hi', ctypes.c_int32), ('Wi', ctypes.c_int32),
       ('Ws', vp),
+      # ABI 5: fp16-pair GEMM (include/epos_hip.h)
+      ('Wh', vp), ('a_amax', vp), ('a_amax2', vp),
+      ('a_gain', ctypes.c_float), ('a_bias', ctypes.c_float),
+      ('c_amax', vp),
   ]
 
 
@@ -63,6 +67,7 @@ class Conv3x3Args(ctypes.Structure):
       ('stride', ctypes.c_int32), ('rate', ctypes.c_int32),
       ('relu', ctypes.c_int32),
       ('Ws', vp),
+      ('Wh', vp), ('x_amax', vp), ('y_amax', vp),
   ]
 
 
@@ -128,6 +133,11 @@ SYMBOLS = {
                                     [vp, ctypes.c_int, ctypes.c_int, vp]),
     'epos_pack_pointwise_weights_split': (ctypes.c_int64,
                                           [vp, ctypes.c_int, ctypes.c_int, vp]),
+    'epos_pack_pointwise_weights_h2': (ctypes.c_int64,
+                                       [vp, ctypes.c_int, ctypes.c_int, vp]),
+    'epos_absmax_f32': (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_int64, vp, vp]),
+    'epos_amax_clear': (ctypes.c_int, [vp, ctypes.c_int64, vp]),
     'epos_pointwise_conv_f32': (ctypes.c_int,
                                 [ctypes.POINTER(PointwiseArgs), vp]),
     'epos_pointwise_conv_grouped_f32': (ctypes.c_int, [
@@ -226,10 +236,13 @@ def load():
     fn.restype = restype
     if argtypes is not None:
       fn.argtypes = argtypes
-  if lib.epos_abi_version() != 4:
+  if lib.epos_abi_version() != 5:
     raise EposError('libepos_hip.so ABI version mismatch')
   _lib = lib
   return lib
+
+
+AMAX_WORDS = 64          # EPOS_AMAX_WORDS: uint32 words per absmax slot
 
 
 def check(rc, what=''):

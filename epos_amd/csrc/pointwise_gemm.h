@@ -28,6 +28,12 @@ bool split_eligible(const EposPointwiseArgs* args, int count);
 // pointwise_gemm_split.hip: the fused separable conv (depthwise producer phase inside
 // the split GEMM's workgroups).
 int launch_sepconv_split(const EposSepConvArgs* a, hipStream_t s);
+// pointwise_gemm_h2.hip: fp32 GEMM on the fp16 matrix pipe (two fp16 pieces per operand,
+// three piece products); every problem carries fp16-pair weights (p.Wh). A problem
+// without an absmax slot (p.a_amax) gets one from the library's ring, measured first.
+int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
+                      const int* conv_cin = nullptr, const int* conv_rate = nullptr);
+bool h2_eligible(const EposPointwiseArgs* args, int count);
 int64_t sepconv_sync_words(int M);
 
 namespace {
@@ -107,6 +113,15 @@ __device__ __forceinline__ void glds16_s_off(unsigned voff, const float* sbase) 
   asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2"
                : : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
+// max over the wave of a non-negative value -> one atomic max on word (salt % 64) of an
+// absmax slot (include/epos_hip.h). NaNs are ignored by fmaxf; +Inf propagates.
+__device__ __forceinline__ void amax_publish(unsigned* slot, float m, int lane, int salt) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0)
+    __hip_atomic_fetch_max(slot + (salt & (EPOS_AMAX_WORDS - 1)), __float_as_uint(m),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f),
                      fmaxf(v.w, 0.f));
@@ -172,6 +187,7 @@ __device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
   // same wave wrote and reads: only the LDS counter has to drain
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   const bool relu = p.relu != 0;
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int row = r0 + i * RPI;
@@ -181,9 +197,13 @@ __device__ __forceinline__ void vec_epilogue(float* ws, const f32x16* acc,
       v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
     }
     if (relu) v = relu4(v);
-    if (m < M && n < N)
+    if (m < M && n < N) {
       *reinterpret_cast<float4*>(p.C + static_cast<int64_t>(m) * p.ldc + n) = v;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
   }
+  // absmax slot of the output (EposPointwiseArgs.c_amax): the consumers' fp16-pair scale
+  if (p.c_amax) amax_publish(p.c_amax, amax, lane, static_cast<int>(blockIdx.x) * 4 + (m0w >> 5));
 }
 
 }  // namespace

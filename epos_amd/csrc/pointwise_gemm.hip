@@ -545,6 +545,14 @@ int validate(const EposPointwiseArgs* a) {
   EPOS_REQUIRE(a->K % 4 == 0 && a->lda % 4 == 0, "K and lda must be multiples of 4");
   EPOS_REQUIRE((reinterpret_cast<uintptr_t>(a->A) & 15) == 0, "A must be 16-byte aligned");
   EPOS_REQUIRE(a->sub >= 1, "sub must be >= 1");
+  if (a->c_amax) {
+    // the absmax of the output is taken in the float4 epilogue of the LDS-DMA kernels
+    bool ok = a->relu_in == 0 && a->M > 8 && (a->N & 3) == 0 && (a->ldc & 3) == 0 &&
+              (reinterpret_cast<uintptr_t>(a->C) & 15) == 0;
+    if (a->R) ok = ok && (a->ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(a->R) & 15) == 0;
+    EPOS_REQUIRE(ok, "c_amax needs N, ldc (ldr) multiples of 4, 16-byte aligned C (R), "
+                     "relu_in == 0 and M > 8");
+  }
   return EPOS_OK;
 }
 
@@ -678,6 +686,10 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
   // Split-operand kernel on the bf16 matrix pipe (pointwise_gemm_split.hip): fp32 in,
   // fp32 out, error not above the fp32 MFMA's; taken whenever the caller supplied the
   // split-packed weights. EPOS_GEMM_SPLIT=0 keeps everything on the fp32 MFMA kernels.
+  // fp16-pair kernel (pointwise_gemm_h2.hip, round 3): the same contract with half the
+  // matrix-pipe work; taken whenever the caller supplied the fp16-pair weights.
+  // EPOS_GEMM_H2=0 falls through to the bf16 x 6 kernel.
+  if (h2_eligible(args, count)) return launch_grouped_h2(args, count, s);
   if (split_eligible(args, count)) return launch_grouped_split(args, count, s);
   // LDS-DMA kernel: the default whenever no pre-activation ReLU has to be applied to
   // A on the way into LDS (measured with warm clocks: 8-30 % faster than the
@@ -689,6 +701,8 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
   }();
   if (args[0].relu_in == 0 && use_dma != 0)
     return launch_grouped_dma(args, count, s);
+  for (int i = 0; i < count; ++i)
+    EPOS_REQUIRE(!args[i].c_amax, "c_amax is not available with the register-staged kernels");
   // Register-staged kernels (pre-activation ReLU on the way into LDS):
   // EPOS_GEMM_TILE_M=64|128 and EPOS_GEMM_WP=0|1 override the choices for tuning.
   // 128-row tiles only when they alone give every CU >= 2 workgroups; the
@@ -730,7 +744,14 @@ extern "C" int epos_conv3x3_f32(const EposConv3x3Args* a, void* stream) {
   p.relu = a->relu; p.relu_in = 0; p.sub = a->stride;
   p.Ho = ho; p.Wo = wo; p.Hi = a->H; p.Wi = a->W;
   p.Ws = a->Ws;
+  p.Wh = a->Wh; p.a_amax = a->x_amax; p.c_amax = a->y_amax;
+  {
+    const int rc = validate(&p);
+    if (rc) return rc;
+  }
   const int cin = a->Cin, rate = a->rate;
+  if (a->Wh && h2_eligible(&p, 1))
+    return launch_grouped_h2(&p, 1, static_cast<hipStream_t>(stream), &cin, &rate);
   // split-operand kernel when the split-packed weights came along (K steps of 16
   // channels inside one tap: Cin % 32 == 0 covers it)
   if (a->Ws && split_eligible(&p, 1))

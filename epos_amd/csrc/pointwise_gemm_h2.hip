@@ -1,0 +1,766 @@
+// fp32 pointwise GEMM on the fp16 matrix pipe of gfx950 ("h2" kernel: two fp16 pieces per
+// operand, three piece products per fp32 product). Round 3; the default fp32 GEMM.
+//
+// The bf16 x 6 split kernel (pointwise_gemm_split.hip) spends six 32x32x16 MFMAs per
+// fp32-equivalent 32x32x16 block, and the step it dominates runs AT the chip's power cap:
+// matrix-pipe work is what the energy goes to. fp16 has 11 significand bits where bf16 has
+// 8, so TWO round-to-nearest pieces carry an fp32 significand,
+//     t  = x * 2^e                      (power of two: exact)
+//     hi = rn_fp16(t)                   |t - hi| <= 2^-11 |t|, t - hi exact in fp32
+//     mid = rn_fp16((t - hi) * 2^11)    hi + mid * 2^-11 = t up to 1 ulp of the 24-bit t
+// and the product needs THREE MFMAs (v_mfma_f32_32x32x16_f16, same rate as bf16):
+//     acc  += ah * bh
+//     corr += ah * bm + am * bh         (scaled by 2^-11 when added to acc in the epilogue)
+// am * bm (<= 2^-22 |a b|, random sign) is dropped. Piece products are exact in fp32
+// (11 x 11 bits), each MFMA adds 16 of them with one rounding; measured against fp64 the
+// rms error is ~1.2e-8 of sum |a||w| (the fp32-MFMA kernel: 2.8e-8, the bf16 x 6 kernel:
+// 1.1e-8) -- tests/test_gpu_layers.py holds it to the same bars as the split kernel.
+//
+// What fp16 costs is exponent range (5 bits), so both operands are scaled by powers of two:
+//   * W per output column on the host (epos_pack_pointwise_weights_h2: column maximum into
+//     [2^14, 2^15); a matrix with a weight outside the ~2^27 window below its column maximum
+//     is REFUSED there and the layer keeps the bf16 x 6 kernel);
+//   * A per tensor, at run time, from an upper bound of max|A| that the producers of A
+//     maintain in device memory (EposPointwiseArgs.a_amax: "absmax slots", atomic max in the
+//     GEMM epilogues; for a depthwise output the bound follows from the depthwise input's
+//     slot and the filter's l1 norm). The scale puts the BOUND into [2^14, 2^15): no element
+//     can overflow, elements down to ~2^-27 of the bound keep full precision, smaller ones
+//     degrade gracefully (absolute error <= 2^-50 x bound). The rounding of hi / mid does not
+//     depend on the power of two, so results do not depend on how tight the bound is.
+// The epilogue multiplies by the two inverse scales (exact) before bias / residual / ReLU.
+//
+// Structure = the split kernel's: 128 x 128 tile per 256-thread workgroup, waves 4 x 1 (a
+// wave owns 32 rows and all 128 columns: 4 column blocks x {acc, corr}), K step 16 per
+// stage, LDS-DMA ring of FIVE 16 KB stages (A: 128 rows x 64 B fp32, XOR-swizzled; W: 8 KB
+// of lane-linear fp16 fragments) = 80 KB, two workgroups per CU; tile kt+4 is issued while
+// tile kt is computed (its four pieces between the first MFMAs), counted vmcnt, one raw
+// s_barrier per stage; the next stage's A fragment is split between the MFMAs of the second
+// half (7 VALU per pair of values: pk_mul, cvt_pk, 2 cvt, pk_add, pk_mul, cvt_pk). Implicit
+// 3x3 conv mode, grouped launches, strided-row shortcut form, XCD-aware / banded tile order
+// and the float4 epilogue are the split kernel's.
+#include <string.h>
+
+#include "pointwise_gemm.h"
+
+namespace epos {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) float g_zero_chunk_h2[4] = {0.f, 0.f, 0.f, 0.f};
+
+constexpr int H2_BM = 128, H2_BN = 128, H2_BK = 16;
+constexpr int H2_W_BYTES = H2_BK * H2_BN * 4;       // 8192: 4 col blocks x 2 pieces x 1 KB
+constexpr int H2_A_BYTES = H2_BM * H2_BK * 4;       // 8192
+constexpr int H2_STAGE = H2_W_BYTES + H2_A_BYTES;   // 16384
+constexpr int H2_NST = 5;
+constexpr int H2_LDS = H2_NST * H2_STAGE;           // 81920: two workgroups per CU
+constexpr int H2_NP = 4;                            // LDS-DMA pieces per wave and stage
+constexpr int H2_EP_ROW = 132;                      // floats per staged epilogue row
+
+__device__ __forceinline__ void mfma_f16(const u32x4& a, const u32x4& b, f32x16& c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                             __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// two fp32 values -> packed (hi, hi), (mid, mid) fp16 pairs; s = the tensor's scale
+__device__ __forceinline__ void split_pair(float x0, float x1, float s, unsigned& hi,
+                                           unsigned& mid) {
+  const f32x2 t = {x0 * s, x1 * s};
+  const f16x2 h = __builtin_convertvector(t, f16x2);          // v_cvt_pk_f16_f32 (RNE)
+  const f32x2 r = (t - __builtin_convertvector(h, f32x2)) * 2048.f;   // exact residual
+  const f16x2 m = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  mid = __builtin_bit_cast(unsigned, m);
+}
+
+// Scale of the A operand from the bound in the absmax slot(s): a power of two s with
+// s * bound in [2^14, 2^15) (fp16 overflows at 65520), and its inverse. A non-finite bound
+// (an Inf / NaN upstream) gives s = 1: such rows come out non-finite, the others right.
+__device__ __forceinline__ void a_scale(const EposPointwiseArgs& p, int lane, float& s,
+                                        float& inv) {
+  unsigned v = p.a_amax[lane];
+  if (p.a_amax2) {
+    const unsigned v2 = p.a_amax2[lane];
+    v = v2 > v ? v2 : v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned w = __shfl_xor(v, o, 64);
+    v = w > v ? w : v;
+  }
+  float bound = __uint_as_float(v);
+  if (p.a_gain != 0.f) bound = p.a_gain * bound + p.a_bias;
+  const unsigned e = __float_as_uint(bound) >> 23;            // bound >= 0: no sign bit
+  int sb = 268 - static_cast<int>(e);                         // 2^(14 - (e - 127)), biased
+  sb = sb > 253 ? 253 : sb;
+  if (e >= 255u) sb = 127;
+  s = __uint_as_float(static_cast<unsigned>(sb) << 23);
+  inv = __uint_as_float(static_cast<unsigned>(254 - sb) << 23);
+}
+
+// Epilogue of the h2 kernel: value = (acc + corr * 2^-11) * 2^-e_n * 2^-e_a + bias
+// (+ residual) (ReLU), transposed through the wave's LDS region and written as float4
+// rows (see vec_epilogue in pointwise_gemm.h); optionally max|value| -> c_amax.
+template <bool HAS_RES>
+__device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
+                                                const f32x16* corr, const float* cn,
+                                                float inv_a, const EposPointwiseArgs& p,
+                                                int m0w, int n0w, int lane, int salt) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = p.M, N = p.N;
+  constexpr int EPR = H2_EP_ROW;
+  constexpr int C4 = 32;                     // float4 per staged row (128 columns)
+  constexpr int RPI = 2;                     // rows per wave instruction
+  constexpr int NI = 16;
+  const int c4 = lane & 31, r0 = lane >> 5;
+  const int n = n0w + c4 * 4;
+  float4 rv[HAS_RES ? NI : 1];
+  if (HAS_RES) {
+    const int ncl = n < N ? n : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      int m = m0w + r0 + i * RPI;
+      m = m < M ? m : M - 1;
+      rv[i] = *reinterpret_cast<const float4*>(p.R + static_cast<int64_t>(m) * p.ldr + ncl);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int nb = n0w + j * 32 + l31;
+    const float bias = p.bias ? p.bias[nb < N ? nb : N - 1] : 0.f;
+    const float c = cn[j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sum = fmaf(corr[j][r], 0x1p-11f, acc[j][r]);
+      ws[((r & 3) + 8 * (r >> 2) + 4 * h) * EPR + j * 32 + l31] = sum * c * inv_a + bias;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const bool relu = p.relu != 0;
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = r0 + i * RPI;
+    const int m = m0w + row;
+    float4 v = *reinterpret_cast<const float4*>(ws + row * EPR + c4 * 4);
+    if (HAS_RES) {
+      v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+    }
+    if (relu) v = relu4(v);
+    if (m < M && n < N) {
+      *reinterpret_cast<float4*>(p.C + static_cast<int64_t>(m) * p.ldc + n) = v;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  }
+  if (p.c_amax) amax_publish(p.c_amax, amax, lane, salt);
+}
+
+template <bool HAS_RES, bool SINGLE, bool CONV>
+__global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs ga_) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int l31 = lane & 31, h = lane >> 5;
+
+  (void)ga_;
+  const GroupedArgs* __restrict__ gp =
+      (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  int bid;
+  {   // workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles
+    const int total = gp->tile_start[MAX_GROUP];
+    const int raw = blockIdx.x, x = raw & 7, idx = raw >> 3;
+    const int q = total >> 3, r = total & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+  }
+  int pi = 0;
+  if (!SINGLE) {
+#pragma unroll
+    for (int i = 1; i < MAX_GROUP; ++i)
+      if (i < gp->count && bid >= gp->tile_start[i]) pi = i;
+    bid -= gp->tile_start[pi];
+  }
+  const EposPointwiseArgs p = gp->p[pi];
+  const int tiles_n = gp->tiles_n[pi];
+  const int M = p.M, N = p.N, K = p.K;
+  // tile order inside an XCD's range: column fastest; wide problems in bands of 8 column
+  // tiles (all row tiles of a band before the next band), as in the split kernel
+  int tile_m, tile_n;
+  if (tiles_n <= 8) {
+    tile_n = bid % tiles_n;
+    tile_m = bid / tiles_n;
+  } else {
+    const int tiles_m = (M + H2_BM - 1) / H2_BM;
+    const int per_band = tiles_m * 8;
+    const int band = bid / per_band;
+    const int rem = bid - band * per_band;
+    const int left = tiles_n - band * 8;
+    const int bw = left < 8 ? left : 8;
+    tile_m = rem / bw;
+    tile_n = band * 8 + (rem - tile_m * bw);
+  }
+  const int m0 = tile_m * H2_BM, n0 = tile_n * H2_BN;
+  const int nks = (K + H2_BK - 1) / H2_BK;
+  const int cblocks = CONV ? gp->conv_cin[pi] / H2_BK : 1;   // channel blocks per tap
+  const int crate = CONV ? gp->conv_rate[pi] : 1;
+
+  float sa_v, inv_a;
+  a_scale(p, lane, sa_v, inv_a);
+  const float sa = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sa_v)));
+
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) float*)smem));
+
+  // ---- A pieces (1 KB = 16 rows x 64 B): piece = wave*2 + i, lane -> (row, slot);
+  //      slot s of row r holds chunk s ^ ((r >> 2) & 3)
+  const float* asrc[2];
+  unsigned avoff[2];
+  int achunk[2];
+  int apy[CONV ? 2 : 1], apx[CONV ? 2 : 1];
+  unsigned a_dst[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 16 * (wave * 2 + i) + (lane >> 2);
+    const int c = (lane & 3) ^ ((r >> 2) & 3);
+    int m = m0 + r;
+    m = m < M ? m : M - 1;
+    int64_t row = m;
+    if (CONV) {                      // centre tap of output pixel m
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      apy[i] = yo * p.sub;
+      apx[i] = xo * p.sub;
+      row = (static_cast<int64_t>(b) * p.Hi + apy[i]) * p.Wi + apx[i];
+    } else if (p.sub > 1) {
+      asm volatile("" ::: "memory");        // keep the divisions off the common path
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw, rem = m - b * hw;
+      const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+      row = (static_cast<int64_t>(b) * p.Hi + yo * p.sub) * p.Wi + xo * p.sub;
+    }
+    asrc[i] = p.A + row * p.lda + c * 4;
+    avoff[i] = static_cast<unsigned>((row * p.lda + c * 4) * 4);   // bytes from p.A
+    achunk[i] = c * 4;
+    a_dst[i] = lds0 + H2_W_BYTES + (wave_u * 2 + i) * 1024;
+  }
+  // ---- W pieces: the 8 KB stage image is contiguous in the packed buffer
+  const unsigned wvoff = static_cast<unsigned>(((wave * 2) * 64 + lane) * 16);
+  const unsigned w_dst = lds0 + (wave_u * 2) * 1024;
+  const float* abase = uniform_ptr(p.A);
+  const float* wsb = uniform_ptr(reinterpret_cast<const float*>(
+      static_cast<const char*>(p.Wh) + static_cast<int64_t>(tile_n) * nks * H2_W_BYTES));
+
+  auto issue_piece = [&](int kt, int stage, auto piece_tag, auto tail_tag) {
+    constexpr int PIECE = decltype(piece_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const unsigned so = static_cast<unsigned>(stage) * H2_STAGE;
+    if constexpr (PIECE < 2) {
+      const float* src;
+      if constexpr (CONV) {
+        const int tap = kt / cblocks, cb = kt - tap * cblocks;       // uniform
+        const int ky = tap / 3, dy = (ky - 1) * crate, dx = (tap - ky * 3 - 1) * crate;
+        const bool ok = static_cast<unsigned>(apy[PIECE] + dy) < static_cast<unsigned>(p.Hi) &&
+                        static_cast<unsigned>(apx[PIECE] + dx) < static_cast<unsigned>(p.Wi);
+        src = asrc[PIECE] + ((dy * p.Wi + dx) * p.lda + cb * H2_BK);
+        src = ok ? src : g_zero_chunk_h2;
+      } else if constexpr (!TAIL) {
+        // full K step of a 1x1 conv: scalar base + 32-bit lane offset
+        const float* ab = abase + (kt * H2_BK - PIECE * 256);      // uniform
+        if constexpr (PIECE == 0) glds16_s_m0(avoff[0], ab, a_dst[0] + so);
+        else glds16_s_off<PIECE * 1024>(avoff[PIECE], ab);
+        return;
+      } else {
+        src = asrc[PIECE] + kt * H2_BK;
+        src = (kt * H2_BK + achunk[PIECE] < K) ? src : g_zero_chunk_h2;
+      }
+      if constexpr (PIECE == 0) glds16_v_m0(src, a_dst[0] + so);
+      else glds16_v_off<PIECE * 1024>(src - PIECE * 256);
+    } else {
+      const float* wb = wsb + static_cast<int64_t>(kt) * (H2_W_BYTES / 4);
+      if constexpr (PIECE == 2) glds16_s_m0(wvoff, wb, w_dst + so);
+      else glds16_s_off<1024>(wvoff, wb);
+    }
+  };
+  auto issue = [&](int kt, int stage) {
+    issue_piece(kt, stage, std::integral_constant<int, 0>{}, std::true_type{});
+    issue_piece(kt, stage, std::integral_constant<int, 1>{}, std::true_type{});
+    issue_piece(kt, stage, std::integral_constant<int, 2>{}, std::true_type{});
+    issue_piece(kt, stage, std::integral_constant<int, 3>{}, std::true_type{});
+  };
+
+  // ---- fragment addresses (float index from the stage base)
+  int a_off[2];
+  {
+    const int sw = (l31 >> 2) & 3;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      a_off[j] = H2_W_BYTES / 4 + (wave * 32 + l31) * H2_BK + (((2 * h + j) ^ sw) << 2);
+  }
+  const int b_off = lane * 4;               // + (cb*2 + piece) * 256 floats
+
+  float4 xa[2];             // raw fp32 A fragments of the NEXT stage to compute
+  u32x4 bp[4][2];           // W fragments {hi, mid} per column block
+  auto read_a = [&](int stage) {
+    const float* s = smem + stage * (H2_STAGE / 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xa[j] = *reinterpret_cast<const float4*>(s + a_off[j]);
+  };
+  auto read_b = [&](int stage, auto cb_tag) {
+    constexpr int cb = decltype(cb_tag)::value;
+    const float* s = smem + stage * (H2_STAGE / 4);
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc)
+      bp[cb][pc] = *reinterpret_cast<const u32x4*>(s + b_off + (cb * 2 + pc) * 256);
+  };
+
+  f32x16 acc[4], corr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; corr[j][r] = 0.f; }
+
+  // ---- prologue: up to four tiles in flight, tile 0 landed + visible
+  issue(0, 0);
+  if (nks > 1) issue(1, 1);
+  if (nks > 2) issue(2, 2);
+  if (nks > 3) issue(3, 3);
+  if (nks > 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nks > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nks > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_a(0);
+  read_b(0, std::integral_constant<int, 0>{});
+  read_b(0, std::integral_constant<int, 1>{});
+  read_b(0, std::integral_constant<int, 2>{});
+  read_b(0, std::integral_constant<int, 3>{});
+
+  u32x4 ah, am;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float* x = reinterpret_cast<const float*>(&xa[u >> 1]);
+    unsigned hh, mm;
+    split_pair(x[(u & 1) * 2], x[(u & 1) * 2 + 1], sa, hh, mm);
+    ah[u] = hh; am[u] = mm;
+  }
+  // MODE 0: issue tile kt+4 (full)   1: issue tile kt+4 (the last, maybe partial)
+  //      2: kt+3 is the last tile    3: kt+2 is the last    4: kt+1 is the last   5: last
+  // LIVE: column blocks that hold any column < N (4, or 3 for the last column tile of
+  // e.g. N = 728: every wave of the workgroup then skips the same quarter of its MFMAs)
+  auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr int LIVE = decltype(live_tag)::value;
+    const int s4 = stage + 4 >= H2_NST ? stage + 4 - H2_NST : stage + 4;
+    const int s1 = stage + 1 >= H2_NST ? stage + 1 - H2_NST : stage + 1;
+    u32x4 nh, nm;
+    auto split_unit = [&](auto u_tag) {
+      constexpr int u = decltype(u_tag)::value;
+      const float* x = reinterpret_cast<const float*>(&xa[u >> 1]);
+      float x0 = x[(u & 1) * 2], x1 = x[(u & 1) * 2 + 1];
+      // the conversions are pure: without an anchor instruction selection emits them right
+      // behind the ds_read (and its lgkmcnt wait) instead of behind the MFMA they are
+      // meant to hide under
+      asm volatile("" : "+v"(x0), "+v"(x1));
+      unsigned hh, mm;
+      split_pair(x0, x1, sa, hh, mm);
+      nh[u] = hh; nm[u] = mm;
+    };
+    constexpr bool ISSUE = MODE <= 1;
+    // one MFMA of the schedule + what is pinned behind it
+    //   DMA >= 0: LDS-DMA piece DMA of tile kt+4 after this MFMA
+    //   SPL >= 0: split unit SPL of the next stage's A fragment after this MFMA
+    auto step = [&](const u32x4& a, const u32x4& b, f32x16& c, auto dma_tag, auto spl_tag) {
+      constexpr int DMA = decltype(dma_tag)::value;
+      constexpr int SPL = decltype(spl_tag)::value;
+      mfma_f16(a, b, c);
+      if constexpr (ISSUE && DMA >= 0 && DMA < H2_NP) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(kt + 4, s4, std::integral_constant<int, DMA>{},
+                    std::integral_constant<bool, MODE == 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (SPL >= 0 && SPL < 4 && MODE != 5) {
+        __builtin_amdgcn_sched_barrier(0);
+        split_unit(std::integral_constant<int, SPL>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using N_ = std::integral_constant<int, -1>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // first half: column blocks 0 and 1 interleaved (consecutive MFMAs never on the same
+    // accumulator), small terms first per accumulator; the four DMA pieces ride along
+    step(ah, bp[0][1], corr[0], I0{}, N_{});
+    step(ah, bp[1][1], corr[1], I1{}, N_{});
+    step(am, bp[0][0], corr[0], I2{}, N_{});
+    step(am, bp[1][0], corr[1], I3{}, N_{});
+    step(ah, bp[0][0], acc[0], N_{}, N_{});
+    step(ah, bp[1][0], acc[1], N_{}, N_{});
+    if constexpr (MODE != 5) {
+      // my reads of this stage are complete (fragments are in registers); my pieces of
+      // tile kt+1 have landed once at most the later tiles' pieces are outstanding
+      if (MODE <= 1) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+      else if (MODE == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if (MODE == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      read_a(s1);
+      read_b(s1, std::integral_constant<int, 0>{});
+      read_b(s1, std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // second half: blocks 2 (and 3); the next stage's A fragment is split behind the MFMAs
+    if constexpr (LIVE == 4) {
+      step(ah, bp[2][1], corr[2], N_{}, N_{});
+      step(ah, bp[3][1], corr[3], N_{}, I0{});
+      step(am, bp[2][0], corr[2], N_{}, I1{});
+      step(am, bp[3][0], corr[3], N_{}, I2{});
+      step(ah, bp[2][0], acc[2], N_{}, I3{});
+      step(ah, bp[3][0], acc[3], N_{}, N_{});
+    } else {
+      step(ah, bp[2][1], corr[2], N_{}, I0{});
+      step(am, bp[2][0], corr[2], N_{}, I1{});
+      step(ah, bp[2][0], acc[2], N_{}, I2{});
+      if constexpr (MODE != 5) split_unit(I3{});
+    }
+    if constexpr (MODE != 5) {
+      read_b(s1, std::integral_constant<int, 2>{});
+      if constexpr (LIVE == 4) read_b(s1, std::integral_constant<int, 3>{});
+      ah = nh; am = nm;
+    }
+  };
+  auto k_loop = [&](auto live_tag) {
+    using LV = decltype(live_tag);
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
+    using M4 = std::integral_constant<int, 4>;
+    using M5 = std::integral_constant<int, 5>;
+    int kt = 0;
+    for (; kt + 9 < nks; kt += 5) {        // every LDS offset an immediate
+      tile(kt, 0, M0{}, LV{});
+      tile(kt + 1, 1, M0{}, LV{});
+      tile(kt + 2, 2, M0{}, LV{});
+      tile(kt + 3, 3, M0{}, LV{});
+      tile(kt + 4, 4, M0{}, LV{});
+    }
+    int stage = 0;                          // kt is a multiple of 5 here
+    auto next = [&] { stage = stage + 1 == H2_NST ? 0 : stage + 1; ++kt; };
+    for (; kt + 5 < nks;) { tile(kt, stage, M0{}, LV{}); next(); }
+    if (kt + 5 == nks) { tile(kt, stage, M1{}, LV{}); next(); }
+    if (kt + 4 == nks) { tile(kt, stage, M2{}, LV{}); next(); }
+    if (kt + 3 == nks) { tile(kt, stage, M3{}, LV{}); next(); }
+    if (kt + 2 == nks) { tile(kt, stage, M4{}, LV{}); next(); }
+    tile(kt, stage, M5{}, LV{});
+  };
+  if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{});   // uniform
+  else k_loop(std::integral_constant<int, 4>{});
+
+  // ---- epilogue --------------------------------------------------------------
+  const float* cscale = reinterpret_cast<const float*>(
+      static_cast<const char*>(p.Wh) + static_cast<int64_t>(tiles_n) * nks * H2_W_BYTES);
+  float cn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cn[j] = cscale[n0 + j * 32 + l31];   // padded to tiles_n*128
+  if (vec_epilogue_ok(p, HAS_RES)) {
+    __syncthreads();
+    float* ws = smem + wave * 32 * H2_EP_ROW;
+    vec_epilogue_h2<HAS_RES>(ws, acc, corr, cn, inv_a, p, m0 + wave * 32, n0, lane,
+                             blockIdx.x * 4 + wave);
+    return;
+  }
+  const bool relu = p.relu != 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + j * 32 + l31;
+    const int nc = n < N ? n : N - 1;
+    const float bias = p.bias ? p.bias[nc] : 0.f;
+    const int mb = m0 + wave * 32 + 4 * h;
+    float rv[16];
+    if (HAS_RES) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = mb + (r & 3) + 8 * (r >> 2);
+        m = m < M ? m : M - 1;
+        rv[r] = p.R[static_cast<int64_t>(m) * p.ldr + nc];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mb + (r & 3) + 8 * (r >> 2);
+      float v = fmaf(corr[j][r], 0x1p-11f, acc[j][r]) * cn[j] * inv_a + bias;
+      if (HAS_RES) v += rv[r];
+      if (relu) v = fmaxf(v, 0.f);
+      if (m < M && n < N) p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
+    }
+  }
+}
+
+template <bool HAS_RES, bool SINGLE, bool CONV>
+int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
+  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS);
+    attr_set = true;
+  }
+  // 80 KB per workgroup: at most two per CU = two MFMA waves per SIMD
+  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), H2_LDS, s, g);
+  return launch_status("pointwise_gemm_h2_f32");
+}
+
+// ---- absmax reduction (epos_absmax_f32 and the library's own measurement of A when the
+// caller gave no slot): float4 rows, one atomic per wave.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* X, int64_t ldx,
+                                                     int64_t rows, int c4n, int cols,
+                                                     int vec, unsigned* slot) {
+  const int64_t total = rows * c4n;
+  float m = 0.f;
+  for (int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; id < total;
+       id += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+    const int64_t r = id / c4n;
+    const int c = static_cast<int>(id - r * c4n) * 4;
+    const float* px = X + r * ldx + c;
+    if (vec && c + 4 <= cols) {
+      const float4 v = *reinterpret_cast<const float4*>(px);
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    } else {
+      for (int e = 0; e < 4 && c + e < cols; ++e) m = fmaxf(m, fabsf(px[e]));
+    }
+  }
+  amax_publish(slot, m, threadIdx.x & 63, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+int launch_absmax(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsigned* slot,
+                  hipStream_t s) {
+  const int vec = (ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+  const int c4n = static_cast<int>(ceil_div(cols, 4));
+  const int64_t total = rows * c4n;
+  if (total <= 0) return EPOS_OK;
+  const int blocks = static_cast<int>(total / 256 + 1 < 2048 ? total / 256 + 1 : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, X, ldx, rows, c4n,
+                     static_cast<int>(cols), vec, slot);
+  return launch_status("absmax_kernel");
+}
+
+// The library's own slots for callers that pass Wh without a_amax (single calls, tests):
+// a ring of 256 slots, taken round robin; memset + reduction + GEMM are ordered on the
+// caller's stream. A slot is reused after 256 further such calls -- plans that overlap
+// streams or capture graphs pass their own slots.
+constexpr int RING_SLOTS = 256;
+unsigned* ring_slot() {
+  static unsigned* base = nullptr;
+  static unsigned next = 0;
+  if (!base) {
+    if (hipMalloc(reinterpret_cast<void**>(&base),
+                  sizeof(unsigned) * EPOS_AMAX_WORDS * RING_SLOTS) != hipSuccess) {
+      base = nullptr;
+      return nullptr;
+    }
+  }
+  const unsigned i = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % RING_SLOTS;
+  return base + static_cast<size_t>(i) * EPOS_AMAX_WORDS;
+}
+
+}  // namespace
+
+// A group goes to the h2 kernel when every problem carries fp16-pair weights and has no
+// pre-activation ReLU; like split_eligible the choice depends on nothing else, so a layer
+// gives the same bits alone or in a group.
+bool h2_eligible(const EposPointwiseArgs* args, int count) {
+  static const int mode = [] {       // EPOS_GEMM_SPLIT=0 means "fp32 MFMA everywhere"
+    const char* e = getenv("EPOS_GEMM_H2");
+    const char* sp = getenv("EPOS_GEMM_SPLIT");
+    if (sp && atoi(sp) == 0) return 0;
+    return e ? atoi(e) : 1;
+  }();
+  if (mode == 0) return false;
+  for (int i = 0; i < count; ++i) {
+    const EposPointwiseArgs& a = args[i];
+    if (!a.Wh || a.relu_in != 0 || a.M <= 8 || (a.K & 3) != 0 || (a.lda & 3) != 0 ||
+        (reinterpret_cast<uintptr_t>(a.A) & 15) != 0)
+      return false;
+    const int64_t rows = a.sub > 1 ? static_cast<int64_t>(a.M) / (static_cast<int64_t>(a.Ho) * a.Wo) *
+                                         a.Hi * a.Wi
+                                   : a.M;
+    if (rows * a.lda * 4 >= (1LL << 32)) return false;
+  }
+  return true;
+}
+
+int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
+                      const int* conv_cin, const int* conv_rate) {
+  if (conv_cin && (count != 1 || args[0].R != nullptr)) {
+    set_error("launch_grouped_h2: implicit conv = one problem without residual");
+    return EPOS_E_INVALID;
+  }
+  GroupedArgs g = {};
+  g.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    g.p[i] = args[i];
+    if (!g.p[i].a_amax) {
+      // no bound given: measure A (rows actually read: the whole [B, Hi, Wi] map when
+      // the rows are gathered with a stride or by conv taps)
+      unsigned* slot = ring_slot();
+      if (!slot) {
+        set_error("launch_grouped_h2: cannot allocate the absmax slot ring");
+        return EPOS_E_INVALID;
+      }
+      const bool gathered = conv_cin || args[i].sub > 1;
+      const int64_t rows = gathered ? static_cast<int64_t>(args[i].M) /
+                                          (static_cast<int64_t>(args[i].Ho) * args[i].Wo) *
+                                          args[i].Hi * args[i].Wi
+                                    : args[i].M;
+      const int64_t cols = conv_cin ? conv_cin[i] : args[i].K;
+      int rc = check_hip(hipMemsetAsync(slot, 0, sizeof(unsigned) * EPOS_AMAX_WORDS, s),
+                         "hipMemsetAsync(absmax slot)");
+      if (rc) return rc;
+      rc = launch_absmax(args[i].A, args[i].lda, rows, cols, slot, s);
+      if (rc) return rc;
+      g.p[i].a_amax = slot;
+      g.p[i].a_amax2 = nullptr;
+      g.p[i].a_gain = 0.f;
+    }
+    g.tile_start[i] = total;
+    g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, H2_BN));
+    g.npad[i] = g.tiles_n[i] * H2_BN;
+    g.conv_cin[i] = conv_cin ? conv_cin[i] : 0;
+    g.conv_rate[i] = conv_rate ? conv_rate[i] : 1;
+    total += static_cast<int>(ceil_div(args[i].M, H2_BM)) * g.tiles_n[i];
+  }
+  for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  const bool res = args[0].R != nullptr;
+  const bool single = count == 1;
+  if (conv_cin) return launch_h2_tt<false, true, true>(g, total, s);
+  if (res) return single ? launch_h2_tt<true, true, false>(g, total, s)
+                         : launch_h2_tt<true, false, false>(g, total, s);
+  return single ? launch_h2_tt<false, true, false>(g, total, s)
+                : launch_h2_tt<false, false, false>(g, total, s);
+}
+
+}  // namespace epos
+
+extern "C" int epos_amax_clear(uint32_t* slots, int64_t n_slots, void* stream) {
+  using namespace epos;
+  EPOS_REQUIRE(slots && n_slots >= 0, "bad argument");
+  return check_hip(hipMemsetAsync(slots, 0, sizeof(uint32_t) * EPOS_AMAX_WORDS * n_slots,
+                                  static_cast<hipStream_t>(stream)),
+                   "hipMemsetAsync(absmax slots)");
+}
+
+extern "C" int epos_absmax_f32(const float* X, int64_t ldx, int64_t rows, int64_t cols,
+                               uint32_t* slot, void* stream) {
+  using namespace epos;
+  EPOS_REQUIRE(X && slot && rows >= 0 && cols >= 0 && ldx >= cols, "bad argument");
+  return launch_absmax(X, ldx, rows, cols, slot, static_cast<hipStream_t>(stream));
+}
+
+namespace {
+// fp32 -> fp16 round-to-nearest-even (host; the device's v_cvt_pk_f16_f32 in RNE mode)
+uint16_t f32_to_f16_rne(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return static_cast<uint16_t>(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (x >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);      // >= 65520 -> inf
+  if (x < 0x33000001u) return static_cast<uint16_t>(sign);                  // <= 2^-25 -> 0
+  const int e = static_cast<int>(x >> 23) - 127;
+  uint32_t man = (x & 0x7fffffu) | 0x800000u;                               // 24 bits
+  int shift = 13;                                                           // normal: keep 11
+  int he = e + 15;
+  if (he <= 0) { shift += 1 - he; he = 0; }                                 // denormal
+  const uint32_t half = 1u << (shift - 1), rest = man & ((1u << shift) - 1);
+  uint32_t q = man >> shift;
+  if (rest > half || (rest == half && (q & 1u))) ++q;
+  uint32_t out;
+  if (he == 0) out = q;                          // may carry into the exponent: correct
+  else out = (static_cast<uint32_t>(he - 1) << 10) + q;   // q has the implicit bit at 1<<10
+  return static_cast<uint16_t>(sign | out);
+}
+float f16_to_f32(uint16_t hbits) {
+  const uint32_t sign = (hbits & 0x8000u) << 16;
+  const int e = (hbits >> 10) & 31;
+  const uint32_t m = hbits & 0x3ffu;
+  float v;
+  if (e == 0) v = ldexpf(static_cast<float>(m), -24);
+  else if (e == 31) { const uint32_t b = 0x7f800000u | (m << 13); memcpy(&v, &b, 4); }
+  else v = ldexpf(static_cast<float>(m | 0x400u), e - 25);
+  uint32_t b;
+  memcpy(&b, &v, 4);
+  b |= sign;
+  memcpy(&v, &b, 4);
+  return v;
+}
+}  // namespace
+
+extern "C" int64_t epos_pack_pointwise_weights_h2(const float* w_kn, int K, int N,
+                                                  void* dst) {
+  using namespace epos;
+  const int64_t tiles_n = ceil_div(N, H2_BN), nks = ceil_div(K, H2_BK);
+  const int64_t npad = tiles_n * H2_BN;
+  const int64_t wbytes = tiles_n * nks * H2_W_BYTES;
+  const int64_t total = wbytes + npad * 4;
+  // column scales and the representability check (needs the weights, not dst)
+  float* scale = static_cast<float*>(malloc(sizeof(float) * npad));
+  bool ok = scale != nullptr;
+  for (int64_t n = 0; ok && n < npad; ++n) {
+    float cmax = 0.f;
+    if (n < N)
+      for (int64_t k = 0; k < K; ++k) {
+        const float a = fabsf(w_kn[k * static_cast<int64_t>(N) + n]);
+        if (!(a <= 3.0e38f)) ok = false;               // Inf / NaN weights: not here
+        cmax = a > cmax ? a : cmax;
+      }
+    int e = 0;
+    if (cmax > 0.f) {
+      (void)frexpf(cmax, &e);                          // cmax = f * 2^e, f in [0.5, 1)
+      e = 15 - e;                                      // cmax * 2^e in [2^14, 2^15)
+    }
+    if (e > 100 || e < -100) ok = false;
+    scale[n] = ldexpf(1.f, e);
+  }
+  for (int64_t n = 0; ok && n < N; ++n)
+    for (int64_t k = 0; k < K; ++k) {
+      const float w = w_kn[k * static_cast<int64_t>(N) + n];
+      if (w == 0.f) continue;
+      const float t = w * scale[n];
+      const float hi = f16_to_f32(f32_to_f16_rne(t));
+      const float mid = f16_to_f32(f32_to_f16_rne((t - hi) * 2048.f));
+      const float err = fabsf((hi + mid * (1.f / 2048.f)) - t);   // exact: both on t's grid
+      if (!(err <= fabsf(t) * 0x1p-22f)) { ok = false; break; }
+    }
+  if (!ok) { free(scale); return 0; }
+  if (!dst) { free(scale); return total; }
+  uint16_t* out = static_cast<uint16_t*>(dst);
+  for (int64_t tn = 0; tn < tiles_n; ++tn)
+    for (int64_t ks = 0; ks < nks; ++ks)
+      for (int cbw = 0; cbw < 4; ++cbw)
+        for (int ln = 0; ln < 64; ++ln)
+          for (int j = 0; j < 8; ++j) {
+            const int64_t col = tn * H2_BN + cbw * 32 + (ln & 31);
+            const int64_t k = ks * H2_BK + (ln >> 5) * 8 + j;
+            const float w = (k < K && col < N) ? w_kn[k * static_cast<int64_t>(N) + col] : 0.f;
+            const float t = w * scale[col];
+            const uint16_t hb = f32_to_f16_rne(t);
+            const uint16_t mb = f32_to_f16_rne((t - f16_to_f32(hb)) * 2048.f);
+            const int64_t base = (((tn * nks + ks) * 4 + cbw) * 2) * 512 + ln * 8 + j;
+            out[base] = hb;
+            out[base + 512] = mb;
+          }
+  float* inv = reinterpret_cast<float*>(static_cast<char*>(dst) + wbytes);
+  for (int64_t n = 0; n < npad; ++n) inv[n] = 1.f / scale[n];
+  free(scale);
+  return total;
+}

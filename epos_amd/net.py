@@ -55,6 +55,8 @@ class EposNet(object):
   """Static-shape forward plan. ``forward(images)`` returns the logits buffers;
   ``predict(images)`` the reference's prediction dict (model.py:629-687)."""
 
+  MAX_SLOTS = 512
+
   def __init__(self, checkpoint, batch, height, width, num_objs, num_frags=64,
                model_variant='xception_65', encoder_output_stride=8,
                decoder_output_stride=4, atrous_rates=(12, 24, 36),
@@ -96,6 +98,16 @@ class EposNet(object):
     self.fuse_sepconv = os.environ.get('EPOS_SEPCONV_FUSED', '0') == '1'
     self.fused_sepconvs = []
     self.sepconv_stats = torch.zeros(2, dtype=torch.int32, device=self.dev)
+    # Absmax slots (include/epos_hip.h): the fp16-pair GEMM scales its fp32 A operand by a
+    # power of two taken from an upper bound of max|A|; the producers of every activation
+    # tensor keep that bound in a slot (GEMM epilogues by atomic max). `_bounds` maps a
+    # buffer to (slot, slot2, gain, bias): bound = gain * max(slot, slot2) + bias. The
+    # table is zeroed by the plan's first op.
+    self._amax_table = torch.zeros(self.MAX_SLOTS * _lib.AMAX_WORDS, dtype=torch.int32,
+                                   device=self.dev)
+    self._n_slots = 0
+    self._bounds = {}
+    self.h2_layers, self.h2_refused = [], []
     self._build_plan()
 
   # ------------------------------------------------------------ buffers ---
@@ -108,6 +120,36 @@ class EposNet(object):
     t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
     self._keep.append(t)
     return t
+
+  # ------------------------------------------------------- absmax slots ---
+  def _new_slot(self):
+    i = self._n_slots
+    if i >= self.MAX_SLOTS:
+      raise _lib.EposError('absmax slot table exhausted')
+    self._n_slots += 1
+    return i
+
+  def _slot_ptr(self, i):
+    return _ptr(self._amax_table, i * _lib.AMAX_WORDS) if i is not None else None
+
+  def _bound_of(self, buf):
+    """(slot, slot2, gain, bias) of a buffer, or None when nobody tracks it."""
+    return self._bounds.get(buf.data_ptr())
+
+  def _set_bound(self, buf, slot, slot2=None, gain=0.0, bias=0.0):
+    self._bounds[buf.data_ptr()] = (slot, slot2, float(gain), float(bias))
+
+  def _out_slot(self, buf, n, ldc, off=0):
+    """Slot that a GEMM writing `buf` publishes max|out| into, or None when its epilogue
+    cannot (rows not float4-able). Writers of one (concat) buffer share the slot."""
+    if n % 4 or ldc % 4 or off % 4:
+      return None
+    b = self._bound_of(buf)
+    if b is not None and b[1] is None and b[2] == 0.0:
+      return b[0]
+    slot = self._new_slot()
+    self._set_bound(buf, slot)
+    return slot
 
   # ------------------------------------------------------ weight packing ---
   def _pack_pointwise(self, w_kn, scale, bias):
@@ -144,6 +186,27 @@ class EposNet(object):
         dst.ctypes.data_as(ctypes.c_void_p))
     return self._dev(dst)
 
+  def _pack_h2(self, w_kn, scale):
+    """The same folded weights as fp16 pairs with per-column power-of-two scales
+    (epos_pack_pointwise_weights_h2), or None when the matrix is refused there (a weight
+    outside the window fp16 pairs represent to 2^-22): the layer then stays on the
+    bf16 x 6 kernel."""
+    k, n = w_kn.shape
+    w = np.ascontiguousarray(w_kn.astype(np.float32) * scale[None, :].astype(
+        np.float32))
+    kpad = (k + 3) // 4 * 4
+    if kpad != k:
+      w = np.concatenate([w, np.zeros((kpad - k, n), np.float32)], 0)
+    total = self.lib.epos_pack_pointwise_weights_h2(
+        w.ctypes.data_as(ctypes.c_void_p), kpad, n, None)
+    if total <= 0:
+      return None
+    dst = np.empty(total, np.uint8)
+    self.lib.epos_pack_pointwise_weights_h2(
+        w.ctypes.data_as(ctypes.c_void_p), kpad, n,
+        dst.ctypes.data_as(ctypes.c_void_p))
+    return self._dev(dst)
+
   def _conv_params(self, scope, eps):
     """1x1 / dense conv followed by BN -> (w [K,N], scale, bias)."""
     w = self.ckpt[scope + '/weights']
@@ -155,6 +218,9 @@ class EposNet(object):
     w = self.ckpt[scope + '/depthwise_weights']          # [3,3,C,1]
     scale, bias = W.fold_bn(self.ckpt, scope, eps, 'dw')
     w9c = (w[:, :, :, 0].reshape(9, -1) * scale[None, :]).astype(np.float32)
+    # |depthwise output| <= gain * max|input| + bias0 (the consumer GEMM's A bound)
+    self._dw_gain = float(np.abs(w9c.astype(np.float64)).sum(0).max())
+    self._dw_bias0 = float(np.abs(np.asarray(bias, np.float64)).max())
     return self._dev(w9c), self._dev(bias)
 
   # --------------------------------------------------------------- ops ---
@@ -167,7 +233,7 @@ class EposNet(object):
 
   def _pointwise(self, name, a, a_off, lda, m, k, w_kn, scale, bias, c, c_off,
                  ldc, relu, relu_in=False, res=None, res_off=0, ldr=0, sub=1,
-                 ho=0, wo=0, hi=0, wi=0, group=None, dw=None):
+                 ho=0, wo=0, hi=0, wi=0, group=None, dw=None, track_out=True):
     """One 1x1 conv. With ``group`` (a list) the problem is only appended to it;
     ``_flush_group`` later launches the whole list as ONE grouped GEMM. With ``dw``
     (the deferred depthwise of ``_depthwise(defer=True)`` whose output is ``a``) the
@@ -177,12 +243,26 @@ class EposNet(object):
     ws = None if relu_in else self._pack_split(w_kn, scale)
     n = w_kn.shape[1]
     assert kpad == k or (kpad > k and lda >= kpad), (name, k, kpad, lda)
+    # fp16-pair weights when the A operand has a bound; the output's slot
+    ab = self._bound_of(a)
+    wh = None
+    if ab is not None and not relu_in and m > 8:
+      wh = self._pack_h2(w_kn, scale)
+      (self.h2_layers if wh is not None else self.h2_refused).append(name)
+    track = track_out and not relu_in and m > 8 and (res is None or ldr % 4 == 0)
+    cslot = self._out_slot(c, n, ldc, c_off) if track else None
     args = _lib.PointwiseArgs(
         A=_ptr(a, a_off), lda=lda, Wp=_ptr(wp), bias=_ptr(bp),
         R=_ptr(res, res_off) if res is not None else None, ldr=ldr,
         C=_ptr(c, c_off), ldc=ldc, M=m, N=n, K=kpad, relu=int(relu),
         relu_in=int(relu_in), sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi,
-        Ws=_ptr(ws) if ws is not None else None)
+        Ws=_ptr(ws) if ws is not None else None,
+        Wh=_ptr(wh) if wh is not None else None,
+        a_amax=self._slot_ptr(ab[0]) if wh is not None else None,
+        a_amax2=self._slot_ptr(ab[1]) if wh is not None else None,
+        a_gain=ab[2] if wh is not None else 0.0,
+        a_bias=ab[3] if wh is not None else 0.0,
+        c_amax=self._slot_ptr(cslot))
     lib = self.lib
     # fp32 activations in and out, weights once (4 B each: what the layer IS; the
     # split kernel streams 6 B per weight), residual once
@@ -245,6 +325,11 @@ class EposNet(object):
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     w9c, bias = self._dw_params(scope, eps)
     y = self._empty(self.B, ho, wo, c)
+    xb = self._bound_of(x)
+    if xb is not None:
+      g, b0 = self._dw_gain, self._dw_bias0
+      self._set_bound(y, xb[0], xb[1], g * (xb[2] if xb[2] else 1.0),
+                      g * xb[3] + b0)
     args = _lib.DepthwiseArgs(
         X=_ptr(x), ldx=ldx, w9c=_ptr(w9c), bias=_ptr(bias), Y=_ptr(y), ldy=c,
         B=self.B, Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c, stride=stride, rate=rate,
@@ -275,10 +360,18 @@ class EposNet(object):
       ws = self._pack_split(w_kn, scale)
       cout = w_kn.shape[1]
       y = self._empty(self.B, ho, wo, cout)
+      xb = self._bound_of(x)
+      wh = None
+      if xb is not None and xb[1] is None and xb[2] == 0.0:   # a plain slot
+        wh = self._pack_h2(w_kn, scale)
+        (self.h2_layers if wh is not None else self.h2_refused).append(name)
+      yslot = self._out_slot(y, cout, cout)
       cargs = _lib.Conv3x3Args(X=_ptr(x), ldx=cin, Wp=_ptr(wp), bias=_ptr(bp),
                                Y=_ptr(y), ldy=cout, B=self.B, H=hi, W=wi, Cin=cin,
                                Cout=cout, stride=stride, rate=rate, relu=1,
-                               Ws=_ptr(ws))
+                               Ws=_ptr(ws), Wh=_ptr(wh) if wh is not None else None,
+                               x_amax=self._slot_ptr(xb[0]) if wh is not None else None,
+                               y_amax=self._slot_ptr(yslot))
       lib = self.lib
 
       def run_conv(stream, cargs=cargs):
@@ -329,6 +422,8 @@ class EposNet(object):
           _lib.check(lib.epos_subsample_f32(_ptr(x), cin, _ptr(y), depth, B, hi,
                                             wi, cin, stride, stream), 'subsample')
         self._add(scope + '/shortcut_subsample', run_sub)
+        if self._bound_of(x) is not None:
+          self._set_bound(shortcut, *self._bound_of(x))
     else:
       w_kn, sc, bi = self._conv_params(scope + '/shortcut', eps)
       shortcut = self._empty(B, ho, wo, depth)
@@ -354,6 +449,13 @@ class EposNet(object):
         _lib.check(lib.epos_add_relu_f32(_ptr(a), _ptr(b), _ptr(y),
                                          m_out * depth, stream), 'add_relu')
       self._add(scope + '/add_relu', run_add)
+      oslot = self._new_slot()
+      self._set_bound(out, oslot)
+
+      def run_amax(stream, y=out, oslot=oslot):
+        _lib.check(lib.epos_absmax_f32(_ptr(y), depth, m_out, depth,
+                                       self._slot_ptr(oslot), stream), 'add_relu/absmax')
+      self._add(scope + '/add_relu/absmax', run_amax)
     else:
       self._pointwise(scope + '/conv3', r2, 0, db, m_out, db, w_kn, sc, bi, out,
                       0, depth, relu=True, res=shortcut, ldr=depth)
@@ -375,6 +477,8 @@ class EposNet(object):
       _lib.check(lib.epos_maxpool3x3_s2_f32(_ptr(x), c, _ptr(y), c, B, h, w, c,
                                             stream), 'maxpool')
     self._add(net + '/pool1', run_pool)                      # :190
+    if self._bound_of(x) is not None:          # a max-pool output is bounded by its input
+      self._set_bound(pooled, *self._bound_of(x))
     x, h, w = pooled, ph, pw
     target, current_stride, rate = 2, 1, 1                   # 8 / 4 (:185-188)
     low_level = None
@@ -491,6 +595,12 @@ class EposNet(object):
   def _build_plan(self):
     B, H, Wd = self.B, self.H, self.W
     self.images = self._empty(B, H, Wd, 3)
+    lib0 = self.lib
+
+    def run_clear(stream):
+      _lib.check(lib0.epos_amax_clear(_ptr(self._amax_table), self._n_slots, stream),
+                 'amax_clear')
+    self._add('amax_clear', run_clear)
     if self.model_variant == 'xception_65':
       x, h, w, c, low_level = self._backbone_xception()
     else:
@@ -532,6 +642,16 @@ class EposNet(object):
       self._pointwise('aspp%d_pointwise' % i, d, 0, ec, m_enc, ec, w_kn, sc, bi,
                       cat, 256 * (i + 1), ldcat, relu=True, group=grp)
     self._flush_group(grp)
+    # the broadcast image-pooling branch is part of `cat` too: its absmax joins the slot
+    # the four GEMM problems publish into
+    cb = self._bound_of(cat)
+    if cb is not None:
+      cslot = self._slot_ptr(cb[0])
+
+      def run_pool_amax(stream, pool_feat=pool_feat):
+        _lib.check(lib.epos_absmax_f32(_ptr(pool_feat), 256, B, 256, cslot, stream),
+                   'image_pooling/absmax')
+      self._add('image_pooling/absmax', run_pool_amax)
     w_kn, sc, bi = self._conv_params('concat_projection', HEAD_BN_EPS)
     proj = self._empty(B, eh, ew, 256)
     self._pointwise('concat_projection', cat, 0, ldcat, m_enc, ldcat, w_kn, sc,
@@ -554,6 +674,13 @@ class EposNet(object):
     w_kn, sc, bi = self._conv_params('decoder/feature_projection0', HEAD_BN_EPS)
     self._pointwise('decoder/feature_projection0', ll, 0, lc, m_dec, lc, w_kn,
                     sc, bi, dcat, 256, 304, relu=True)
+    # dcat = [bilinear resize of proj | feature projection]: an interpolation never
+    # exceeds its input's absmax, so the concat is bounded by the two producers' slots
+    pb, fb = self._bound_of(proj), self._bound_of(dcat)
+    if pb is not None and fb is not None:
+      self._set_bound(dcat, fb[0], pb[0])
+    else:
+      self._bounds.pop(dcat.data_ptr(), None)
     self.decoder_concat = dcat
     x, c = dcat, 304
     for j in range(2):
@@ -581,7 +708,7 @@ class EposNet(object):
       buf = self._empty(B, dh, dw_, ch)
       self._pointwise('logits/' + name, x, 0, 256, m_dec, 256, wt,
                       np.ones(ch, np.float32), bs, buf, 0, ch, relu=False,
-                      group=grp)
+                      group=grp, track_out=False)
       self.logits[name] = buf
     obj_only = [g for g in grp if g[0].endswith(W.PRED_OBJ_CONF)]
     self._flush_group(grp)              # the three heads: one grouped launch
@@ -658,10 +785,12 @@ class EposNet(object):
       one_c, one_l = np.ones(F, np.float32), np.ones(3 * F, np.float32)
       pc = self._pack_pointwise(wc[:, o * F:(o + 1) * F], one_c,
                                 bc[o * F:(o + 1) * F])
-      pc = pc + (self._pack_split(wc[:, o * F:(o + 1) * F], one_c),)
+      pc = pc + (self._pack_split(wc[:, o * F:(o + 1) * F], one_c),
+                 self._pack_h2(wc[:, o * F:(o + 1) * F], one_c))
       pl = self._pack_pointwise(wl[:, o * 3 * F:(o + 1) * 3 * F], one_l,
                                 bl[o * 3 * F:(o + 1) * 3 * F])
-      pl = pl + (self._pack_split(wl[:, o * 3 * F:(o + 1) * 3 * F], one_l),)
+      pl = pl + (self._pack_split(wl[:, o * 3 * F:(o + 1) * 3 * F], one_l),
+                 self._pack_h2(wl[:, o * 3 * F:(o + 1) * 3 * F], one_l))
       packs.append((pc, pl))
     self._sparse_packs = packs
 
@@ -684,14 +813,22 @@ class EposNet(object):
     for kind in (0, 1):
       probs = []
       for im, obj_id in slots:
-        wp, bp, _, ws = self._sparse_packs[obj_id - 1][kind]
+        wp, bp, _, ws, wh = self._sparse_packs[obj_id - 1][kind]
+        xb = self._bound_of(x)
+        if xb is None:
+          wh = None
         n = F if kind == 0 else 3 * F
         buf = conf if kind == 0 else loc
         ldc = O * n
         probs.append(_lib.PointwiseArgs(
             A=_ptr(x, im * P * 256), lda=256, Wp=_ptr(wp), bias=_ptr(bp), R=None,
             ldr=0, C=_ptr(buf, im * P * ldc + (obj_id - 1) * n), ldc=ldc, M=P,
-            N=n, K=256, relu=0, relu_in=0, sub=1, Ws=_ptr(ws)))
+            N=n, K=256, relu=0, relu_in=0, sub=1, Ws=_ptr(ws),
+            Wh=_ptr(wh) if wh is not None else None,
+            a_amax=self._slot_ptr(xb[0]) if wh is not None else None,
+            a_amax2=self._slot_ptr(xb[1]) if wh is not None else None,
+            a_gain=xb[2] if wh is not None else 0.0,
+            a_bias=xb[3] if wh is not None else 0.0))
         flops += 2 * P * n * 256
       for i in range(0, len(probs), 8):
         chunk = probs[i:i + 8]

@@ -33,7 +33,7 @@ extern "C" {
 #define EPOS_E_NODEVICE (-3)  /* no HIP device available */
 #define EPOS_E_HIP_BASE (-1000)
 
-#define EPOS_ABI_VERSION 4   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32; 4: epos_solve_pnp_ransac */
+#define EPOS_ABI_VERSION 5   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32; 4: epos_solve_pnp_ransac; 5: fp16-pair GEMM (Wh, a_amax, c_amax, epos_pack_pointwise_weights_h2, epos_absmax_f32) */
 
 int epos_abi_version(void);
 const char* epos_last_error(void);
@@ -68,6 +68,44 @@ int64_t epos_pack_pointwise_weights(const float* w_kn, int K, int N, float* dst)
  * if dst == NULL). */
 int64_t epos_pack_pointwise_weights_split(const float* w_kn, int K, int N, void* dst);
 
+/* The same matrix for the fp16-pair GEMM (pointwise_gemm_h2_f32, the default fp32 GEMM
+ * since round 3): every column n is scaled by a power of two 2^e_n that puts its largest
+ * weight into [2^14, 2^15), and every scaled weight t is stored as TWO fp16 values
+ *     hi = rn_fp16(t),  mid = rn_fp16((t - hi) * 2^11)        (t - hi is exact in fp32)
+ * so that hi + mid * 2^-11 carries 22-23 significant bits of t (error <= 1 ulp of the 24-bit
+ * significand). The kernel forms a*w from THREE fp16 MFMA products,
+ *     ah*wh                      (main accumulator)
+ *     ah*wm + am*wh              (correction accumulator, scaled by 2^-11 in the epilogue)
+ * (am*wm, below 2^-22 |a*w| and of random sign, is dropped): fp32-equivalent, not exact; its
+ * measured error against fp64 is below the fp32-MFMA kernel's (tests/test_gpu_layers.py).
+ * Half the matrix-pipe work of the bf16 x 6 split above, 4 instead of 6 bytes per weight.
+ * Layout: [ceil(N/128)][ceil(K/16)][4 column blocks][2 pieces][64 lanes][8 fp16] (fragment
+ * order of v_mfma_f32_32x32x16_f16), then round_up(N,128) floats 2^-e_n.
+ * NOT every matrix qualifies: if some nonzero weight is not reproduced to 2^-22 relative
+ * (it lies more than ~2^27 below its column's maximum, or the column's scale leaves the
+ * fp32 exponent range) the function returns 0 and writes nothing -- the caller then keeps
+ * the bf16 x 6 split kernel for this layer (Wh = NULL).
+ * Host-side helper (host pointers). Returns the number of BYTES written (or required, if
+ * dst == NULL; 0 = not representable). */
+int64_t epos_pack_pointwise_weights_h2(const float* w_kn, int K, int N, void* dst);
+
+/* Absolute-maximum slots. The fp16-pair GEMM scales its fp32 A operand by a power of two
+ * chosen from an UPPER BOUND of max|A| that it reads from device memory when it starts:
+ * a slot is 64 uint32 words [device] holding the bit patterns of non-negative floats; the
+ * bound is the maximum over the 64 words. Producers combine into a slot with atomic max
+ * (the GEMM epilogues do when c_amax is given; epos_absmax_f32 does for any other tensor);
+ * the caller zeroes a slot (hipMemsetAsync) before the first producer of the step runs.
+ * Any upper bound is valid (max-pool / subsample / bilinear resize outputs may reuse their
+ * input's slot); a bound that is too large by 2^j costs j of the ~27 octaves below the
+ * bound within which elements keep full precision. Overflow is impossible by construction.
+ *
+ * epos_absmax_f32: slot = max(slot, max |X[r, 0..cols)|) over `rows` rows of ldx floats. */
+#define EPOS_AMAX_WORDS 64
+int epos_absmax_f32(const float* X, int64_t ldx, int64_t rows, int64_t cols,
+                    uint32_t* slot, void* stream);
+/* Zeroes n_slots consecutive slots (hipMemsetAsync on `stream`). */
+int epos_amax_clear(uint32_t* slots, int64_t n_slots, void* stream);
+
 /* out[m, n] = act( sum_k A[row(m), k] * W[k, n] + bias[n] (+ R[m, n]) )
  * = slim.conv2d(kernel 1x1, stride `sub`) + folded BatchNorm (+ residual add)
  * (+ ReLU): net_xception.py:167-182 (pointwise half of separable_conv2d_same),
@@ -91,6 +129,22 @@ typedef struct EposPointwiseArgs {
   int32_t Ho, Wo, Hi, Wi;   /* only read when sub > 1 */
   const void* Ws;     /* optional [device]: the same weights packed by
                        * epos_pack_pointwise_weights_split (NULL = not provided) */
+  /* ---- ABI 5: fp16-pair GEMM (taken when Wh is given, relu_in == 0 and M > 8;
+   *      EPOS_GEMM_H2=0 disables it; otherwise Ws -> bf16 x 6 kernel, else fp32 MFMA) */
+  const void* Wh;     /* optional [device]: epos_pack_pointwise_weights_h2 of the weights */
+  const uint32_t* a_amax;   /* optional [device]: slot bounding max|A| (see above). NULL
+                       * with Wh given: the library measures A itself first (one memset +
+                       * one reduction launch into an internal slot ring of 256 slots --
+                       * convenient for single calls; plans pass their own slots) */
+  const uint32_t* a_amax2;  /* optional second slot: the bound is the larger of the two
+                       * (A = a concat written by two producers) */
+  float a_gain, a_bias; /* bound = a_gain * slot + a_bias (a_gain == 0 reads as 1, 0):
+                       * A = a depthwise conv of the tensor the slot describes,
+                       * a_gain = max_c sum_taps |w|, a_bias = max_c |bias| */
+  uint32_t* c_amax;   /* optional [device]: slot that receives max|C| over the elements
+                       * this call writes (atomic max). Needs the float4 epilogue:
+                       * N % 4 == 0, ldc % 4 == 0, C (and R) 16-byte aligned, relu_in == 0,
+                       * M > 8; EPOS_E_INVALID otherwise */
 } EposPointwiseArgs;
 int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
 
@@ -136,6 +190,10 @@ typedef struct EposConv3x3Args {
   int32_t relu;
   const void* Ws;     /* optional [device]: epos_pack_pointwise_weights_split of the same
                        * [9*Cin][Cout] matrix (NULL = fp32-MFMA kernel) */
+  /* ---- ABI 5, as in EposPointwiseArgs */
+  const void* Wh;     /* optional [device]: epos_pack_pointwise_weights_h2 of that matrix */
+  const uint32_t* x_amax;   /* optional [device]: slot bounding max|X| */
+  uint32_t* y_amax;   /* optional [device]: receives max|Y| */
 } EposConv3x3Args;
 int epos_conv3x3_f32(const EposConv3x3Args* args, void* stream);
 

@@ -1,0 +1,376 @@
+"""GPU tests of the fp16-pair GEMM (pointwise_gemm_h2_f32, round 3: two fp16 pieces per
+operand, three piece products per fp32 product -- the default fp32 GEMM), through the C ABI.
+Same bars as the bf16 x 6 split kernel it replaces: tests/test_gpu_layers.py::
+test_pointwise_gemm_split_ring / _accuracy / test_split_gemm_adversarial_operands."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.0 ** -24
+
+
+@pytest.fixture(scope='module')
+def lib():
+  from epos_amd import _lib
+  assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+  return _lib.load()
+
+
+def _p(t, off=0):
+  return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+
+
+def _pack(lib, w_kn, which='plain'):
+  k, n = w_kn.shape
+  w = np.ascontiguousarray(w_kn, np.float32)
+  wp = w.ctypes.data_as(ctypes.c_void_p)
+  fn = {'plain': lib.epos_pack_pointwise_weights, 'split': lib.epos_pack_pointwise_weights_split,
+        'h2': lib.epos_pack_pointwise_weights_h2}[which]
+  total = fn(wp, k, n, None)
+  if total <= 0:
+    return None
+  dst = np.empty(total, np.float32 if which == 'plain' else np.uint8)
+  fn(wp, k, n, dst.ctypes.data_as(ctypes.c_void_p))
+  return torch.from_numpy(dst).cuda()
+
+
+def _slot():
+  from epos_amd import _lib
+  return torch.zeros(_lib.AMAX_WORDS, dtype=torch.int32, device='cuda')
+
+
+def _slot_value(slot):
+  return float(slot.cpu().numpy().view(np.float32).max())
+
+
+def _gemm(lib, a, w, kind, bias=None, res=None, relu=0, a_amax=None, a_gain=0.0, a_bias=0.0,
+          c_amax=None, lda=None):
+  """C = A W through epos_pointwise_conv_f32; kind: 'fp32' | 'split' | 'h2'."""
+  from epos_amd import _lib
+  m, k = a.shape
+  n = w.shape[1]
+  lda = lda or k
+  abuf = np.full((m, lda), np.nan, np.float32)
+  abuf[:, :k] = a
+  A = torch.from_numpy(abuf).cuda()
+  C = torch.zeros(m, n, device='cuda')
+  keep = [A, C, _pack(lib, w)]
+  ws = _pack(lib, w, 'split') if kind in ('split', 'h2') else None
+  wh = _pack(lib, w, 'h2') if kind == 'h2' else None
+  assert kind != 'h2' or wh is not None, 'the packer refused this matrix'
+  bd = rd = None
+  if bias is not None:
+    bp = np.zeros((n + 127) // 128 * 128, np.float32); bp[:n] = bias
+    bd = torch.from_numpy(bp).cuda()
+  if res is not None:
+    rd = torch.from_numpy(np.ascontiguousarray(res, np.float32)).cuda()
+  args = _lib.PointwiseArgs(A=_p(A), lda=lda, Wp=_p(keep[2]), bias=_p(bd) if bd is not None else None,
+                            R=_p(rd) if rd is not None else None, ldr=n, C=_p(C), ldc=n,
+                            M=m, N=n, K=k, relu=relu, relu_in=0, sub=1,
+                            Ws=_p(ws) if ws is not None else None,
+                            Wh=_p(wh) if wh is not None else None,
+                            a_amax=_p(a_amax) if a_amax is not None else None,
+                            a_gain=a_gain, a_bias=a_bias,
+                            c_amax=_p(c_amax) if c_amax is not None else None)
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  torch.cuda.synchronize()
+  return C.cpu().numpy()
+
+
+@pytest.mark.parametrize('k', [16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 40, 92, 728])
+@pytest.mark.parametrize('m,n,aligned,res', [(128, 128, 1, 0), (130, 200, 1, 1),
+                                             (257, 132, 0, 1), (1000, 96, 1, 0),
+                                             (16700, 500, 1, 1), (16450, 490, 0, 0)])
+def test_pointwise_gemm_h2_ring(lib, k, m, n, aligned, res):
+  """Every prologue / steady / tail path of the five-stage ring (1..46 K steps, partial last
+  step), ragged M and N tiles (3 and 4 live column blocks), float4 and scalar epilogue,
+  residual + ReLU, output into a wider buffer at an offset; NaNs behind every row of A
+  poison any read past K (also in the library's own absmax pass, taken here because no
+  slot is passed)."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(k * 7 + m + n)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  bias = rng.standard_normal(n).astype(np.float32)
+  r = rng.standard_normal((m, n)).astype(np.float32)
+  npad = (n + 127) // 128 * 128
+  bpad = np.zeros(npad, np.float32); bpad[:n] = bias
+  lda = k + 36
+  abuf = np.full((m, lda), np.nan, np.float32); abuf[:, :k] = a
+  A, Wp, Wh, Bd, R = (torch.from_numpy(abuf).cuda(), _pack(lib, w), _pack(lib, w, 'h2'),
+                      torch.from_numpy(bpad).cuda(), torch.from_numpy(r).cuda())
+  ldc = n + (4 if aligned else 5)
+  off = 4 if aligned else 3
+  C = torch.full((m, ldc), -7.0, device='cuda')
+  args = _lib.PointwiseArgs(A=_p(A), lda=lda, Wp=_p(Wp), bias=_p(Bd),
+                            R=_p(R) if res else None, ldr=n, C=_p(C, off), ldc=ldc,
+                            M=m, N=n, K=k, relu=res, relu_in=0, sub=1, Wh=_p(Wh))
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  torch.cuda.synchronize()
+  out = C.cpu().numpy()
+  ref = a.astype(np.float64) @ w.astype(np.float64) + bias
+  if res:
+    ref = np.maximum(ref + r, 0)
+  np.testing.assert_allclose(out[:, off:off + n], ref, rtol=2e-5, atol=2e-5)
+  assert (out[:, :off] == -7.0).all() and (out[:, off + n:] == -7.0).all()
+
+
+@pytest.mark.parametrize('m,k,n', [(4800, 728, 728), (2048, 2048, 256), (4096, 256, 1344)])
+def test_pointwise_gemm_h2_accuracy(lib, m, k, n):
+  """The claim the kernel rests on (same assertions as test_pointwise_gemm_split_accuracy):
+  its error against an fp64 product is NOT larger than the fp32-MFMA kernel's on the same
+  inputs (ReLU-like activations, as in the network), relative to sum_k |a||w| per output."""
+  rng = np.random.RandomState(k + n)
+  a = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  ref = a.astype(np.float64) @ w.astype(np.float64)
+  mag = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64)
+  errs = {}
+  for kind in ('fp32', 'split', 'h2'):
+    c = _gemm(lib, a, w, kind).astype(np.float64)
+    e = np.abs(c - ref) / mag
+    errs[kind] = (float(np.sqrt((e * e).mean())), float(e.max()))
+  print('rms / max error relative to sum|a||w|:', errs)
+  assert errs['h2'][0] <= errs['fp32'][0] * 1.05
+  assert errs['h2'][1] <= errs['fp32'][1] * 1.5
+  assert errs['h2'][1] < 4e-7
+
+
+def test_h2_result_does_not_depend_on_the_bound(lib):
+  """The power of two only moves exponents: as long as every element stays inside the
+  window of full precision (~2^27 below the bound) a looser bound (slot x gain + bias)
+  gives the same bits; a bound 1000x too large costs 10 octaves of that window and only the
+  smallest elements (< 2^-17 of the maximum here) lose relative precision -- absolute error
+  <= 2^-50 x bound each."""
+  rng = np.random.RandomState(5)
+  m, k, n = 700, 328, 260
+  a = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32)
+  a[(a > 0) & (a < 1e-3)] = 1e-3       # ReLU outputs, none closer to 0 than 2^-12 of the max
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  base = _gemm(lib, a, w, 'h2')
+  from epos_amd import _lib
+  for gain, bias in ((0.0, 0.0), (8.0, 0.0), (1.0, 3.7), (1000.0, 50.0)):
+    slot = _slot()
+    A = torch.from_numpy(a).cuda()
+    _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+    torch.cuda.synchronize()
+    assert _slot_value(slot) == np.abs(a).max()
+    c = _gemm(lib, a, w, 'h2', a_amax=slot, a_gain=gain, a_bias=bias)
+    assert np.array_equal(c, base), (gain, bias)
+  # elements below the shrunken window: still within the absolute floor
+  a2 = a.copy()
+  a2[:, ::7] = np.float32(2.0 ** -22) * np.maximum(rng.standard_normal((m, (k + 6) // 7)), 0)
+  ref = a2.astype(np.float64) @ w.astype(np.float64)
+  slot = _slot()
+  A = torch.from_numpy(a2).cuda()
+  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+  c = _gemm(lib, a2, w, 'h2', a_amax=slot, a_gain=1000.0, a_bias=50.0)
+  bound = 1000.0 * np.abs(a2).max() + 50.0
+  floor = 2.0 ** -50 * 2 * bound * np.abs(w).astype(np.float64).sum(0)
+  mag = np.abs(a2).astype(np.float64) @ np.abs(w).astype(np.float64)
+  assert (np.abs(c - ref) <= 4 * EPS * mag + floor[None, :]).all()
+
+
+def test_h2_publishes_the_output_absmax(lib):
+  """c_amax receives max|C| over what the launch wrote (bias, residual and ReLU applied),
+  from the h2, the bf16 x 6 and the fp32-MFMA kernels alike; it accumulates by max."""
+  rng = np.random.RandomState(6)
+  m, k, n = 1000, 96, 392
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  bias = rng.standard_normal(n).astype(np.float32)
+  r = rng.standard_normal((m, n)).astype(np.float32)
+  for kind in ('h2', 'split', 'fp32'):
+    for relu in (0, 1):
+      slot = _slot()
+      c = _gemm(lib, a, w, kind, bias=bias, res=r, relu=relu, c_amax=slot)
+      assert _slot_value(slot) == np.abs(c).max(), (kind, relu)
+      c2 = _gemm(lib, 0.5 * a, w, kind, c_amax=slot)          # smaller: the slot stays
+      assert _slot_value(slot) == max(np.abs(c).max(), np.abs(c2).max())
+
+
+def test_absmax_kernel(lib):
+  from epos_amd import _lib
+  rng = np.random.RandomState(7)
+  for rows, cols, ldx in ((1, 256, 256), (4800, 728, 728), (1000, 30, 36), (77, 5, 5)):
+    x = rng.standard_normal((rows, ldx)).astype(np.float32)
+    x[:, cols:] = 1e9                                        # outside the window
+    X = torch.from_numpy(x).cuda()
+    slot = _slot()
+    _lib.check(lib.epos_absmax_f32(_p(X), ldx, rows, cols, _p(slot), None))
+    torch.cuda.synchronize()
+    assert _slot_value(slot) == np.abs(x[:, :cols]).max()
+    _lib.check(lib.epos_amax_clear(_p(slot), 1, None))
+    torch.cuda.synchronize()
+    assert _slot_value(slot) == 0.0
+
+
+def test_h2_grouped_and_strided(lib):
+  """Three problems in one grid (one of them 22 columns wide: scalar epilogue inside a
+  group) and a stride-2 row gather, through the h2 kernel."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(12)
+  b, hi, wi, cin = 2, 13, 18, 72
+  ho, wo = (hi + 1) // 2, (wi + 1) // 2
+  x = rng.standard_normal((b, hi, wi, cin)).astype(np.float32)
+  X = torch.from_numpy(x).cuda()
+  outs, refs, arr = [], [], (_lib.PointwiseArgs * 3)()
+  keep = []
+  for i, (n, sub) in enumerate([(136, 2), (22, 2), (260, 2)]):
+    w = (rng.standard_normal((cin, n)) / np.sqrt(cin)).astype(np.float32)
+    Wp, Wh = _pack(lib, w), _pack(lib, w, 'h2')
+    C = torch.zeros(b * ho * wo, n, device='cuda')
+    keep += [Wp, Wh, C]
+    arr[i] = _lib.PointwiseArgs(A=_p(X), lda=cin, Wp=_p(Wp), bias=None, R=None, ldr=0,
+                                C=_p(C), ldc=n, M=b * ho * wo, N=n, K=cin, relu=0,
+                                relu_in=0, sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi,
+                                Wh=_p(Wh))
+    outs.append(C)
+    refs.append(x[:, ::2, ::2, :].reshape(-1, cin).astype(np.float64) @ w)
+  _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
+  torch.cuda.synchronize()
+  for C, ref in zip(outs, refs):
+    np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('b,h,w,cin,cout,stride,rate', [
+    (2, 12, 16, 32, 64, 1, 1), (1, 9, 21, 64, 40, 1, 1), (2, 7, 5, 32, 136, 1, 1),
+    (2, 15, 21, 64, 72, 2, 1), (1, 20, 28, 64, 130, 1, 2), (2, 13, 17, 32, 48, 1, 4),
+    (4, 60, 80, 32, 64, 1, 1)])
+def test_conv3x3_implicit_gemm_h2(lib, b, h, w, cin, cout, stride, rate):
+  """Dense 3x3 conv as an implicit GEMM through the h2 kernel (taps gathered by the
+  LDS-DMA, zero block outside the image) vs the oracle's conv2d_same."""
+  from epos_amd import _lib
+  from oracle import net_ref
+  rng = np.random.RandomState(b * h + cin)
+  x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+  wgt = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+  bias = rng.standard_normal(cout).astype(np.float32)
+  xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+  if stride == 1:
+    ref = net_ref.conv2d_raw(xt, wgt, 1, rate, 'SAME')
+  else:
+    ref = net_ref.conv2d_raw(net_ref.fixed_padding(xt, 3, rate), wgt, stride, rate, 'VALID')
+  ref = np.maximum(ref.permute(0, 2, 3, 1).numpy() + bias, 0)
+  ho, wo = ref.shape[1], ref.shape[2]
+  X = torch.from_numpy(x).cuda()
+  wkn = wgt.reshape(9 * cin, cout)
+  Wp, Wh = _pack(lib, wkn), _pack(lib, wkn, 'h2')
+  npad = (cout + 127) // 128 * 128
+  bpad = np.zeros(npad, np.float32); bpad[:cout] = bias
+  Bd = torch.from_numpy(bpad).cuda()
+  Y = torch.full((b, ho, wo, cout), -3.0, device='cuda')
+  xs, ys = _slot(), _slot()
+  _lib.check(lib.epos_absmax_f32(_p(X), cin, b * h * w, cin, _p(xs), None))
+  args = _lib.Conv3x3Args(X=_p(X), ldx=cin, Wp=_p(Wp), bias=_p(Bd), Y=_p(Y), ldy=cout,
+                          B=b, H=h, W=w, Cin=cin, Cout=cout, stride=stride, rate=rate,
+                          relu=1, Wh=_p(Wh), x_amax=_p(xs),
+                          y_amax=_p(ys) if cout % 4 == 0 else None)
+  _lib.check(lib.epos_conv3x3_f32(ctypes.byref(args), None))
+  torch.cuda.synchronize()
+  got = Y.cpu().numpy()
+  np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
+  if cout % 4 == 0:
+    assert _slot_value(ys) == np.abs(got).max()
+
+
+def test_h2_adversarial_operands(lib):
+  """The fp32-equivalence claim outside the comfortable range, with the bounds of
+  test_split_gemm_adversarial_operands (relative to sum_k |a_k||w_k|, eps = 2^-24) wherever
+  fp16 pairs can hold the operands, and PROVABLE routing to the bf16 x 6 kernel where they
+  cannot (the packer refuses the weights)."""
+  rng = np.random.RandomState(0)
+  m, k, n = 256, 512, 128
+  rms = {}
+
+  def rel_err(a, w):
+    ref = a.astype(np.float64) @ w.astype(np.float64)
+    scale = np.abs(a).astype(np.float64) @ np.abs(w).astype(np.float64)
+    out = {}
+    for kind in ('h2', 'fp32'):
+      c = _gemm(lib, a, w, kind).astype(np.float64)
+      with np.errstate(invalid='ignore', divide='ignore'):
+        r = np.abs(c - ref) / np.maximum(scale, 1e-300)
+      out[kind] = np.nanmax(r)
+      rms[kind] = float(np.sqrt(np.nanmean(r * r)))
+    return out
+
+  # 1. alternating-sign cancellation: the exact result is tiny against the terms
+  v = rng.uniform(1, 2, (m, k)).astype(np.float32)
+  a = v * np.where(np.arange(k) % 2 == 0, 1.0, -1.0).astype(np.float32)
+  a[:, 1::2] = -a[:, 0::2] * (1 + rng.uniform(-1e-6, 1e-6, (m, k // 2)).astype(np.float32))
+  w = np.ones((k, n), np.float32) * rng.uniform(0.5, 1.5, (1, n)).astype(np.float32)
+  e = rel_err(a, w)
+  assert e['h2'] <= 2 * EPS and e['h2'] <= e['fp32'] * 1.01 + EPS / 8, e
+  # 2. magnitudes spread over 2^-60 .. 2^60 in BOTH operands: fp16 pairs cannot hold such a
+  #    weight column -> the packer refuses, the layer runs on the bf16 x 6 kernel (whose
+  #    bound on this case is asserted in test_gpu_layers.py)
+  w2 = (rng.uniform(1, 2, (k, n)) * 2.0 ** rng.randint(-60, 61, (k, n)) *
+        rng.choice([-1, 1], (k, n))).astype(np.float32)
+  assert _pack(lib, w2, 'h2') is None
+  # 2b. the same spread in A ONLY (per-tensor scale: elements more than ~2^27 below the
+  #     tensor's maximum lose relative precision, their ABSOLUTE error stays below
+  #     2^-50 x max|A| x |w|): with weights of one magnitude sum|a||w| is dominated by the
+  #     large elements and the bound of the fp32 class holds
+  a = (rng.uniform(1, 2, (m, k)) * 2.0 ** rng.randint(-60, 61, (m, k)) *
+       rng.choice([-1, 1], (m, k))).astype(np.float32)
+  w = (rng.uniform(1, 2, (k, n)) * rng.choice([-1, 1], (k, n))).astype(np.float32)
+  e = rel_err(a, w)
+  assert e['h2'] <= 16 * EPS and rms['h2'] <= 1.25 * rms['fp32'] + EPS / 8, (e, rms)
+  # 2c. weights spread over the window the packer accepts (2^20 here) and activations
+  #     spread over 2^20: every element is inside both windows
+  a = (rng.uniform(1, 2, (m, k)) * 2.0 ** rng.randint(-10, 11, (m, k)) *
+       rng.choice([-1, 1], (m, k))).astype(np.float32)
+  w = (rng.uniform(1, 2, (k, n)) * 2.0 ** rng.randint(-10, 11, (k, n)) *
+       rng.choice([-1, 1], (k, n))).astype(np.float32)
+  e = rel_err(a, w)
+  assert e['h2'] <= 16 * EPS and rms['h2'] <= 1.25 * rms['fp32'] + EPS / 8, (e, rms)
+  # 3. tiny magnitudes (|x| ~ 2^-118 .. 2^-108): the scale 2^+122 is a normal fp32 number,
+  #    the inverse scales are applied one after the other in the epilogue
+  a = (rng.uniform(1, 2, (m, k)) * 2.0 ** rng.randint(-118, -107, (m, k))).astype(np.float32)
+  w = rng.uniform(1, 2, (k, n)).astype(np.float32)
+  e = rel_err(a, w)
+  assert e['h2'] <= 32 * EPS and rms['h2'] <= 1.25 * rms['fp32'] + EPS / 8, (e, rms)
+  #    and huge ones (2^100 .. 2^110)
+  a = (rng.uniform(1, 2, (m, k)) * 2.0 ** rng.randint(100, 111, (m, k))).astype(np.float32)
+  w = rng.uniform(2.0 ** -8, 2.0 ** -7, (k, n)).astype(np.float32)
+  e = rel_err(a, w)
+  assert e['h2'] <= 32 * EPS and rms['h2'] <= 1.25 * rms['fp32'] + EPS / 8, (e, rms)
+  # 4. non-finite operands stay non-finite, finite rows are untouched (the bound is Inf /
+  #    ignores NaN: scale 1 resp. the finite maximum)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = rng.standard_normal((k, n)).astype(np.float32)
+  a[3, 17] = np.inf
+  a[5, 100] = np.nan
+  c = _gemm(lib, a, w, 'h2').astype(np.float64)
+  assert not np.isfinite(c[3]).any() and np.isnan(c[5]).all()
+  ok = np.ones(m, bool); ok[[3, 5]] = False
+  ref = a[ok].astype(np.float64) @ w.astype(np.float64)
+  assert np.abs(c[ok] - ref).max() <= 8 * EPS * (np.abs(a[ok]).astype(np.float64) @ np.abs(w)).max()
+  # 5. an all-zero A and a zero column of W
+  a = np.zeros((m, k), np.float32)
+  w = rng.standard_normal((k, n)).astype(np.float32); w[:, 5] = 0
+  assert (_gemm(lib, a, w, 'h2') == 0).all()
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  c = _gemm(lib, a, w, 'h2')
+  assert (c[:, 5] == 0).all() and np.abs(c).max() > 1
+
+
+def test_h2_fp16_denormal_pieces_are_not_flushed(lib):
+  """Elements 2^-30 of the tensor's maximum: their scaled value 2^-16 is an fp16 DENORMAL
+  (8 significant bits in hi, the rest in a barely normal mid): the representation is good
+  to ~2^-20 relative. If the matrix pipe flushed fp16 denormals these elements would vanish
+  altogether (error of order 1)."""
+  rng = np.random.RandomState(9)
+  m, k, n = 256, 256, 128
+  a = (rng.uniform(1, 2, (m, k)) * 2.0 ** -30).astype(np.float32)
+  a[:, 0] = 1.0                         # the maximum that fixes the scale
+  w = rng.uniform(1, 2, (k, n)).astype(np.float32)
+  w[0] = 0                              # ... and contributes nothing
+  ref = a.astype(np.float64) @ w.astype(np.float64)
+  c = _gemm(lib, a, w, 'h2').astype(np.float64)
+  assert np.abs(c - ref).max() <= 2.0 ** -18 * np.abs(ref).max()

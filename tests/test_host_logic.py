@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
   assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
   for name in declared:
     assert hasattr(lib, name), name
-  assert lib.epos_abi_version() == 4
+  assert lib.epos_abi_version() == 5
 
 
 def test_pack_pointwise_weights_host():
@@ -144,3 +144,80 @@ def test_two_rank_gloo_gather(tmp_path):
        '29617', str(script)], env=env, capture_output=True, text=True,
       timeout=300)
   assert 'GATHER_OK' in out.stdout, out.stdout + out.stderr
+
+
+def _pack_h2_host(lib, w):
+  import ctypes
+  k, n = w.shape
+  w = np.ascontiguousarray(w, np.float32)
+  total = lib.epos_pack_pointwise_weights_h2(w.ctypes.data_as(ctypes.c_void_p), k, n, None)
+  if total <= 0:
+    return None
+  dst = np.empty(total, np.uint8)
+  assert lib.epos_pack_pointwise_weights_h2(w.ctypes.data_as(ctypes.c_void_p), k, n,
+                                            dst.ctypes.data_as(ctypes.c_void_p)) == total
+  return dst
+
+
+def test_pack_pointwise_weights_h2_host():
+  """The fp16-pair packer against numpy's float16 (IEEE round-to-nearest-even, the
+  rounding of v_cvt_pk_f16_f32): column scales put the column maximum into [2^14, 2^15),
+  hi = f16(t), mid = f16((t - hi) * 2^11), fragment order of v_mfma_f32_32x32x16_f16, the
+  inverse scales behind the pieces; hi + mid/2^11 reproduces every weight to 2^-22."""
+  from epos_amd import _lib
+  lib = _lib.load()
+  rng = np.random.RandomState(3)
+  k, n = 40, 150                       # ragged: K pads to 48, N to 256
+  w = (rng.standard_normal((k, n)) * 10.0 ** rng.uniform(-3, 3, (1, n))).astype(np.float32)
+  w[:, 7] = 0                          # an all-zero column
+  w[3, 9] = 0
+  blob = _pack_h2_host(lib, w)
+  tiles_n, nks = 2, 3
+  wbytes = tiles_n * nks * 8192
+  assert blob.size == wbytes + 256 * 4
+  pieces = blob[:wbytes].view(np.float16).reshape(tiles_n, nks, 4, 2, 64, 8)
+  inv = blob[wbytes:].view(np.float32)
+  cmax = np.abs(w).max(0)
+  for col in range(n):
+    if cmax[col] == 0:
+      assert inv[col] == 1.0
+      continue
+    s = np.float32(1.0) / inv[col]
+    assert np.log2(s) == np.round(np.log2(s)) and 2.0 ** 14 <= cmax[col] * s < 2.0 ** 15
+  assert (inv[n:] == 1.0).all()
+  for kk in range(48):
+    for col in range(256):
+      tn, cbw, l31 = col // 128, (col % 128) // 32, col % 32
+      ks, hh, j = kk // 16, (kk % 16) // 8, kk % 8
+      got_hi = pieces[tn, ks, cbw, 0, hh * 32 + l31, j]
+      got_mid = pieces[tn, ks, cbw, 1, hh * 32 + l31, j]
+      if kk >= k or col >= n:
+        assert got_hi == 0 and got_mid == 0
+        continue
+      t = np.float32(w[kk, col] * (np.float32(1.0) / inv[col]))
+      hi = np.float16(t)
+      mid = np.float16(np.float32((t - np.float32(hi)) * np.float32(2048.0)))
+      assert got_hi == hi and got_mid == mid, (kk, col)
+      rec = np.float64(hi) + np.float64(mid) / 2048.0
+      assert abs(rec - np.float64(t)) <= abs(np.float64(t)) * 2.0 ** -22
+
+
+def test_pack_h2_refuses_what_fp16_pairs_cannot_hold():
+  """A weight far below its column's maximum (outside the ~2^27 window), non-finite
+  weights and columns whose scale leaves the exponent range: the packer returns 0 and the
+  layer keeps the bf16 x 6 kernel (provable routing, not a silent loss of precision)."""
+  from epos_amd import _lib
+  lib = _lib.load()
+  rng = np.random.RandomState(4)
+  w = rng.standard_normal((64, 32)).astype(np.float32)
+  assert _pack_h2_host(lib, w) is not None
+  bad = w.copy(); bad[5, 3] = np.float32(1e-12) * np.abs(w[:, 3]).max()
+  assert _pack_h2_host(lib, bad) is None
+  ok = w.copy(); ok[5, 3] = np.float32(2.0 ** -20) * np.abs(w[:, 3]).max()
+  assert _pack_h2_host(lib, ok) is not None
+  for v in (np.inf, np.nan):
+    bad = w.copy(); bad[0, 0] = v
+    assert _pack_h2_host(lib, bad) is None
+  assert _pack_h2_host(lib, (w * np.float32(2.0 ** -120)).astype(np.float32)) is None
+  spread = (rng.uniform(1, 2, (64, 32)) * 2.0 ** rng.randint(-60, 61, (64, 32))).astype(np.float32)
+  assert _pack_h2_host(lib, spread) is None

@@ -60,16 +60,19 @@ class EposNet(object):
   def __init__(self, checkpoint, batch, height, width, num_objs, num_frags=64,
                model_variant='xception_65', encoder_output_stride=8,
                decoder_output_stride=4, atrous_rates=(12, 24, 36),
-               multi_grid=None, device='cuda:0'):
+               multi_grid=None, device='cuda:0', dry_run=False):
     if model_variant not in ('xception_65', 'resnet_v1_101_beta'):
       raise ValueError('Unsupported model variant: %s' % model_variant)
     self.model_variant = model_variant
     if encoder_output_stride != 8 or decoder_output_stride != 4:
       raise ValueError('Only encoder OS 8 / decoder OS 4 (common.py:127-135).')
-    if not torch.cuda.is_available():
+    # dry_run: build the plan's STRUCTURE only (tests/test_graph_trace.py) -- buffers are
+    # shape-only 'meta' tensors, no weight is packed, nothing can be launched.
+    self.dry_run = bool(dry_run)
+    if not self.dry_run and not torch.cuda.is_available():
       raise _lib.EposError('EposNet needs a HIP device (no CPU fallback).')
-    self.lib = _lib.load()
-    self.dev = torch.device(device)
+    self.lib = None if self.dry_run else _lib.load()
+    self.dev = torch.device('meta' if self.dry_run else device)
     self.B, self.H, self.W = batch, height, width
     self.num_objs, self.num_frags = num_objs, num_frags
     self.atrous_rates = tuple(atrous_rates)
@@ -85,8 +88,9 @@ class EposNet(object):
     self._graph_sparse = None
     # Workspace of the persistent stream-K GEMM (partial-sum slabs + flags); one
     # per plan, because launches sharing it must be ordered on one stream.
-    self._gemm_ws = torch.zeros(int(self.lib.epos_pointwise_workspace_bytes()),
-                                dtype=torch.uint8, device=self.dev)
+    self._gemm_ws = torch.zeros(
+        0 if self.dry_run else int(self.lib.epos_pointwise_workspace_bytes()),
+        dtype=torch.uint8, device=self.dev)
     # Fused separable convs (depthwise as a producer phase of the pointwise GEMM's
     # workgroups, epos_separable_conv_f32) for every stride-1 sep-conv whose GEMM is a
     # launch of its own: OPT-IN (EPOS_SEPCONV_FUSED=1). Same bits either way, but
@@ -108,6 +112,14 @@ class EposNet(object):
     self._n_slots = 0
     self._bounds = {}
     self.h2_layers, self.h2_refused = [], []
+    # Structure trace: one record per parametrised layer and a canonical expression per
+    # buffer (channel slices of concat buffers separately), in the grammar of
+    # tests/golden/tf_recorder.py -- what each launch computes, written down from the very
+    # arguments the launch is built from. tests/test_graph_trace.py holds it against the
+    # graph the reference's own code builds (tests/golden/graph_*.json).
+    self.trace_layers, self.trace_outputs = [], {}
+    self._exprs = {}
+    self._last_bn = (None, None)
     self._build_plan()
 
   # ------------------------------------------------------------ buffers ---
@@ -120,6 +132,38 @@ class EposNet(object):
     t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
     self._keep.append(t)
     return t
+
+  # ---------------------------------------------------- structure trace ---
+  def _set_expr(self, buf, expr, off=0, width=None):
+    width = buf.shape[-1] if width is None else width
+    ent = [e for e in self._exprs.get(id(buf), []) if e[0] != off]
+    ent.append((off, width, expr))
+    self._exprs[id(buf)] = sorted(ent)
+
+  def _expr_of(self, buf, off=0, width=None):
+    width = buf.shape[-1] if width is None else width
+    ent = self._exprs[id(buf)]
+    for o, w, e in ent:
+      if o == off and w == width:
+        return e
+    parts, at = [], off
+    for o, w, e in ent:                   # a read across the slices of a concat buffer
+      if o == at and at < off + width:
+        parts.append(e)
+        at += w
+    assert at == off + width and parts, ('no expression for the slice', off, width, ent)
+    return 'concat(%s)' % ','.join(parts)
+
+  @staticmethod
+  def _relu_expr(e):
+    return e if e.startswith('relu(') else 'relu(%s)' % e
+
+  def _trace_layer(self, scope, op, kernel, stride, rate, padding, cin, cout, bn_eps,
+                   bias, expr_in, out_hw):
+    self.trace_layers.append({
+        'scope': scope, 'op': op, 'kernel': [kernel, kernel], 'stride': stride,
+        'rate': rate, 'padding': padding, 'cin': cin, 'cout': cout, 'bn_eps': bn_eps,
+        'bias': bias, 'input': expr_in, 'out_hw': [int(out_hw[0]), int(out_hw[1])]})
 
   # ------------------------------------------------------- absmax slots ---
   def _new_slot(self):
@@ -134,10 +178,10 @@ class EposNet(object):
 
   def _bound_of(self, buf):
     """(slot, slot2, gain, bias) of a buffer, or None when nobody tracks it."""
-    return self._bounds.get(buf.data_ptr())
+    return self._bounds.get(id(buf))
 
   def _set_bound(self, buf, slot, slot2=None, gain=0.0, bias=0.0):
-    self._bounds[buf.data_ptr()] = (slot, slot2, float(gain), float(bias))
+    self._bounds[id(buf)] = (slot, slot2, float(gain), float(bias))
 
   def _out_slot(self, buf, n, ldc, off=0):
     """Slot that a GEMM writing `buf` publishes max|out| into, or None when its epilogue
@@ -155,6 +199,8 @@ class EposNet(object):
   def _pack_pointwise(self, w_kn, scale, bias):
     """w_kn [K, N] (TF HWIO with H=W=1), BN scale folded, packed for the GEMM."""
     k, n = w_kn.shape
+    if self.dry_run:
+      return self._empty(1), self._empty(1), (k + 3) // 4 * 4
     w = np.ascontiguousarray(w_kn.astype(np.float32) * scale[None, :].astype(
         np.float32))
     kpad = (k + 3) // 4 * 4
@@ -173,6 +219,8 @@ class EposNet(object):
   def _pack_split(self, w_kn, scale):
     """The same folded weights in the split-operand GEMM's layout (three exact bf16
     pieces per weight, MFMA fragment order): epos_pack_pointwise_weights_split."""
+    if self.dry_run:
+      return self._empty(1)
     k, n = w_kn.shape
     w = np.ascontiguousarray(w_kn.astype(np.float32) * scale[None, :].astype(
         np.float32))
@@ -191,6 +239,8 @@ class EposNet(object):
     (epos_pack_pointwise_weights_h2), or None when the matrix is refused there (a weight
     outside the window fp16 pairs represent to 2^-22): the layer then stays on the
     bf16 x 6 kernel."""
+    if self.dry_run:
+      return self._empty(1)
     k, n = w_kn.shape
     w = np.ascontiguousarray(w_kn.astype(np.float32) * scale[None, :].astype(
         np.float32))
@@ -212,6 +262,7 @@ class EposNet(object):
     w = self.ckpt[scope + '/weights']
     kh, kw, cin, cout = w.shape
     scale, bias = W.fold_bn(self.ckpt, scope, eps, 'conv')
+    self._last_bn = (scope, eps)
     return w.reshape(kh * kw * cin, cout), scale, bias
 
   def _dw_params(self, scope, eps):
@@ -221,6 +272,7 @@ class EposNet(object):
     # |depthwise output| <= gain * max|input| + bias0 (the consumer GEMM's A bound)
     self._dw_gain = float(np.abs(w9c.astype(np.float64)).sum(0).max())
     self._dw_bias0 = float(np.abs(np.asarray(bias, np.float64)).max())
+    self._last_bn = (scope, eps)
     return self._dev(w9c), self._dev(bias)
 
   # --------------------------------------------------------------- ops ---
@@ -233,7 +285,8 @@ class EposNet(object):
 
   def _pointwise(self, name, a, a_off, lda, m, k, w_kn, scale, bias, c, c_off,
                  ldc, relu, relu_in=False, res=None, res_off=0, ldr=0, sub=1,
-                 ho=0, wo=0, hi=0, wi=0, group=None, dw=None, track_out=True):
+                 ho=0, wo=0, hi=0, wi=0, group=None, dw=None, track_out=True,
+                 trace=True):
     """One 1x1 conv. With ``group`` (a list) the problem is only appended to it;
     ``_flush_group`` later launches the whole list as ONE grouped GEMM. With ``dw``
     (the deferred depthwise of ``_depthwise(defer=True)`` whose output is ``a``) the
@@ -243,6 +296,20 @@ class EposNet(object):
     ws = None if relu_in else self._pack_split(w_kn, scale)
     n = w_kn.shape[1]
     assert kpad == k or (kpad > k and lda >= kpad), (name, k, kpad, lda)
+    # ---- structure trace: what this launch computes, from its own arguments. A stem conv
+    # that runs as im2col + GEMM is recorded by _stem_conv (it passes trace=False).
+    if trace:
+      ein = self._expr_of(a, a_off, k)
+      if relu_in:
+        ein = self._relu_expr(ein)
+      bn_eps = self._last_bn[1] if self._last_bn[0] == name else None
+      hw = (ho, wo) if sub > 1 else (c.shape[1:3] if c.dim() == 4 else (1, 1))
+      self._trace_layer(name, 'conv2d', 1, sub, 1, 'SAME', k, n, bn_eps, bn_eps is None,
+                        ein, hw)
+      eout = 'L:' + name
+      if res is not None:
+        eout = 'add(%s)' % ','.join(sorted([eout, self._expr_of(res, res_off, n)]))
+      self._set_expr(c, self._relu_expr(eout) if relu else eout, c_off, n)
     # fp16-pair weights when the A operand has a bound; the output's slot
     ab = self._bound_of(a)
     wh = None
@@ -325,6 +392,14 @@ class EposNet(object):
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     w9c, bias = self._dw_params(scope, eps)
     y = self._empty(self.B, ho, wo, c)
+    ein = self._expr_of(x, 0, c)
+    if relu_in:
+      ein = self._relu_expr(ein)
+    if stride > 1:                # fixed_padding (net_xception.py:74-93) + VALID
+      ein = 'pad(%s,%d,%d)' % (ein, rate, rate)
+    self._trace_layer(name, 'depthwise_conv2d', 3, stride, rate,
+                      'SAME' if stride == 1 else 'VALID', c, c, eps, False, ein, (ho, wo))
+    self._set_expr(y, self._relu_expr('L:' + name) if relu_out else 'L:' + name)
     xb = self._bound_of(x)
     if xb is not None:
       g, b0 = self._dw_gain, self._dw_bias0
@@ -353,6 +428,15 @@ class EposNet(object):
     ho = hi if stride == 1 else (hi - 1) // 2 + 1
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     k = 9 * cin
+    ein = self._expr_of(x, 0, cin)
+    if preprocess:                # fused into the im2col (feature.py:171-174)
+      assert ein == 'input'
+      ein = 'preprocess(input)'
+    if stride > 1:                # conv2d_same: explicit padding + VALID
+      ein = 'pad(%s,%d,%d)' % (ein, rate, rate)
+    cout_t = self.ckpt[scope + '/weights'].shape[3]
+    self._trace_layer(name, 'conv2d', 3, stride, rate, 'SAME' if stride == 1 else 'VALID',
+                      cin, cout_t, eps, False, ein, (ho, wo))
     if cin % 32 == 0 and not preprocess:
       # implicit GEMM: the LDS-DMA kernel gathers the shifted input pixels itself
       w_kn, scale, bias = self._conv_params(scope, eps)
@@ -378,6 +462,7 @@ class EposNet(object):
         _lib.check(lib.epos_conv3x3_f32(ctypes.byref(cargs), stream), name)
       self._add(name, run_conv, 2 * self.B * ho * wo * cout * k, 'gemm',
                 4 * (self.B * hi * wi * cin + k * cout + self.B * ho * wo * cout))
+      self._set_expr(y, 'relu(L:%s)' % name)
       return y, ho, wo, cout
     ldcol = (k + 3) // 4 * 4
     m = self.B * ho * wo
@@ -395,7 +480,8 @@ class EposNet(object):
     cout = w_kn.shape[1]
     y = self._empty(self.B, ho, wo, cout)
     self._pointwise(name, col, 0, ldcol, m, k, w_kn, scale, bias, y, 0, cout,
-                    relu=True)
+                    relu=True, trace=False)
+    self._set_expr(y, 'relu(L:%s)' % name)
     return y, ho, wo, cout
 
   # ------------------------------------------------ ResNet-v1-101-beta (C5) ---
@@ -422,6 +508,7 @@ class EposNet(object):
           _lib.check(lib.epos_subsample_f32(_ptr(x), cin, _ptr(y), depth, B, hi,
                                             wi, cin, stride, stream), 'subsample')
         self._add(scope + '/shortcut_subsample', run_sub)
+        self._set_expr(shortcut, 'subsample(%s,%d)' % (self._expr_of(x, 0, cin), stride))
         if self._bound_of(x) is not None:
           self._set_bound(shortcut, *self._bound_of(x))
     else:
@@ -449,6 +536,8 @@ class EposNet(object):
         _lib.check(lib.epos_add_relu_f32(_ptr(a), _ptr(b), _ptr(y),
                                          m_out * depth, stream), 'add_relu')
       self._add(scope + '/add_relu', run_add)
+      self._set_expr(out, 'relu(add(%s))' % ','.join(sorted(
+          [self._expr_of(conv3), self._expr_of(shortcut)])))
       oslot = self._new_slot()
       self._set_bound(out, oslot)
 
@@ -477,6 +566,7 @@ class EposNet(object):
       _lib.check(lib.epos_maxpool3x3_s2_f32(_ptr(x), c, _ptr(y), c, B, h, w, c,
                                             stream), 'maxpool')
     self._add(net + '/pool1', run_pool)                      # :190
+    self._set_expr(pooled, 'maxpool(%s,3,2,SAME)' % self._expr_of(x, 0, c))
     if self._bound_of(x) is not None:          # a max-pool output is bounded by its input
       self._set_bound(pooled, *self._bound_of(x))
     x, h, w = pooled, ph, pw
@@ -595,6 +685,7 @@ class EposNet(object):
   def _build_plan(self):
     B, H, Wd = self.B, self.H, self.W
     self.images = self._empty(B, H, Wd, 3)
+    self._set_expr(self.images, 'input')
     lib0 = self.lib
 
     def run_clear(stream):
@@ -620,6 +711,7 @@ class EposNet(object):
       _lib.check(lib.epos_global_avg_pool_f32(_ptr(x), ec, _ptr(pooled), B,
                                               eh * ew, ec, stream), 'avg_pool')
     self._add('image_pooling/mean', run_pool)
+    self._set_expr(pooled, 'mean(%s)' % self._expr_of(x, 0, ec))
     w_kn, sc, bi = self._conv_params('image_pooling', HEAD_BN_EPS)
     pool_feat = self._empty(B, 256)
     self._pointwise('image_pooling', pooled, 0, ec, B, ec, w_kn, sc, bi,
@@ -630,6 +722,7 @@ class EposNet(object):
           _ptr(pool_feat), 256, _ptr(cat), ldcat, B, 1, 1, eh, ew, 256, stream),
                  'image_pooling/resize')
     self._add('image_pooling/resize', run_bcast)
+    self._set_expr(cat, 'resize(%s,%dx%d)' % (self._expr_of(pool_feat), eh, ew), 0, 256)
     # The four spatial ASPP branches (N = 256 each) share ONE grouped GEMM launch.
     grp = []
     w_kn, sc, bi = self._conv_params('aspp0', HEAD_BN_EPS)
@@ -670,6 +763,8 @@ class EposNet(object):
           _ptr(proj), 256, _ptr(dcat), 304, B, eh, ew, dh, dw_, 256, stream),
                  'decoder/resize')
     self._add('decoder/resize', run_up)
+    self._set_expr(dcat, self._expr_of(proj) if (eh, ew) == (dh, dw_) else
+                   'resize(%s,%dx%d)' % (self._expr_of(proj), dh, dw_), 0, 256)
     m_dec = B * dh * dw_
     w_kn, sc, bi = self._conv_params('decoder/feature_projection0', HEAD_BN_EPS)
     self._pointwise('decoder/feature_projection0', ll, 0, lc, m_dec, lc, w_kn,
@@ -680,7 +775,7 @@ class EposNet(object):
     if pb is not None and fb is not None:
       self._set_bound(dcat, fb[0], pb[0])
     else:
-      self._bounds.pop(dcat.data_ptr(), None)
+      self._bounds.pop(id(dcat), None)
     self.decoder_concat = dcat
     x, c = dcat, 304
     for j in range(2):
@@ -747,6 +842,17 @@ class EposNet(object):
     self.post_ops = [('softmax_obj', run_softmax_obj),
                      ('softmax_frag', run_softmax_frag),
                      ('argmax', run_argmax)]
+    # model.py:117-147 (reshape), :677-683 (softmax over the last axis, argmax)
+    eo = self._expr_of(self.logits[W.PRED_OBJ_CONF])
+    ef = self._expr_of(self.logits[W.PRED_FRAG_CONF])
+    el = self._expr_of(self.logits[W.PRED_FRAG_LOC])
+    self.trace_outputs = {
+        W.PRED_OBJ_CONF: {'expr': 'softmax(%s)' % eo, 'shape': [B, dh, dw_, O + 1]},
+        W.PRED_OBJ_LABEL: {'expr': 'argmax(softmax(%s))' % eo, 'shape': [B, dh, dw_]},
+        W.PRED_FRAG_CONF: {'expr': 'softmax(reshape(%s,%s))' % (ef, [O, F]),
+                           'shape': [B, dh, dw_, O, F]},
+        W.PRED_FRAG_LOC: {'expr': 'reshape(%s,%s)' % (el, [O, F, 3]),
+                          'shape': [B, dh, dw_, O, F, 3]}}
 
   # ----------------------------------------------------------- running ---
   def _stream(self):

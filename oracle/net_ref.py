@@ -50,8 +50,92 @@ class precision(object):
     DTYPE = self.prev
 
 
+# torch device of the restatement: None = CPU. 'meta' (shapes only, nothing computed) is
+# what the structure trace runs on at the full BASELINE sizes.
+DEVICE = None
+
+
 def _t(a):
-  return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DTYPE)
+  t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DTYPE)
+  return t.to(DEVICE) if DEVICE else t
+
+
+# ----------------------------------------------------------------------------
+# Structure trace (tests/test_graph_trace.py): while a `trace()` block is active every
+# parametrised layer appends a record and every tensor carries a canonical expression over
+# layer outputs -- the grammar of tests/golden/tf_recorder.py, whose fixtures
+# (tests/golden/graph_*.json) are what the REFERENCE's own graph-building code produces. The
+# arithmetic is not touched: tracing only tags tensors.
+# ----------------------------------------------------------------------------
+TRACE = None
+_EXPR, _ALIVE = {}, []
+
+
+class trace(object):
+  """with net_ref.trace() as tr: net_ref.predict(...); tr.layers / tr.outputs"""
+
+  def __enter__(self):
+    global TRACE
+    self.layers, self.outputs = [], {}
+    TRACE = self
+    _EXPR.clear()
+    del _ALIVE[:]
+    return self
+
+  def __exit__(self, *exc):
+    global TRACE
+    TRACE = None
+    _EXPR.clear()
+    del _ALIVE[:]
+
+
+def _tag(t, expr):
+  if TRACE is not None:
+    _EXPR[id(t)] = expr
+    _ALIVE.append(t)           # ids must stay unique while the trace lives
+  return t
+
+
+def _e(t):
+  return _EXPR[id(t)]
+
+
+def _record(kind, x, y, w, stride, rate, padding, scope):
+  if TRACE is None or scope is None:
+    return y
+  kh, kw = int(w.shape[0]), int(w.shape[1])
+  cin = int(x.shape[1])
+  cout = cin if kind == 'depthwise_conv2d' else int(w.shape[3])
+  TRACE.layers.append({
+      'scope': scope, 'op': kind, 'kernel': [kh, kw], 'stride': stride, 'rate': rate,
+      'padding': padding, 'cin': cin, 'cout': cout, 'bn_eps': None, 'bias': False,
+      'input': _e(x), 'out_hw': [int(y.shape[2]), int(y.shape[3])]})
+  return _tag(y, 'L:' + scope)
+
+
+def relu(x):
+  y = F.relu(x)
+  if TRACE is not None:
+    e = _e(x)
+    _tag(y, e if e.startswith('relu(') else 'relu(%s)' % e)
+  return y
+
+
+_relu = relu     # for functions with a parameter called `relu`
+
+
+def add(a, b):
+  y = a + b
+  if TRACE is not None:
+    _tag(y, 'add(%s)' % ','.join(sorted([_e(a), _e(b)])))
+  return y
+
+
+def concat(ts):
+  y = torch.cat(ts, dim=1)
+  if TRACE is not None:
+    _tag(y, 'concat(%s)' % ','.join(_e(t) for t in ts))
+  return y
 
 
 # ----------------------------------------------------------------------------
@@ -64,7 +148,10 @@ def fixed_padding(x, kernel_size, rate=1):
   pad_total = k_eff - 1
   pad_beg = pad_total // 2
   pad_end = pad_total - pad_beg
-  return F.pad(x, (pad_beg, pad_end, pad_beg, pad_end))
+  y = F.pad(x, (pad_beg, pad_end, pad_beg, pad_end))
+  if TRACE is not None:
+    _tag(y, 'pad(%s,%d,%d)' % (_e(x), pad_beg, pad_end))
+  return y
 
 
 def _tf_same_pad(x, k, stride, rate):
@@ -79,40 +166,44 @@ def _tf_same_pad(x, k, stride, rate):
   return F.pad(x, tuple(pads))
 
 
-def conv2d_raw(x, w_hwio, stride=1, rate=1, padding='SAME'):
-  """slim.conv2d without normalizer/activation. x NCHW, w HWIO."""
+def conv2d_raw(x, w_hwio, stride=1, rate=1, padding='SAME', scope=None):
+  """slim.conv2d without normalizer/activation. x NCHW, w HWIO. `scope` (the layer's
+  variable scope) is only used by the structure trace."""
   w = _t(w_hwio).permute(3, 2, 0, 1).contiguous()
   k = w.shape[2]
-  if padding == 'SAME':
-    x = _tf_same_pad(x, k, stride, rate)
-  return F.conv2d(x, w, stride=stride, dilation=rate)
+  xp = _tf_same_pad(x, k, stride, rate) if padding == 'SAME' else x
+  y = F.conv2d(xp, w, stride=stride, dilation=rate)
+  return _record('conv2d', x, y, w_hwio, stride, rate, padding, scope)
 
 
-def depthwise_raw(x, w_hwc1, stride=1, rate=1, padding='SAME'):
+def depthwise_raw(x, w_hwc1, stride=1, rate=1, padding='SAME', scope=None):
   """Depthwise part of slim.separable_conv2d(num_outputs=None, depth_multiplier=1).
   Weights [kh, kw, C, 1]."""
   c = x.shape[1]
   w = _t(w_hwc1).permute(2, 3, 0, 1).contiguous()  # [C,1,kh,kw]
   k = w.shape[2]
-  if padding == 'SAME':
-    x = _tf_same_pad(x, k, stride, rate)
-  return F.conv2d(x, w, stride=stride, dilation=rate, groups=c)
+  xp = _tf_same_pad(x, k, stride, rate) if padding == 'SAME' else x
+  y = F.conv2d(xp, w, stride=stride, dilation=rate, groups=c)
+  return _record('depthwise_conv2d', x, y, w_hwc1, stride, rate, padding, scope)
 
 
-def conv2d_same_raw(x, w_hwio, stride, rate=1):
+def conv2d_same_raw(x, w_hwio, stride, rate=1, scope=None):
   """external/slim/nets/resnet_utils.py:77-122 (conv2d_same) without BN: stride 1
   -> SAME; stride > 1 -> explicit fixed padding then VALID."""
   if stride == 1:
-    return conv2d_raw(x, w_hwio, 1, rate, 'SAME')
+    return conv2d_raw(x, w_hwio, 1, rate, 'SAME', scope)
   k = w_hwio.shape[0]
-  return conv2d_raw(fixed_padding(x, k, rate), w_hwio, stride, rate, 'VALID')
+  return conv2d_raw(fixed_padding(x, k, rate), w_hwio, stride, rate, 'VALID', scope)
 
 
 def subsample(x, factor):
   """external/slim/nets/resnet_utils.py:59-74: max_pool 1x1 stride factor."""
   if factor == 1:
     return x
-  return x[:, :, ::factor, ::factor]
+  y = x[:, :, ::factor, ::factor]
+  if TRACE is not None:
+    _tag(y, 'subsample(%s,%d)' % (_e(x), factor))
+  return y
 
 
 def batch_norm(x, wts, scope, eps):
@@ -121,13 +212,22 @@ def batch_norm(x, wts, scope, eps):
   b = _t(wts[scope + '/BatchNorm/beta'])
   m = _t(wts[scope + '/BatchNorm/moving_mean'])
   v = _t(wts[scope + '/BatchNorm/moving_variance'])
-  return F.batch_norm(x, m, v, g, b, training=False, eps=eps)
+  y = F.batch_norm(x, m, v, g, b, training=False, eps=eps)
+  if TRACE is not None:
+    rec = TRACE.layers[-1]
+    assert rec['scope'] == scope and _e(x) == 'L:' + scope, (rec['scope'], scope)
+    rec['bn_eps'] = eps
+    _tag(y, _e(x))
+  return y
 
 
 def resize_bilinear_align_corners(x, size_hw):
   """misc.py:94-107: tf.image.resize_bilinear(align_corners=True)."""
-  return F.interpolate(x, size=tuple(size_hw), mode='bilinear',
-                       align_corners=True)
+  y = F.interpolate(x, size=tuple(size_hw), mode='bilinear', align_corners=True)
+  if TRACE is not None:
+    same = (int(x.shape[2]), int(x.shape[3])) == tuple(int(v) for v in size_hw)
+    _tag(y, _e(x) if same else 'resize(%s,%dx%d)' % (_e(x), size_hw[0], size_hw[1]))
+  return y
 
 
 def scale_dimension(dim, scale):
@@ -141,8 +241,8 @@ def scale_dimension(dim, scale):
 def _conv_bn_relu_same(x, wts, scope, stride, eps):
   """resnet_utils.conv2d_same under the xception arg scope (conv + BN + ReLU),
   net_xception.py:460-463."""
-  y = conv2d_same_raw(x, wts[scope + '/weights'], stride)
-  return F.relu(batch_norm(y, wts, scope, eps))
+  y = conv2d_same_raw(x, wts[scope + '/weights'], stride, scope=scope)
+  return relu(batch_norm(y, wts, scope, eps))
 
 
 def separable_conv2d_same(x, wts, scope, stride, rate, act, eps):
@@ -150,16 +250,17 @@ def separable_conv2d_same(x, wts, scope, stride, rate, act, eps):
   then 1x1(+BN[+act]); stride on the depthwise only; stride>1 -> fixed_padding+VALID."""
   dw_w = wts[scope + '_depthwise/depthwise_weights']
   if stride == 1:
-    y = depthwise_raw(x, dw_w, 1, rate, 'SAME')
+    y = depthwise_raw(x, dw_w, 1, rate, 'SAME', scope + '_depthwise')
   else:
-    y = depthwise_raw(fixed_padding(x, 3, rate), dw_w, stride, rate, 'VALID')
+    y = depthwise_raw(fixed_padding(x, 3, rate), dw_w, stride, rate, 'VALID',
+                      scope + '_depthwise')
   y = batch_norm(y, wts, scope + '_depthwise', eps)
   if act:
-    y = F.relu(y)
-  y = conv2d_raw(y, wts[scope + '_pointwise/weights'], 1, 1, 'SAME')
+    y = relu(y)
+  y = conv2d_raw(y, wts[scope + '_pointwise/weights'], 1, 1, 'SAME', scope + '_pointwise')
   y = batch_norm(y, wts, scope + '_pointwise', eps)
   if act:
-    y = F.relu(y)
+    y = relu(y)
   return y
 
 
@@ -169,7 +270,7 @@ def xception_module(x, wts, scope, depth_list, skip, act_in_sep, stride, rate,
   residual = x
   for i in range(3):
     if not act_in_sep:
-      residual = F.relu(residual)          # :272-276, ReLU before the sep-conv
+      residual = relu(residual)            # :272-276, ReLU before the sep-conv
     residual = separable_conv2d_same(
         residual, wts, '%s/separable_conv%d' % (scope, i + 1),
         stride=stride if i == 2 else 1, rate=rate * unit_rate_list[i],
@@ -177,11 +278,11 @@ def xception_module(x, wts, scope, depth_list, skip, act_in_sep, stride, rate,
     end_points['%s/separable_conv%d_pointwise' % (scope, i + 1)] = residual
   if skip == 'conv':
     sc = scope + '/shortcut'
-    shortcut = conv2d_raw(x, wts[sc + '/weights'], stride, 1, 'SAME')  # :296-302
+    shortcut = conv2d_raw(x, wts[sc + '/weights'], stride, 1, 'SAME', sc)  # :296-302
     shortcut = batch_norm(shortcut, wts, sc, eps)
-    out = residual + shortcut
+    out = add(residual, shortcut)
   elif skip == 'sum':
-    out = residual + x
+    out = add(residual, x)
   elif skip == 'none':
     out = residual
   else:
@@ -254,8 +355,10 @@ def max_pool_3x3_s2_same(x):
     out = -(-size // 2)
     total = max((out - 1) * 2 + 3 - size, 0)
     pads += [total // 2, total - total // 2]
-  x = F.pad(x, tuple(pads), value=float('-inf'))
-  return F.max_pool2d(x, 3, stride=2)
+  y = F.max_pool2d(F.pad(x, tuple(pads), value=float('-inf')), 3, stride=2)
+  if TRACE is not None:
+    _tag(y, 'maxpool(%s,3,2,SAME)' % _e(x))
+  return y
 
 
 def _resnet_conv(x, wts, scope, k, stride, rate, relu, eps=RESNET_BN_EPS):
@@ -263,11 +366,11 @@ def _resnet_conv(x, wts, scope, k, stride, rate, relu, eps=RESNET_BN_EPS):
   (conv + BN [+ ReLU])."""
   w = wts[scope + '/weights']
   if k == 1:
-    y = conv2d_raw(x, w, stride, 1, 'SAME')
+    y = conv2d_raw(x, w, stride, 1, 'SAME', scope)
   else:
-    y = conv2d_same_raw(x, w, stride, rate)
+    y = conv2d_same_raw(x, w, stride, rate, scope)
   y = batch_norm(y, wts, scope, eps)
-  return F.relu(y) if relu else y
+  return _relu(y) if relu else y
 
 
 def bottleneck(x, wts, scope, depth, depth_bottleneck, stride, rate, end_points):
@@ -281,7 +384,7 @@ def bottleneck(x, wts, scope, depth, depth_bottleneck, stride, rate, end_points)
   r = _resnet_conv(r, wts, scope + '/conv2', 3, stride, rate, True)   # :82-83
   r = _resnet_conv(r, wts, scope + '/conv3', 1, 1, 1, False)          # :84-85
   end_points[scope + '/conv3'] = r
-  out = F.relu(shortcut + r)                                          # :86
+  out = relu(add(shortcut, r))                                        # :86
   end_points[scope] = out
   return out
 
@@ -333,15 +436,16 @@ def resnet_v1_101_beta(x, wts, output_stride, multi_grid=None,
 # ----------------------------------------------------------------------------
 def split_separable_conv2d(x, wts, scope, rate, eps):
   """model.py:51-97: dw3x3(rate)+BN+ReLU then 1x1+BN+ReLU."""
-  y = depthwise_raw(x, wts[scope + '_depthwise/depthwise_weights'], 1, rate)
-  y = F.relu(batch_norm(y, wts, scope + '_depthwise', eps))
-  y = conv2d_raw(y, wts[scope + '_pointwise/weights'])
-  return F.relu(batch_norm(y, wts, scope + '_pointwise', eps))
+  y = depthwise_raw(x, wts[scope + '_depthwise/depthwise_weights'], 1, rate,
+                    scope=scope + '_depthwise')
+  y = relu(batch_norm(y, wts, scope + '_depthwise', eps))
+  y = conv2d_raw(y, wts[scope + '_pointwise/weights'], scope=scope + '_pointwise')
+  return relu(batch_norm(y, wts, scope + '_pointwise', eps))
 
 
 def _conv1x1_bn_relu(x, wts, scope, eps):
-  return F.relu(batch_norm(conv2d_raw(x, wts[scope + '/weights']), wts, scope,
-                           eps))
+  return relu(batch_norm(conv2d_raw(x, wts[scope + '/weights'], scope=scope), wts,
+                         scope, eps))
 
 
 def aspp(features, wts, atrous_rates, end_points):
@@ -350,15 +454,17 @@ def aspp(features, wts, atrous_rates, end_points):
   h, w = features.shape[2], features.shape[3]
   branches = []
   pooled = features.mean(dim=(2, 3), keepdim=True)                 # :220
+  if TRACE is not None:
+    _tag(pooled, 'mean(%s)' % _e(features))
   pooled = _conv1x1_bn_relu(pooled, wts, 'image_pooling', eps)     # :223-224
   branches.append(resize_bilinear_align_corners(pooled, (h, w)))   # :225-226
   branches.append(_conv1x1_bn_relu(features, wts, 'aspp0', eps))   # :236-237
   for i, rate in enumerate(atrous_rates, 1):                       # :239-253
     branches.append(split_separable_conv2d(features, wts, 'aspp%d' % i, rate,
                                            eps))
-  concat = torch.cat(branches, dim=1)                              # :256
-  end_points['aspp_concat'] = concat
-  out = _conv1x1_bn_relu(concat, wts, 'concat_projection', eps)    # :257-258
+  cat = concat(branches)                                           # :256
+  end_points['aspp_concat'] = cat
+  out = _conv1x1_bn_relu(cat, wts, 'concat_projection', eps)       # :257-258
   end_points['concat_projection'] = out
   return out                                  # dropout = identity (:259-263)
 
@@ -375,7 +481,7 @@ def decoder(features, low_level, wts, im_size_wh, decoder_output_stride,
     dw = scale_dimension(im_size_wh[0], 1.0 / stride)              # :355
     dh = scale_dimension(im_size_wh[1], 1.0 / stride)              # :356
     feats = [resize_bilinear_align_corners(t, (dh, dw)) for t in (x, proj)]
-    x = torch.cat(feats, dim=1)                                    # :372
+    x = concat(feats)                                              # :372
     end_points['decoder_concat' + suffix] = x
     x = split_separable_conv2d(x, wts, 'decoder/decoder_conv0' + suffix, 1, eps)
     end_points['decoder/decoder_conv0' + suffix] = x
@@ -400,10 +506,14 @@ def logits(images, wts, num_objs, num_frags, model_variant='xception_65',
   if model_variant not in DECODER_TAP:
     raise ValueError('oracle covers xception_65 and resnet_v1_101_beta.')
   x = torch.as_tensor(np.asarray(images), dtype=torch.float32).to(DTYPE)
+  if DEVICE:
+    x = x.to(DEVICE)
   x = x.permute(0, 3, 1, 2).contiguous()
   if crop_size_wh is None:
     crop_size_wh = (x.shape[3], x.shape[2])
+  _tag(x, 'input')
   x = (2.0 / 255.0) * x - 1.0                                # feature.py:171-174
+  _tag(x, 'preprocess(input)')
   if model_variant == 'xception_65':
     feats, end_points = xception_65(x, wts, encoder_output_stride, multi_grid)
   else:
@@ -420,8 +530,13 @@ def logits(images, wts, num_objs, num_frags, model_variant='xception_65',
   }
   out = {}
   for name in sorted(num_channels):                           # model.py:503
-    y = conv2d_raw(feats, wts['logits/%s/weights' % name])    # :449-456
+    y = conv2d_raw(feats, wts['logits/%s/weights' % name],    # :449-456
+                   scope='logits/' + name)
+    e = _e(y) if TRACE is not None else None
     y = y + _t(wts['logits/%s/biases' % name]).view(1, -1, 1, 1)
+    if TRACE is not None:
+      TRACE.layers[-1]['bias'] = True
+      _tag(y, e)
     assert y.shape[1] == num_channels[name]
     out[name] = y
   return out, end_points
@@ -441,6 +556,17 @@ def predict(images, wts, num_objs, num_frags=64, **kw):
         b, h, w, num_objs, num_frags, 3)
     obj_conf = torch.softmax(obj, dim=-1)                     # :677
     frag_conf = torch.softmax(frag, dim=-1)                   # :678
+    if TRACE is not None:
+      eo, ef, el = (_e(lg[k]) for k in (PRED_OBJ_CONF, PRED_FRAG_CONF, PRED_FRAG_LOC))
+      TRACE.outputs = {
+          PRED_OBJ_CONF: {'expr': 'softmax(%s)' % eo, 'shape': [b, h, w, num_objs + 1]},
+          PRED_OBJ_LABEL: {'expr': 'argmax(softmax(%s))' % eo, 'shape': [b, h, w]},
+          PRED_FRAG_CONF: {'expr': 'softmax(reshape(%s,%s))' % (ef, [num_objs, num_frags]),
+                           'shape': [b, h, w, num_objs, num_frags]},
+          PRED_FRAG_LOC: {'expr': 'reshape(%s,%s)' % (el, [num_objs, num_frags, 3]),
+                          'shape': [b, h, w, num_objs, num_frags, 3]}}
+    if DEVICE == 'meta':
+      return None
     return {
         PRED_OBJ_CONF: obj_conf.numpy(),
         PRED_OBJ_LABEL: torch.argmax(obj_conf, dim=3).numpy(),  # :683, int64

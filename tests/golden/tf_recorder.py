@@ -84,7 +84,8 @@ class Tensor(object):
 
 
 def _canon_preprocess(expr):
-  return 'preprocess(input)' if expr == 'sub(mul(input,%.9g),1)' % (2.0 / 255.0) else expr
+  """feature.py:171-174, (2.0 / 255.0) * x - 1.0, wherever it occurs in an expression."""
+  return expr.replace('sub(mul(input,%.9g),1)' % (2.0 / 255.0), 'preprocess(input)')
 
 
 def _conv_out(size, k, stride, rate, padding):
@@ -181,6 +182,8 @@ def convert_collection_to_dict(collection, clear_collection=False):
 
 # ------------------------------------------------------------------- layers ---
 def relu(x, name=None):
+  if x.expr.startswith('relu('):       # ReLU is idempotent: one canonical spelling
+    return Tensor(x.shape, x.expr)
   return Tensor(x.shape, 'relu(%s)' % x.expr)
 
 
@@ -385,7 +388,12 @@ class _FlagsModule(object):
     object.__setattr__(self.FLAGS, name, default)
 
   DEFINE_string = DEFINE_integer = DEFINE_float = DEFINE_boolean = DEFINE_bool = _define
-  DEFINE_list = DEFINE_multi_float = DEFINE_multi_integer = _define
+  DEFINE_multi_float = DEFINE_multi_integer = _define
+
+  def DEFINE_list(self, name, default, *a, **k):          # absl: 'a,b' -> ['a', 'b']
+    if isinstance(default, str):
+      default = default.split(',')
+    object.__setattr__(self.FLAGS, name, default)
 
   def DEFINE_enum(self, name, default, values, *a, **k):
     object.__setattr__(self.FLAGS, name, default)

@@ -51,8 +51,19 @@ from epos_amd import _lib                   # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 roof
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 # The split kernel spends six bf16 piece products per fp32 product, so its roof in
-# ALGORITHMIC (fp32) flops is the bf16 peak / 6.
+# ALGORITHMIC (fp32) flops is the bf16 peak / 6; the fp16-pair kernel (round 3, default)
+# spends three fp16 products (same MFMA rate as bf16): peak / 3.
 SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+H2_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 3.0
+
+
+def gemm_family():
+  """Which kernel the plan's GEMMs run on (the library's environment switches)."""
+  if os.environ.get('EPOS_GEMM_SPLIT', '1') == '0':
+    return 'fp32'
+  if os.environ.get('EPOS_GEMM_H2', '1') == '0':
+    return 'split'
+  return 'h2' 
 ALGO_GFLOP_C2 = 455.0           # SURVEY.md App. A, per image
 
 
@@ -285,8 +296,18 @@ def gemm_roofline(pipe, steps):
       abytes += net.op_bytes.get(name, 0)
       per.setdefault(name, []).append(ms)
   achieved = flops / (total_ms * 1e-3) / 1e12
-  split = os.environ.get('EPOS_GEMM_SPLIT', '1') != '0'
-  if split:
+  fam = gemm_family()
+  if fam == 'h2':
+    kernel, peak = 'pointwise_gemm_h2_f32', H2_PEAK_TFLOPS
+    peak_note = ('algorithmic fp32 flops against the fp16 dense MFMA peak (2516.6, the bf16 '
+                 'figure: v_mfma_f32_32x32x16_f16 runs at the same rate) / 3: the kernel '
+                 'forms every fp32 product from THREE fp16 piece products of two-piece '
+                 'round-to-nearest operand splits under power-of-two scales (fp32 in, fp32 '
+                 'out, measured error below the fp32 MFMA kernel\'s); frac is therefore '
+                 'also the utilisation of the matrix pipe. The bf16 x 6 kernel\'s roof for '
+                 'the same work is 419.4, the fp32-MFMA roof 157.3; what bare MFMAs sustain '
+                 'at the 1400 W cap is ~2000 (-> ~667 here)')
+  elif fam == 'split':
     kernel, peak = 'pointwise_gemm_split_f32', SPLIT_PEAK_TFLOPS
     peak_note = ('algorithmic fp32 flops against the bf16 dense MFMA peak (2516.6) / 6: the '
                  'kernel forms every fp32 product from six bf16 piece products of exact '
@@ -319,6 +340,8 @@ def gemm_roofline(pipe, steps):
       'kernel': kernel,
       'peak_note': peak_note,
       'frac_of_fp32_mfma_peak': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+      'mfma_pipe_utilisation': round(achieved * {'h2': 3.0, 'split': 6.0}.get(fam, 16.0) /
+                                     BF16_MFMA_PEAK_TFLOPS, 4),
       'launches_per_image': launches // steps // net.B,
       'avg_launch_us': round(total_ms * 1e3 / launches, 2),
       'gflop_per_image': round(flops / steps / net.B / 1e9, 1),
@@ -452,14 +475,19 @@ def main():
                           'raw' if args.no_calibrate else 'calibrated to ~10% '
                           'masked pixels per object', args.num_objs,
                           args.num_frags, args.objs_per_image, B),
-          'arithmetic': ('fp32 activations / weights / accumulators everywhere, as the '
-                         'reference; 1x1-conv GEMMs: fp32-equivalent products from exact '
-                         'three-way bf16 splits of both operands (six of the nine bf16 '
-                         'piece products, fp32 accumulate; the three dropped terms are '
-                         'below 2^-23 of the product), measured error vs fp64 below the '
-                         'fp32-MFMA kernel (EPOS_GEMM_SPLIT=0 selects that kernel)'
-                         if os.environ.get('EPOS_GEMM_SPLIT', '1') != '0' else
-                         'fp32 everywhere, GEMMs on v_mfma_f32_32x32x2_f32'),
+          'arithmetic': {
+              'h2': 'fp32 activations / weights / accumulators everywhere, as the reference; '
+                    '1x1-conv and implicit 3x3 GEMMs: fp32-equivalent products from two-piece '
+                    'fp16 splits of both operands (hi = rn(x 2^e), mid = rn((x 2^e - hi) '
+                    '2^11): 22-23 significant bits; three of the four piece products, fp32 '
+                    'accumulate, the dropped one below 2^-22 of the product and of random '
+                    'sign), power-of-two scales per weight column (host) and per activation '
+                    'tensor (absmax slots kept by the producing kernels: overflow impossible), '
+                    'measured error vs fp64 below the fp32-MFMA kernel at the full C2 size '
+                    '(EPOS_GEMM_H2=0: bf16 x 6 kernel, EPOS_GEMM_SPLIT=0: fp32 MFMA kernel)',
+              'split': 'fp32 everywhere; GEMMs: fp32-equivalent products from exact three-way '
+                       'bf16 splits (six of nine piece products), EPOS_GEMM_H2=0',
+              'fp32': 'fp32 everywhere, GEMMs on v_mfma_f32_32x32x2_f32'}[gemm_family()],
           'height': args.height, 'width': args.width,
           'batch_per_gpu': B, 'global_batch': B * world,
           'parallelism': 'dp%d (images sharded, one all_gather of pose records per '
@@ -476,6 +504,35 @@ def main():
           'algorithmic_gflop_per_image': round(pipe.net.flops / B / 1e9, 1),
       },
   }
+  # Comparability: what a step is made of, at the top level of the line
+  fitp = pipe.fit
+  result['batch_per_gpu'] = B
+  result['pipeline_depth'] = depth
+  result['fit'] = {'method': args.fitting_method, 'max_iters': int(fitp.max_iters),
+                   'lo_iters': int(fitp.lo_iters), 'gc_sweeps': int(fitp.gc_sweeps),
+                   'pearl_iters': int(fitp.pearl_iters), 'max_instances': 1,
+                   'rounds_per_step': 1}
+  # Decomposition of the TIMED step (same pipelined regime, same steps): the plans' graphs
+  # are re-captured without their GEMM / depthwise launches and the same `steps` steps are
+  # timed again; step - that = what those kernels cost inside the step, overlap with the
+  # other plans in flight included. launches x average <= ms_per_step holds by construction.
+  decomp = None
+  if not args.no_graph and not args.sparse_heads and not args.no_roofline:
+    decomp = {}
+    for kinds in (('gemm',), ('dw',)):
+      for p_ in pipes:
+        with torch.cuda.stream(p_.stream):
+          p_.net.capture_alt(kinds)
+      run(0, min(args.warmup, 3))
+      torch.cuda.synchronize()
+      edist.barrier()
+      ta = time.perf_counter()
+      run(args.warmup, args.steps)
+      torch.cuda.synchronize()
+      edist.barrier()
+      decomp[kinds[0]] = edist.max_over_ranks(time.perf_counter() - ta) / args.steps * 1e3
+    for p_ in pipes:
+      p_.net.capture_alt(None)
   # shader clock under the same load: a few extra steps with a spinning probe wave
   # on a side stream (the fp32 MFMA roof is 64 FLOP/clk/SIMD x this clock)
   clk_stream = torch.cuda.Stream(device=dev)
@@ -539,7 +596,8 @@ def main():
     if core_mhz:
       # sampled in extra steps after the timed region; peak stays the 2.4 GHz figure
       roof['core_clock_mhz_under_load'] = round(core_mhz, 0)
-      per_clk = 1024 / 6.0 if roof['kernel'] == 'pointwise_gemm_split_f32' else 64
+      per_clk = {'pointwise_gemm_split_f32': 1024 / 6.0,
+                 'pointwise_gemm_h2_f32': 1024 / 3.0}.get(roof['kernel'], 64)
       roof['peak_at_measured_clock'] = round(per_clk * 1024 * core_mhz * 1e6 / 1e12, 1)
     roof['end_to_end_tflops'] = round(value / world * pipe.net.flops / B / 1e12, 2)
     gemm_gflop = roof['gflop_per_image']
@@ -552,6 +610,24 @@ def main():
       roof['gflop_per_image_sparse_heads'] = gemm_gflop
     roof['achieved_in_pipeline'] = round(
         value / world * gemm_gflop / 1e3, 2)   # GEMM flops only, all streams busy
+    if decomp:
+      step_ms = result['ms_per_step']
+      g_ms = max(step_ms - decomp['gemm'], 0.0)
+      d_ms = max(step_ms - decomp['dw'], 0.0)
+      nl = roof['launches_per_image'] * B
+      roof['in_step'] = {
+          'gemm_ms_per_step': round(g_ms, 3), 'depthwise_ms_per_step': round(d_ms, 3),
+          'rest_ms_per_step': round(max(step_ms - g_ms - d_ms, 0.0), 3),
+          'ms_per_step': step_ms,
+          'avg_launch_us': round(g_ms * 1e3 / max(nl, 1), 2),
+          'achieved': round(gemm_gflop * B / max(g_ms, 1e-9), 2),
+          'frac': round(gemm_gflop * B / max(g_ms, 1e-9) / roof['peak'], 4),
+          'how': 'the same %d pipelined steps timed again with the GEMM (resp. depthwise) '
+                 'launches removed from every plan\'s graph: step - that = the kernels\' '
+                 'cost inside the timed regime; launches x avg_launch_us = gemm_ms_per_step '
+                 '<= ms_per_step. roofline.achieved / avg_launch_us above are per-launch '
+                 'figures from eager passes (launch gaps included, no overlap) and agree '
+                 'with the rocprofv3 kernel trace' % args.steps}
     result['roofline'] = roof
     dwr = depthwise_roofline(pipe, max(2, min(args.steps, 5)))
     if dwr:

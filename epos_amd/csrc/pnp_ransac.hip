@@ -391,6 +391,10 @@ struct Work {
   uint8_t* lab_b;        // [N] labels, pong
   const int32_t* yorder; // [N] correspondences of a slot sorted by image y (or null:
   const int32_t* ypos;   //     they already are), and the inverse permutation
+  // cooperative local optimisation (LO_G workgroups per slot)
+  unsigned* lo_cnt;      // [S][lo_launches(max_k)] arrival counters, zeroed by ransac_init
+  double* lo_data;       // [S][2][LO_G * 4][LO_NV] wave sums, double buffered
+  int32_t* lo_timeout;   // [1] sticky: a workgroup gave up waiting for its siblings
   // joint refinement
   double* pearl_pose;            // [S][8][12] candidate poses
   unsigned long long* pearl_acc; // [S][4] data / smoothness sums before, after (exact)
@@ -437,8 +441,11 @@ __device__ void round_failed(int s, const Work& w, const EposFitParams& prm, int
 __global__ __launch_bounds__(256) void ransac_init(const int64_t* slot_base, int S,
                                                    Work w, int32_t* labels,
                                                    int32_t* num_models,
-                                                   int min_pts, int64_t n_capacity) {
+                                                   int min_pts, int64_t n_capacity, int n_lo) {
   const int s = blockIdx.x;
+  for (int i = threadIdx.x; i < n_lo; i += blockDim.x)
+    w.lo_cnt[static_cast<int64_t>(s) * n_lo + i] = 0u;
+  if (s == 0 && threadIdx.x == 0) *w.lo_timeout = 0;
   const int64_t base = slot_base[s];
   // A slot whose rows would end beyond the pooled arrays (the correspondence stage
   // raised its overflow flag and wrote nothing there) is fitted as EMPTY: no kernel of
@@ -531,175 +538,170 @@ __device__ void orthonormalize(double* R) {
   cross3(R, R + 3, R + 6);
 }
 
+// Gaussian elimination with partial pivoting, the arithmetic of oracle/pnp_ref.c's solve6
+// operation for operation, but with every index a compile-time constant (the pivot row is
+// swapped in by selects): the 6 x 7 system stays in registers. The indexed form went
+// through scratch memory -- a dependent chain of ~300 private loads and stores that every
+// thread of the workgroup repeated in every refit pass (~6 us of each ~17 us pass).
 __device__ int solve6(const double* H /*[36]*/, const double* g, double* x) {
   double A[6][7];
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
+#pragma unroll
     for (int j = 0; j < 6; ++j) A[i][j] = H[i * 6 + j];
     A[i][6] = -g[i];
   }
+#pragma unroll
   for (int c = 0; c < 6; ++c) {
     int piv = c;
-    for (int r = c + 1; r < 6; ++r)
-      if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
-    if (!(fabs(A[piv][c]) > 1e-300)) return 1;
-    if (piv != c)
-      for (int j = 0; j < 7; ++j) { const double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
+    double best = fabs(A[c][c]);
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) {
+      const double v = fabs(A[r][c]);
+      if (v > best) { best = v; piv = r; }
+    }
+    if (!(best > 1e-300)) return 1;
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) {
+      const bool sw = piv == r;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const double tc = A[c][j], tr = A[r][j];
+        A[c][j] = sw ? tr : tc;
+        A[r][j] = sw ? tc : tr;
+      }
+    }
+#pragma unroll
     for (int r = c + 1; r < 6; ++r) {
       const double fct = A[r][c] / A[c][c];
+#pragma unroll
       for (int j = c; j < 7; ++j) A[r][j] -= fct * A[c][j];
     }
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
     double sacc = A[i][6];
+#pragma unroll
     for (int j = i + 1; j < 6; ++j) sacc -= A[i][j] * x[j];
     x[i] = sacc / A[i][i];
   }
   return 0;
 }
 
-// ---- workgroup-wide (256 threads) sums of the local optimisation -------------------
-// Canonical order: 256 strided partials (thread t takes items t, t+256, ...), the xor
-// butterfly inside each wave, then (w0 + w1) + (w2 + w3) through LDS. Every thread gets
-// the same value, so the control flow that depends on it stays workgroup-uniform.
-__device__ __forceinline__ double block_combine(double wave_sum, double* s_red, int t) {
-  if ((t & 63) == 0) s_red[t >> 6] = wave_sum;
-  __syncthreads();
-  const double r = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  __syncthreads();
-  return r;
-}
+// ---- sums of the local optimisation ------------------------------------------------------
+// Canonical order over P = 256 * G strided partials (partial q takes items q, q + P, ...):
+// the xor butterfly inside each group of 64, (w0 + w1) + (w2 + w3) inside each group of 256,
+// then (W0 + W1) + (W2 + W3) over the G = 4 groups of 256 (G = 1: the group of 256 alone).
+// G = 1 is one 256-thread workgroup (joint refinement). G = LO_G = 4 (round 3): FOUR
+// workgroups per slot, workgroup g owning partials [256 g, 256 g + 256): each pass of a refit
+// is a latency-bound sweep over the slot's correspondences (a dependent gather and ~250 fp64
+// operations per item), so four workgroups on four CUs shorten it almost four-fold; the
+// sixteen wave sums meet in global memory (placement-independent agent-scope hand-off of
+// cdna_hip_programming.md Guideline 16: plain stores, every wave drains, ONE release + ticket
+// per workgroup, relaxed polling, ONE acquire) and every workgroup combines them in the same
+// order, so all of them continue with identical values and identical control flow. The
+// siblings of a slot have adjacent block indices, i.e. the same position in their XCDs'
+// dispatch order: whenever one of them is resident the others are or are about to be; the
+// spin is bounded anyway (lo_timeout).
+constexpr int LO_G = 4;
+constexpr int LO_NV = 32;            // doubles per wave row (27 sums, score, count)
+constexpr unsigned LO_SPIN_MAX = 1u << 24;
 
-__device__ double score_pose_block(const double* pose, const double* K, const double* xy,
-                                   const double* xyz, const int32_t* idx, int64_t m,
-                                   double thr2, int t, double* s_red, int* s_cnt,
-                                   int* count) {
-  const double inv_thr2 = 1.0 / thr2;
-  double acc = 0.0;
-  int cnt = 0;
-  for (int64_t i0 = t; i0 < m; i0 += 256 * PF) {
-    PointBatch pb;
-    pb.load(xy, xyz, idx, i0, 256, m);
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      if (!pb.ok[u]) continue;
-      double e2, Xc[3], r[2];
-      if (reproj(pose, K, pb.x2[u], pb.x3[u], &e2, Xc, r)) continue;
-      if (e2 < thr2) { acc += 1.0 - e2 * inv_thr2; ++cnt; }
+struct LoSync {
+  unsigned* cnt;        // this launch's counter of the slot (null: single workgroup)
+  double* data;         // [2][LO_G * 4][LO_NV]
+  int32_t* timeout;
+  int g;                // workgroup index within the slot
+  unsigned epoch;       // exchanges done so far in this launch
+};
+
+// wv[0..nv): this WAVE's sums (uniform over its lanes). Returns the canonical totals in
+// comb[0..nv) (LDS, valid for every thread after the call). s_rows: LDS [4][LO_NV].
+__device__ void lo_combine(LoSync& sy, const double* wv, int nv, int t, double* s_rows,
+                           double* comb) {
+  const int lane = t & 63, wave = t >> 6;
+  if (sy.cnt == nullptr) {                       // one workgroup: through LDS only
+    if (lane == 0)
+      for (int v = 0; v < nv; ++v) s_rows[wave * LO_NV + v] = wv[v];
+    __syncthreads();
+    if (t < nv)
+      comb[t] = (s_rows[t] + s_rows[LO_NV + t]) + (s_rows[2 * LO_NV + t] + s_rows[3 * LO_NV + t]);
+    __syncthreads();
+    return;
+  }
+  double* buf = sy.data + (sy.epoch & 1u) * (LO_G * 4 * LO_NV);
+  if (lane == 0)
+    for (int v = 0; v < nv; ++v) buf[(sy.g * 4 + wave) * LO_NV + v] = wv[v];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
+  __syncthreads();
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(sy.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = LO_G * (sy.epoch + 1u);
+    unsigned spins = 0;
+    while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > LO_SPIN_MAX) { *sy.timeout = 1; break; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  cnt = butterfly_sum_i(cnt);
-  if ((t & 63) == 0) s_cnt[t >> 6] = cnt;
-  const double sc = block_combine(butterfly_sum(acc), s_red, t);   // two barriers inside
-  *count = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
   __syncthreads();
-  return sc;
-}
-
-// lab == nullptr: the inliers of `pose` at thr2; otherwise the points with lab[p] == sel
-// (fixed membership, full weight)
-__device__ int gn_step_block(const double* pose, const double* K, const double* xy,
-                             const double* xyz, const int32_t* idx, int64_t m,
-                             double thr2, int t, double* s_red27 /*[4][27]*/,
-                             double* next, const uint8_t* lab = nullptr, int sel = 1) {
-  double acc[27];
+  if (t < nv) {
+    double W[LO_G];
 #pragma unroll
-  for (int v = 0; v < 27; ++v) acc[v] = 0.0;
-  for (int64_t i0 = t; i0 < m; i0 += 256 * PF) {
-    PointBatch pb;
-    pb.load(xy, xyz, idx, i0, 256, m);
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-    if (!pb.ok[u]) continue;
-    double e2, Xc[3], r[2];
-    if (reproj(pose, K, pb.x2[u], pb.x3[u], &e2, Xc, r)) continue;
-    if (lab ? lab[pb.p[u]] != sel : !(e2 < thr2)) continue;
-    const double iz = 1.0 / Xc[2];
-    const double a0 = K[0] * iz, a1 = K[1] * iz,
-                 a2 = -(K[0] * Xc[0] + K[1] * Xc[1]) * iz * iz;
-    const double b1 = K[4] * iz, b2 = -(K[4] * Xc[1]) * iz * iz;
-    double J0[6], J1[6];
-    // Xc(w) = Xc - [Xc]x w: row . (-[Xc]x)  (sign fixed in round 2)
-    J0[0] = -a1 * Xc[2] + a2 * Xc[1];
-    J0[1] = a0 * Xc[2] - a2 * Xc[0];
-    J0[2] = -a0 * Xc[1] + a1 * Xc[0];
-    J0[3] = a0; J0[4] = a1; J0[5] = a2;
-    J1[0] = -b1 * Xc[2] + b2 * Xc[1];
-    J1[1] = -b2 * Xc[0];
-    J1[2] = b1 * Xc[0];
-    J1[3] = 0.0; J1[4] = b1; J1[5] = b2;
-    int v = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = a; b < 6; ++b) { acc[v] += J0[a] * J0[b] + J1[a] * J1[b]; ++v; }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) { acc[v] += J0[a] * r[0] + J1[a] * r[1]; ++v; }
+    for (int g = 0; g < LO_G; ++g) {
+      const double* r = buf + (g * 4) * LO_NV + t;
+      W[g] = (r[0] + r[LO_NV]) + (r[2 * LO_NV] + r[3 * LO_NV]);
     }
-  }
-#pragma unroll
-  for (int v = 0; v < 27; ++v) {
-    const double ws = butterfly_sum(acc[v]);
-    if ((t & 63) == 0) s_red27[(t >> 6) * 27 + v] = ws;
+    comb[t] = (W[0] + W[1]) + (W[2] + W[3]);
   }
   __syncthreads();
-#pragma unroll
-  for (int v = 0; v < 27; ++v)
-    acc[v] = (s_red27[v] + s_red27[27 + v]) + (s_red27[54 + v] + s_red27[81 + v]);
-  __syncthreads();
-  double H[36], g[6], x[6];
-  int v = 0;
-  for (int a = 0; a < 6; ++a)
-    for (int b = a; b < 6; ++b) { H[a * 6 + b] = acc[v]; H[b * 6 + a] = acc[v]; ++v; }
-  for (int a = 0; a < 6; ++a) g[a] = acc[v++];
-  if (solve6(H, g, x)) return 1;
-  double qw = 1.0, qx = 0.5 * x[0], qy = 0.5 * x[1], qz = 0.5 * x[2];
-  const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
-  qw /= qn; qx /= qn; qy /= qn; qz /= qn;
-  double dR[9];
-  dR[0] = 1.0 - 2.0 * (qy * qy + qz * qz); dR[1] = 2.0 * (qx * qy - qz * qw); dR[2] = 2.0 * (qx * qz + qy * qw);
-  dR[3] = 2.0 * (qx * qy + qz * qw); dR[4] = 1.0 - 2.0 * (qx * qx + qz * qz); dR[5] = 2.0 * (qy * qz - qx * qw);
-  dR[6] = 2.0 * (qx * qz - qy * qw); dR[7] = 2.0 * (qy * qz + qx * qw); dR[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
-  for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j)
-      next[i * 3 + j] = dR[i * 3] * pose[j] + dR[i * 3 + 1] * pose[3 + j] + dR[i * 3 + 2] * pose[6 + j];
-    next[9 + i] = dR[i * 3] * pose[9] + dR[i * 3 + 1] * pose[10] + dR[i * 3 + 2] * pose[11] + x[3 + i];
-  }
-  for (int i = 0; i < 12; ++i)
-    if (!(next[i] == next[i])) return 1;
-  return 0;
+  ++sy.epoch;
 }
 
-// One pass over the correspondences that yields BOTH the MSAC score / inlier count of
-// `pose` (exactly score_pose_block's sums) and the Gauss-Newton step from it (exactly
-// gn_step_block's): the local optimisation then costs one pass per refit instead of two
-// (step from the accepted pose + score of the candidate). Returns the step's failure flag.
-__device__ int score_and_step_block(const double* pose, const double* K, const double* xy,
-                                    const double* xyz, const int32_t* idx, int64_t m,
-                                    double thr2, int t, double* s_red27, double* s_red,
-                                    int* s_cnt, const uint8_t* lab, int sel, double* score,
-                                    int* count, double* next) {
+struct LoLds {                 // LDS of a local-optimisation workgroup
+  double rows[4 * LO_NV];
+  double comb[LO_NV];
+};
+
+// One pass over the correspondences idx[0..m) (idx == nullptr: 0..m) that yields
+//   * SCORE: the MSAC score and inlier count of `pose` at thr2,
+//   * the Gauss-Newton step from `pose` on its members -- lab == nullptr: the inliers at
+//     thr2; otherwise the points with lab[p] == sel (fixed membership, full weight) --
+//     as the next pose (returns 1 when the normal equations are singular / non-finite).
+// One pass per refit: the step of an accepted candidate is already there when the next
+// refit starts. All sums in the canonical order of lo_combine (G = 1 or LO_G workgroups).
+template <bool SCORE>
+__device__ int lo_pass(const double* pose, const double* K, const double* xy,
+                       const double* xyz, const int32_t* idx, int64_t m, double thr2, int t,
+                       LoSync& sy, LoLds* lds, const uint8_t* lab, int sel, double* score,
+                       int* count, double* next) {
+  const int G = sy.cnt ? LO_G : 1;
+  const int stride = 256 * G;
   const double inv_thr2 = 1.0 / thr2;
-  double acc[27];
+  double acc[29];
 #pragma unroll
-  for (int v = 0; v < 27; ++v) acc[v] = 0.0;
-  double sacc = 0.0;
+  for (int v = 0; v < 29; ++v) acc[v] = 0.0;
   int cnt = 0;
-  for (int64_t i0 = t; i0 < m; i0 += 256 * PF) {
+  for (int64_t i0 = static_cast<int64_t>(sy.g) * 256 + t; i0 < m;
+       i0 += static_cast<int64_t>(stride) * PF) {
     PointBatch pb;
-    pb.load(xy, xyz, idx, i0, 256, m);
+    pb.load(xy, xyz, idx, i0, stride, m);
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       if (!pb.ok[u]) continue;
       double e2, Xc[3], r[2];
       if (reproj(pose, K, pb.x2[u], pb.x3[u], &e2, Xc, r)) continue;
       const bool inl = e2 < thr2;
-      if (inl) { sacc += 1.0 - e2 * inv_thr2; ++cnt; }
+      if (SCORE && inl) { acc[27] += 1.0 - e2 * inv_thr2; ++cnt; }
       if (lab ? lab[pb.p[u]] != sel : !inl) continue;
       const double iz = 1.0 / Xc[2];
       const double a0 = K[0] * iz, a1 = K[1] * iz,
                    a2 = -(K[0] * Xc[0] + K[1] * Xc[1]) * iz * iz;
       const double b1 = K[4] * iz, b2 = -(K[4] * Xc[1]) * iz * iz;
       double J0[6], J1[6];
+      // Xc(w) = Xc - [Xc]x w: row . (-[Xc]x)  (sign fixed in round 2)
       J0[0] = -a1 * Xc[2] + a2 * Xc[1];
       J0[1] = a0 * Xc[2] - a2 * Xc[0];
       J0[2] = -a0 * Xc[1] + a1 * Xc[0];
@@ -717,24 +719,30 @@ __device__ int score_and_step_block(const double* pose, const double* K, const d
       for (int a = 0; a < 6; ++a) { acc[v] += J0[a] * r[0] + J1[a] * r[1]; ++v; }
     }
   }
-  cnt = butterfly_sum_i(cnt);
-  if ((t & 63) == 0) s_cnt[t >> 6] = cnt;
+  constexpr int NV = SCORE ? 29 : 27;
 #pragma unroll
-  for (int v = 0; v < 27; ++v) {
-    const double ws = butterfly_sum(acc[v]);
-    if ((t & 63) == 0) s_red27[(t >> 6) * 27 + v] = ws;
+  for (int v = 0; v < 27; ++v) acc[v] = butterfly_sum(acc[v]);
+  if (SCORE) {
+    acc[27] = butterfly_sum(acc[27]);
+    acc[28] = static_cast<double>(butterfly_sum_i(cnt));      // exact: counts < 2^31
   }
-  *score = block_combine(butterfly_sum(sacc), s_red, t);      // two barriers inside
-  *count = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-#pragma unroll
-  for (int v = 0; v < 27; ++v)
-    acc[v] = (s_red27[v] + s_red27[27 + v]) + (s_red27[54 + v] + s_red27[81 + v]);
-  __syncthreads();
+  lo_combine(sy, acc, NV, t, lds->rows, lds->comb);
+  const double* tot = lds->comb;
+  if (SCORE) {
+    *score = tot[27];
+    *count = static_cast<int>(tot[28]);
+  }
   double H[36], g[6], x[6];
-  int v = 0;
-  for (int a = 0; a < 6; ++a)
-    for (int b = a; b < 6; ++b) { H[a * 6 + b] = acc[v]; H[b * 6 + a] = acc[v]; ++v; }
-  for (int a = 0; a < 6; ++a) g[a] = acc[v++];
+  {
+    int v = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) { H[a * 6 + b] = tot[v]; H[b * 6 + a] = tot[v]; ++v; }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) g[a] = tot[v++];
+  }
+  __syncthreads();               // every thread has read the totals: comb may be reused
   if (solve6(H, g, x)) return 1;
   double qw = 1.0, qx = 0.5 * x[0], qy = 0.5 * x[1], qz = 0.5 * x[2];
   const double qn = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
@@ -743,14 +751,17 @@ __device__ int score_and_step_block(const double* pose, const double* K, const d
   dR[0] = 1.0 - 2.0 * (qy * qy + qz * qz); dR[1] = 2.0 * (qx * qy - qz * qw); dR[2] = 2.0 * (qx * qz + qy * qw);
   dR[3] = 2.0 * (qx * qy + qz * qw); dR[4] = 1.0 - 2.0 * (qx * qx + qz * qz); dR[5] = 2.0 * (qy * qz - qx * qw);
   dR[6] = 2.0 * (qx * qz - qy * qw); dR[7] = 2.0 * (qy * qz + qx * qw); dR[8] = 1.0 - 2.0 * (qx * qx + qy * qy);
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
+#pragma unroll
     for (int j = 0; j < 3; ++j)
       next[i * 3 + j] = dR[i * 3] * pose[j] + dR[i * 3 + 1] * pose[3 + j] + dR[i * 3 + 2] * pose[6 + j];
     next[9 + i] = dR[i * 3] * pose[9] + dR[i * 3 + 1] * pose[10] + dR[i * 3 + 2] * pose[11] + x[3 + i];
   }
-  for (int i = 0; i < 12; ++i)
-    if (!(next[i] == next[i])) return 1;
-  return 0;
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) bad = bad || !(next[i] == next[i]);
+  return bad ? 1 : 0;
 }
 
 // ---- round, step 2: best hypothesis (with the RANSAC confidence bound) + local
@@ -759,13 +770,18 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
     const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
     const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
     const int32_t* __restrict__ max_models, EposFitParams prm, int max_k, int round,
-    Work w, const int32_t* __restrict__ num_models) {
+    Work w, const int32_t* __restrict__ num_models, const int32_t* __restrict__ labels_all,
+    int lo_launch, int n_lo) {
   __shared__ double s_score[256];
   __shared__ int s_index[256];
-  const int s = blockIdx.x;
+  __shared__ LoLds s_lo;
+  // LO_G workgroups per slot (blockIdx.x = g: siblings are adjacent in dispatch order);
+  // all of them take every decision from the same data, workgroup 0 writes the state
+  const int s = blockIdx.y;
+  const int g = blockIdx.x;
   const int t = threadIdx.x;
-  if (t == 0) w.state[s] = 0;
-  if (w.done[s]) return;                                   // block-uniform
+  if (t == 0 && g == 0) w.state[s] = 0;
+  if (w.done[s]) return;                                   // uniform over the slot
   int want = max_models[s];
   if (want < 0 || want > max_k) want = max_k;
   const int k = num_models[s];
@@ -775,7 +791,7 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   const int64_t n_active = w.n_active[s];
   if (k >= want || round >= want + (want > 1 ? 2 : 0) ||
       n_active < prm.min_point_number || n_active < 3) {
-    if (t == 0) w.done[s] = 1;
+    if (t == 0 && g == 0) w.done[s] = 1;
     return;
   }
   const int nh = prm.max_iters * MAX_SOL;
@@ -821,16 +837,19 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
       __syncthreads();
     }
   }
-  __shared__ double s_red[4];
-  __shared__ double s_red27[4 * 27];
-  __shared__ int s_cnt[4];
   double best_score = s_score[0];
   const int bi = s_index[0];
   int best_count = best_score > 0.0 ? hcnt[bi] : 0;
   if (!(best_score > 0.0) || best_count < 3) {             // uniform
-    if (t == 0) round_failed(s, w, prm, want, k, n_active);
+    if (t == 0 && g == 0) round_failed(s, w, prm, want, k, n_active);
     return;
   }
+  LoSync sy;
+  sy.cnt = w.lo_cnt + static_cast<int64_t>(s) * n_lo + lo_launch;
+  sy.data = w.lo_data + static_cast<int64_t>(s) * (2 * LO_G * 4 * LO_NV);
+  sy.timeout = w.lo_timeout;
+  sy.g = g;
+  sy.epoch = 0;
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
   double K[9];
@@ -843,13 +862,13 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   // each pass scores a pose AND takes the Gauss-Newton step from it: the step of an
   // accepted candidate is already there when the next refit starts
   double cand[12];
-  int fail = score_and_step_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red27, s_red,
-                                  s_cnt, nullptr, 1, &best_score, &best_count, cand);
+  int fail = lo_pass<true>(pose, K, xy, xyz, active, n_active, thr2, t, sy, &s_lo, nullptr, 1,
+                           &best_score, &best_count, cand);
   for (int li = 0; li < prm.lo_iters && !fail; ++li) {
     double sc, cand2[12];
     int cnt;
-    const int fail2 = score_and_step_block(cand, K, xy, xyz, active, n_active, thr2, t, s_red27,
-                                           s_red, s_cnt, nullptr, 1, &sc, &cnt, cand2);
+    const int fail2 = lo_pass<true>(cand, K, xy, xyz, active, n_active, thr2, t, sy, &s_lo,
+                                    nullptr, 1, &sc, &cnt, cand2);
     if (!(sc > best_score)) break;
     const double gain = sc - best_score;
     best_score = sc; best_count = cnt;
@@ -857,20 +876,24 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
     fail = fail2;
     if (!(gain > LO_MIN_GAIN * sc)) break;        // converged: further steps are noise
   }
-  if (t < 12) w.cur_pose[s * 12 + t] = pose[t];
-  if (t == 0) { w.cur_score[s] = best_score; w.cur_count[s] = best_count; }
+  if (g == 0) {
+    if (t < 12) w.cur_pose[s * 12 + t] = pose[t];
+    if (t == 0) { w.cur_score[s] = best_score; w.cur_count[s] = best_count; }
+  }
   const bool gc = prm.gc_sweeps > 0 && prm.spatial_coherence_weight > 0.0 &&
                   prm.neighborhood_ball_radius > 0.0;
-  if (!gc) { if (t == 0) w.state[s] = 2; return; }
+  if (!gc) { if (t == 0 && g == 0) w.state[s] = 2; return; }
   // ---- residual table (2^-20 fixed point of min(e^2 / (1.5 tau)^2, 1)) and the
-  //      thresholded labelling the sweeps start from; 2 = not active
+  //      thresholded labelling the sweeps start from; 2 = not active. A correspondence is
+  //      active iff no accepted instance explains it yet (labels < 0: ransac_refit_accept
+  //      labels exactly the ones it removes from the active list), so every point is
+  //      decided by the one thread that owns it -- the workgroups of the slot share the rows
   uint8_t* lab = w.lab_a + base;
   int32_t* gq = w.gq + base;
-  for (int64_t i = t; i < n; i += 256) lab[i] = 2;
-  __syncthreads();
+  const int32_t* labels = labels_all + base;
   const double tthr = 1.5 * prm.threshold, tthr2 = tthr * tthr;
-  for (int64_t i = t; i < n_active; i += 256) {
-    const int32_t p = active[i];
+  for (int64_t p = static_cast<int64_t>(g) * 256 + t; p < n; p += 256 * LO_G) {
+    if (labels[p] >= 0) { lab[p] = 2; continue; }
     double e2, Xc[3], r[2];
     if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) { gq[p] = GC_Q; lab[p] = 0; continue; }
     double d = e2 / tthr2;
@@ -878,7 +901,7 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
     gq[p] = static_cast<int32_t>(d * static_cast<double>(GC_Q));
     lab[p] = e2 < thr2 ? 1 : 0;
   }
-  if (t == 0) w.state[s] = 1;
+  if (t == 0 && g == 0) w.state[s] = 1;
 }
 
 // ---- round, step 3 (gc_sweeps launches): one synchronous relabelling sweep of the
@@ -943,6 +966,11 @@ __device__ __forceinline__ void for_each_neighbour(const double* xy, const doubl
 #ifndef EPOS_GC_THREADS
 #define EPOS_GC_THREADS 256
 #endif
+struct GcCand {
+  double x, y, X, Y, Z;
+  int32_t q;          // fixed-point residual
+  int32_t ol;         // slot-local index | label << 30
+};
 constexpr int GC_T = EPOS_GC_THREADS;  // threads per tile workgroup
 constexpr int GC_W = GC_T / 64;       // waves: each takes every GC_W-th candidate
 __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
@@ -951,9 +979,10 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
     const uint8_t* __restrict__ lab_in_all, uint8_t* __restrict__ lab_out_all) {
   const int s = blockIdx.y;
   if (w.state[s] != 1) return;
-  __shared__ double c_x[GC_T], c_y[GC_T], c_X[GC_T], c_Y[GC_T], c_Z[GC_T];
-  __shared__ int32_t c_q[GC_T], c_o[GC_T];
-  __shared__ uint8_t c_l[GC_T];
+  // one 48-byte record per candidate = three ds_read_b128 (round 3; eight separate
+  // arrays before: the reads of a candidate were serialised behind one another, ~1000
+  // cycles per candidate and wave -- profiles/r03/gc_sweep_ablation.txt)
+  __shared__ __attribute__((aligned(16))) GcCand c_rec[GC_T];
   __shared__ int64_t s_win[2];
   __shared__ int s_deg[GC_W][64], s_n0[GC_W][64];
   __shared__ int64_t s_S[GC_W][64];
@@ -1028,31 +1057,44 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
       const int64_t c = c0 + t;
       if (c < whi) {
         const int32_t o = yorder ? yorder[c] : static_cast<int32_t>(c);
-        c_o[t] = o;
-        c_x[t] = xy[2 * o]; c_y[t] = xy[2 * o + 1];
-        c_X[t] = xyz[3 * o]; c_Y[t] = xyz[3 * o + 1]; c_Z[t] = xyz[3 * o + 2];
-        c_q[t] = gq[o];
-        c_l[t] = lab_in[o];
+        GcCand r;
+        r.x = xy[2 * o]; r.y = xy[2 * o + 1];
+        r.X = xyz[3 * o]; r.Y = xyz[3 * o + 1]; r.Z = xyz[3 * o + 2];
+        r.q = gq[o];
+        r.ol = o | (static_cast<int32_t>(lab_in[o]) << 30);
+        c_rec[t] = r;
       }
       __syncthreads();
       const int cnt = whi - c0 < GC_T ? static_cast<int>(whi - c0) : GC_T;
-      // branch-free: every LDS read of an iteration is issued up front (wave-uniform
-      // addresses: broadcasts), the tests are arithmetic; four candidates per trip so
-      // that the reads of the next ones overlap the fp64 chain of the current one (the
-      // first version -- early-outs between dependent LDS reads -- ran at ~1500 cycles
-      // per candidate)
-#pragma unroll 4
-      for (int j = sub; j < cnt; j += GC_W) {
-        const int lo_ = c_l[j];
-        const int32_t co = c_o[j], cq = c_q[j];
-        const double dx = px - c_x[j], dy = py - c_y[j];
-        const double dX = pX - c_X[j], dY = pY - c_Y[j], dZ = pZ - c_Z[j];
-        const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
-        const int nb = static_cast<int>(act) & static_cast<int>(lo_ != 2) &
-                       static_cast<int>(co != p) & static_cast<int>(d2 <= r2);
-        deg += nb;
-        S += nb ? cq : 0;
-        n0 += nb & static_cast<int>(lo_ == 0);
+      // branch-free, four candidates per trip: their twelve 16-byte LDS reads (wave-uniform
+      // addresses: broadcasts) are issued together from clamped positions, the tests are
+      // arithmetic. (The first version -- early-outs between dependent LDS reads -- ran at
+      // ~1500 cycles per candidate; eight scalar arrays still at ~1000.)
+#ifdef EPOS_GC_ABL_NOLOOP       // ablation (tools/): everything but the pair tests
+      if (cnt < 0)
+#endif
+      for (int j0 = sub; j0 < cnt; j0 += 4 * GC_W) {
+        GcCand r[4];
+        int okj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u * GC_W;
+          okj[u] = j < cnt;
+          r[u] = c_rec[okj[u] ? j : sub];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int lo_ = (r[u].ol >> 30) & 3;
+          const int32_t co = r[u].ol & 0x3fffffff, cq = r[u].q;
+          const double dx = px - r[u].x, dy = py - r[u].y;
+          const double dX = pX - r[u].X, dY = pY - r[u].Y, dZ = pZ - r[u].Z;
+          const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
+          const int nb = okj[u] & static_cast<int>(act) & static_cast<int>(lo_ != 2) &
+                         static_cast<int>(co != p) & static_cast<int>(d2 <= r2);
+          deg += nb;
+          S += nb ? cq : 0;
+          n0 += nb & static_cast<int>(lo_ == 0);
+        }
       }
       __syncthreads();
     }
@@ -1084,11 +1126,12 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
     const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
     const int32_t* __restrict__ max_models, EposFitParams prm, int max_k, Work w,
     const uint8_t* __restrict__ lab_all, double* poses, double* scores,
-    int32_t* num_models, int32_t* labels_all) {
-  const int s = blockIdx.x;
+    int32_t* num_models, int32_t* labels_all, int lo_launch, int n_lo) {
+  const int s = blockIdx.y;
+  const int g = blockIdx.x;          // LO_G workgroups refit together; workgroup 0 accepts
   const int t = threadIdx.x;
   const int state = w.state[s];
-  if (state == 0) return;                                  // block-uniform
+  if (state == 0) return;                                  // uniform over the slot
   int want = max_models[s];
   if (want < 0 || want > max_k) want = max_k;
   const int k = num_models[s];
@@ -1096,9 +1139,7 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
   const int64_t n = slot_base[s + 1] - base;
   int32_t* active = w.active + base;
   const int64_t n_active = w.n_active[s];
-  __shared__ double s_red[4];
-  __shared__ double s_red27[4 * 27];
-  __shared__ int s_cnt[4];
+  __shared__ LoLds s_lo;
   __shared__ int s_inl[4], s_new[4];
   const int lane = t & 63, wave = t >> 6;
   const double* xy = xy_all + 2 * base;
@@ -1113,15 +1154,22 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
   int best_count = w.cur_count[s];
   if (state == 1) {
     const uint8_t* lab = lab_all + base;
+    LoSync sy;
+    sy.cnt = w.lo_cnt + static_cast<int64_t>(s) * n_lo + lo_launch;
+    sy.data = w.lo_data + static_cast<int64_t>(s) * (2 * LO_G * 4 * LO_NV);
+    sy.timeout = w.lo_timeout;
+    sy.g = g;
+    sy.epoch = 0;
     // the first step on the labelled set starts from the accepted pose (its score is
     // known); from then on each pass scores a candidate and steps from it
     double cand[12];
-    int fail = gn_step_block(pose, K, xy, xyz, active, n_active, thr2, t, s_red27, cand, lab, 1);
+    int fail = lo_pass<false>(pose, K, xy, xyz, active, n_active, thr2, t, sy, &s_lo, lab, 1,
+                              nullptr, nullptr, cand);
     for (int li = 0; li < prm.lo_iters && !fail; ++li) {
       double sc, cand2[12];
       int cnt;
-      const int fail2 = score_and_step_block(cand, K, xy, xyz, active, n_active, thr2, t,
-                                             s_red27, s_red, s_cnt, lab, 1, &sc, &cnt, cand2);
+      const int fail2 = lo_pass<true>(cand, K, xy, xyz, active, n_active, thr2, t, sy, &s_lo,
+                                      lab, 1, &sc, &cnt, cand2);
       if (!(sc > best_score)) break;
       const double gain = sc - best_score;
       best_score = sc; best_count = cnt;
@@ -1130,6 +1178,7 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
       if (!(gain > LO_MIN_GAIN * sc)) break;
     }
   }
+  if (g != 0) return;          // the siblings only helped with the sums
   if (best_count < prm.min_point_number) {
     if (t == 0) round_failed(s, w, prm, want, k, n_active);
     return;
@@ -1365,8 +1414,10 @@ __global__ __launch_bounds__(256) void pearl_refit(
   const int s = blockIdx.x;
   if (!w.pearl_state[s]) return;
   const int t = threadIdx.x;
-  __shared__ double s_red27[4 * 27];
+  __shared__ LoLds s_lo;
   __shared__ int s_cnt[4];
+  LoSync sy;                         // one workgroup: the sums stay in LDS
+  sy.cnt = nullptr; sy.data = nullptr; sy.timeout = nullptr; sy.g = 0; sy.epoch = 0;
   const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
@@ -1388,7 +1439,8 @@ __global__ __launch_bounds__(256) void pearl_refit(
     __syncthreads();
     bool ok = false;
     if (c >= prm.min_point_number)                         // uniform
-      ok = !gn_step_block(pose, K, xy, xyz, nullptr, n, thr2, t, s_red27, next, lab, m);
+      ok = !lo_pass<false>(pose, K, xy, xyz, nullptr, n, thr2, t, sy, &s_lo, lab, m, nullptr,
+                           nullptr, next);
     if (t < 12) w.pearl_pose[(static_cast<int64_t>(s) * PEARL_MAX_K + m) * 12 + t] =
         ok ? next[t] : pose[t];
     moved |= ok;
@@ -1431,7 +1483,11 @@ struct Layout {
   int64_t words_total;
   int64_t cur_pose, cur_score, cur_count, state, tries, last_new, gq, lab_a, lab_b;
   int64_t pearl_pose, pearl_acc, pearl_state, pearl_moved;
+  int64_t lo_cnt, lo_data, lo_timeout;
 };
+
+// cooperating launches per call: select + refit of every round (max_k + 2 rounds at most)
+int lo_launches(int max_k) { return 2 * (max_k + 2); }
 
 Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   Layout L;
@@ -1454,6 +1510,9 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.gq = off; off = align_up(off + (n_cap + 1) * 4);
   L.lab_a = off; off = align_up(off + n_cap + 1);
   L.lab_b = off; off = align_up(off + n_cap + 1);
+  L.lo_cnt = off; off = align_up(off + static_cast<int64_t>(S + 1) * lo_launches(max_k) * 4);
+  L.lo_data = off; off = align_up(off + static_cast<int64_t>(S + 1) * 2 * LO_G * 4 * LO_NV * 8);
+  L.lo_timeout = off; off = align_up(off + 8);
   L.pearl_pose = off; off = align_up(off + (S + 1) * PEARL_MAX_K * 12 * 8);
   L.pearl_acc = off; off = align_up(off + (S + 1) * 4 * 8);
   L.pearl_state = off; off = align_up(off + (S + 1) * 4);
@@ -1492,12 +1551,16 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   w.lab_b = reinterpret_cast<uint8_t*>(wb + L.lab_b);
   w.yorder = yorder;
   w.ypos = ypos;
+  w.lo_cnt = reinterpret_cast<unsigned*>(wb + L.lo_cnt);
+  w.lo_data = reinterpret_cast<double*>(wb + L.lo_data);
+  w.lo_timeout = reinterpret_cast<int32_t*>(wb + L.lo_timeout);
   w.pearl_pose = reinterpret_cast<double*>(wb + L.pearl_pose);
   w.pearl_acc = reinterpret_cast<unsigned long long*>(wb + L.pearl_acc);
   w.pearl_state = reinterpret_cast<int32_t*>(wb + L.pearl_state);
   w.pearl_moved = reinterpret_cast<int32_t*>(wb + L.pearl_moved);
+  const int n_lo = lo_launches(max_k);
   hipLaunchKernelGGL(ransac_init, dim3(S), dim3(256), 0, st, slot_base, S, w, labels,
-                     num_models, p->min_point_number, n_capacity);
+                     num_models, p->min_point_number, n_capacity, n_lo);
   int rc = launch_status("ransac_init");
   if (rc) return rc;
   const dim3 hgrid(static_cast<unsigned>(ceil_div(p->max_iters, 4)), S);
@@ -1517,8 +1580,9 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
                        round, w);
     rc = launch_status("ransac_hypotheses");
     if (rc) return rc;
-    hipLaunchKernelGGL(ransac_select_lo, dim3(S), dim3(256), 0, st, xy, xyz, slot_base, Ks,
-                       max_models, *p, max_k, round, w, num_models);
+    hipLaunchKernelGGL(ransac_select_lo, dim3(LO_G, S), dim3(256), 0, st, xy, xyz, slot_base,
+                       Ks, max_models, *p, max_k, round, w, num_models, labels, 2 * round,
+                       n_lo);
     rc = launch_status("ransac_select_lo");
     if (rc) return rc;
     const uint8_t* lab_final = w.lab_a;
@@ -1533,9 +1597,9 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
         lab_final = out;
       }
     }
-    hipLaunchKernelGGL(ransac_refit_accept, dim3(S), dim3(256), 0, st, xy, xyz, slot_base,
-                       Ks, max_models, *p, max_k, w, lab_final, poses, scores, num_models,
-                       labels);
+    hipLaunchKernelGGL(ransac_refit_accept, dim3(LO_G, S), dim3(256), 0, st, xy, xyz,
+                       slot_base, Ks, max_models, *p, max_k, w, lab_final, poses, scores,
+                       num_models, labels, 2 * round + 1, n_lo);
     rc = launch_status("ransac_refit_accept");
     if (rc) return rc;
   }

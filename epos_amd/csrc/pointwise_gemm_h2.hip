@@ -368,7 +368,11 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
       // meant to hide under
       asm volatile("" : "+v"(x0), "+v"(x1));
       unsigned hh, mm;
+#ifdef EPOS_H2_ABL_NOSPLIT          // ablation (tools/bench_gemm_h2_abl.py): wrong results
+      hh = __float_as_uint(x0) ^ 0x3c003c00u; mm = __float_as_uint(x1) & 0x3bff3bffu;
+#else
       split_pair(x0, x1, sa, hh, mm);
+#endif
       nh[u] = hh; nm[u] = mm;
     };
     constexpr bool ISSUE = MODE <= 1;
@@ -379,7 +383,12 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
       constexpr int DMA = decltype(dma_tag)::value;
       constexpr int SPL = decltype(spl_tag)::value;
       mfma_f16(a, b, c);
-      if constexpr (ISSUE && DMA >= 0 && DMA < H2_NP) {
+#ifdef EPOS_H2_ABL_NODMA
+      constexpr bool kIssue = false;
+#else
+      constexpr bool kIssue = true;
+#endif
+      if constexpr (kIssue && ISSUE && DMA >= 0 && DMA < H2_NP) {
         __builtin_amdgcn_sched_barrier(0);
         issue_piece(kt + 4, s4, std::integral_constant<int, DMA>{},
                     std::integral_constant<bool, MODE == 1>{});
@@ -407,14 +416,18 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     if constexpr (MODE != 5) {
       // my reads of this stage are complete (fragments are in registers); my pieces of
       // tile kt+1 have landed once at most the later tiles' pieces are outstanding
+#ifndef EPOS_H2_ABL_NOBAR
       if (MODE <= 1) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
       else if (MODE == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       else if (MODE == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#endif
+#ifndef EPOS_H2_ABL_NOREAD
       read_a(s1);
       read_b(s1, std::integral_constant<int, 0>{});
       read_b(s1, std::integral_constant<int, 1>{});
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     // second half: blocks 2 (and 3); the next stage's A fragment is split behind the MFMAs
@@ -432,8 +445,10 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
       if constexpr (MODE != 5) split_unit(I3{});
     }
     if constexpr (MODE != 5) {
+#ifndef EPOS_H2_ABL_NOREAD
       read_b(s1, std::integral_constant<int, 2>{});
       if constexpr (LIVE == 4) read_b(s1, std::integral_constant<int, 3>{});
+#endif
       ah = nh; am = nm;
     }
   };

@@ -86,6 +86,7 @@ class EposNet(object):
     self.op_bytes = {}       # GEMM launches: algorithmic bytes (A + W + out + residual)
     self._graph = None
     self._graph_sparse = None
+    self._graph_alt, self.alt_skip = None, None   # measurement aid: see capture_alt()
     # Workspace of the persistent stream-K GEMM (partial-sum slabs + flags); one
     # per plan, because launches sharing it must be ordered on one stream.
     self._gemm_ws = torch.zeros(
@@ -861,12 +862,16 @@ class EposNet(object):
   def sync_current(self):
     torch.cuda.current_stream(self.dev).synchronize()
 
-  def run_plan(self, with_post=True, sparse=False):
+  def run_plan(self, with_post=True, sparse=False, skip_kinds=()):
     """sparse=False: the whole dense plan. sparse=True: trunk + object head +
-    object softmax/argmax only (the fragment heads follow per target object)."""
+    object softmax/argmax only (the fragment heads follow per target object).
+    skip_kinds: op kinds left out (capture_alt: the plan WITHOUT its GEMM / depthwise
+    launches, for the step decomposition of bench.py -- results are then meaningless)."""
     s = self._stream()
     if not sparse:
-      for _, fn in self.ops:
+      for name, fn in self.ops:
+        if self.op_kind.get(name) in skip_kinds:
+          continue
         fn(s)
       if with_post:
         for _, fn in self.post_ops:
@@ -975,6 +980,23 @@ class EposNet(object):
       self._graph = g
     return g
 
+  def capture_alt(self, skip_kinds):
+    """A second hipGraph of the dense plan without the launches of the given kinds
+    ('gemm', 'dw'); forward(use_graph=True) replays it while `alt_skip` is set. bench.py
+    times the same pipelined steps with it: step time - that time = what the left-out
+    kernels cost INSIDE the timed regime (overlap with the other plans included)."""
+    if skip_kinds is None:
+      self._graph_alt, self.alt_skip = None, None
+      return
+    torch.cuda.synchronize(self.dev)
+    side = torch.cuda.current_stream(self.dev)
+    if side == torch.cuda.default_stream(self.dev):
+      side = _capture_stream(self.dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+      self.run_plan(skip_kinds=tuple(skip_kinds))
+    self._graph_alt, self.alt_skip = g, tuple(skip_kinds)
+
   def forward(self, images=None, use_graph=False, sparse=False):
     """Runs the plan (logits + softmax/argmax post-ops) on the current stream and
     returns the prediction dict of ``model.predict`` (model.py:629-687) as views
@@ -986,12 +1008,27 @@ class EposNet(object):
         if self._graph_sparse is None:
           self.capture_graph(sparse=True)
         self._graph_sparse.replay()
+      elif self._graph_alt is not None:
+        self._graph_alt.replay()
       else:
         if self._graph is None:
           self.capture_graph()
         self._graph.replay()
     else:
       self.run_plan(sparse=sparse)
+    B, h, w = self.B, self.out_h, self.out_w
+    O, F = self.num_objs, self.num_frags
+    return {
+        W.PRED_OBJ_CONF: self.logits[W.PRED_OBJ_CONF],
+        W.PRED_OBJ_LABEL: self.obj_label,
+        W.PRED_FRAG_CONF: self.logits[W.PRED_FRAG_CONF].view(B, h, w, O, F),
+        W.PRED_FRAG_LOC: self.logits[W.PRED_FRAG_LOC].view(B, h, w, O, F, 3),
+    }
+
+  def outputs(self):
+    """The prediction dict of the LAST dense run as views of the plan's HBM buffers (no
+    launch): what forward() returned, for callers that read the heads after a pipeline
+    step (infer.py --vis / --save_corresp)."""
     B, h, w = self.B, self.out_h, self.out_w
     O, F = self.num_objs, self.num_frags
     return {

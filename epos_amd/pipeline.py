@@ -60,6 +60,7 @@ class EposPipeline(object):
     self.tau_a, self.tau_b = corr_min_obj_conf, corr_min_frag_rel_conf
     self.max_slots = max_slots or batch * num_objs
     self.max_k = max_instances
+    self._warned_cap = False
     centers, sizes = _corresp.pack_model_store(model_store, num_objs, num_frags)
     self.obj_ids = list(model_store.dp_model['obj_ids'])
     self.corr = _corresp.CorrExtractor(
@@ -147,9 +148,16 @@ class EposPipeline(object):
         if task_type == LOCALIZATION:
           if obj_id not in t:                          # corresp.py:42-43
             continue
-          wants.append(min(int(t[obj_id]), self.max_k))
+          if int(t[obj_id]) > self.max_k:
+            # never clamp silently (a frame with more instances of one object than the
+            # plan was sized for would lose poses): the caller sizes max_instances from
+            # the frames it is going to feed (infer.py does), or caps the counts itself
+            raise _lib.EposError(
+                'image %d: %d instances of object %d requested, the pipeline was built '
+                'with max_instances=%d' % (im, int(t[obj_id]), obj_id, self.max_k))
+          wants.append(int(t[obj_id]))
         else:
-          wants.append(-1)
+          wants.append(-1)                             # all found, up to max_instances
         slots.append((im, obj_id))
     _corresp.check_obj_ids([o for _, o in slots], self.O)
     return slots, wants
@@ -250,6 +258,12 @@ class EposPipeline(object):
       self.last_totals = self._view(rh, rl, 'totals')[:S * 2].numpy().reshape(
           S, 2).copy()
       for s, (im, obj_id) in enumerate(slots):
+        if wants[s] < 0 and int(nm[s]) >= max_k and not self._warned_cap:
+          # "all found" (detection) stopped at the plan's instance cap: say so, once
+          import warnings
+          warnings.warn('object %d: %d instances found = the cap this pipeline was built '
+                        'with (max_instances); more may exist' % (obj_id, int(nm[s])))
+          self._warned_cap = True
         for i in range(int(nm[s])):
           poses_out.append({
               'scene_id': scene_ids[im] if scene_ids is not None else 0,

@@ -399,10 +399,15 @@ typedef struct EposFitParams {
 void epos_fit_params_default(EposFitParams* p);
 
 /* Host-pointer drop-in for pyprogressivex.find6DPoses: xy f64[n,2] (pixels),
- * xyz f64[n,3] (mm), K f64[9] row-major. Outputs (caller-owned): poses
- * f64[max_k*12] = k blocks of row-major [R|t] 3x4 (the reference stacks them as
- * [3k,4], infer.py:490-495), labels i32[n] (instance index or -1), scores
- * f64[max_k]. Returns k >= 0 (0 <=> the reference's `pose_ests is None`) or < 0. */
+ * xyz f64[n,3] (mm), K f64[9] row-major. Outputs (caller-owned):
+ *   poses  f64[max_k*12]: instance j occupies poses[12*j .. 12*j+11] as
+ *          R row-major in [0..8] (R[r][c] = poses[12*j + 3*r + c]) followed by
+ *          t in [9..11] -- NOT a row-major 3x4 [R|t]: reading the 12 doubles as a 3x4
+ *          matrix gives wrong poses. (The reference's module returns the instances
+ *          stacked as a [3k,4] array which infer.py:490-495 slices into R, t; the binding
+ *          in INTEGRATION.md rebuilds exactly that from this layout.)
+ *   labels i32[n] (instance index or -1), scores f64[max_k].
+ * Returns k >= 0 (0 <=> the reference's `pose_ests is None`) or < 0. */
 int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
                       const double* K, const EposFitParams* p, uint64_t seed,
                       double* poses_out, int32_t* labels_out, double* scores_out,
@@ -414,8 +419,17 @@ int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
  *   Ks f64[S,9]; max_models i32[S] (per-slot num_instances, <= max_k)
  *   seeds u64[S]
  *   work: scratch of epos_fit_workspace_bytes(S, N_capacity, p) bytes
- * Outputs: poses f64[S,max_k,12], scores f64[S,max_k], num_models i32[S],
- *          labels i32[N] (instance index within the slot or -1). */
+ * Outputs: poses f64[S,max_k,12] (per instance: R row-major [0..8], then t [9..11], as
+ *          above), scores f64[S,max_k], num_models i32[S], labels i32[N] (instance index
+ *          within the slot or -1).
+ * PRECONDITION (not checked): the rows of every slot are in image-row order --
+ * xy[.,1] non-decreasing within [slot_base[s], slot_base[s+1]) -- which is the raster order
+ * epos_corr_fill writes. The spatial-coherence sweeps and the joint refinement find a
+ * point's neighbours in a window of rows around it and stop at the first row farther than
+ * neighborhood_ball_radius: with unsorted rows neighbourhoods are silently truncated and
+ * the poses change. Callers with arbitrary row order use epos_find6d_poses (it sorts
+ * internally and keeps the caller's order for PROSAC) or sort first; with
+ * spatial_coherence_weight == 0 (or gc_sweeps == 0) and max_k == 1 no order is needed. */
 int64_t epos_fit_workspace_bytes(int S, int64_t n_capacity, const EposFitParams* p,
                                  int32_t max_k);
 int epos_find6d_poses_device(const double* xy, const double* xyz,
@@ -453,7 +467,8 @@ void epos_pnp_ransac_params_default(EposPnpRansacParams* p);
 
 /* Host-pointer drop-in: xy f64[n,2] (imagePoints), xyz f64[n,3] (objectPoints), K f64[9]
  * row-major (fx, fy, cx, cy are used, as by OpenCV without distortion). Outputs
- * (caller-owned): pose_out f64[12] = row-major [R | t] (R = Rodrigues(rvec) of the
+ * (caller-owned): pose_out f64[12] = R row-major in [0..8], then t in [9..11] (the layout of
+ * epos_find6d_poses, NOT a row-major 3x4; R = Rodrigues(rvec) of the
  * reference), inlier_mask_out u8[n], info_out i32[4] or NULL = {index of the winning set,
  * its inlier count, the final iteration cap, sets evaluated}. Returns 1 (pose found),
  * 0 (`pose_est_success` false) or < 0. */
@@ -462,7 +477,8 @@ int epos_solve_pnp_ransac(const double* xy, const double* xyz, int64_t n, const 
                           uint8_t* inlier_mask_out, int32_t* info_out);
 
 /* Batched device entry (slots as for epos_find6d_poses_device), all buffers [device]:
- * poses f64[S,12], success i32[S], inlier_mask u8[N], info i32[S,4] or NULL;
+ * poses f64[S,12] (R row-major [0..8], t [9..11]), success i32[S], inlier_mask u8[N],
+ * info i32[S,4] or NULL;
  * work = epos_pnp_ransac_workspace_bytes(S, N_capacity, p) bytes. Nothing synchronises. */
 int64_t epos_pnp_ransac_workspace_bytes(int S, int64_t n_capacity,
                                         const EposPnpRansacParams* p);

@@ -51,6 +51,11 @@ from epos_amd import synthetic, weights                                # noqa: E
 PARAMS_FILENAME = 'params.yml'   # common.py
 
 
+# "all found" (num_instances = -1, detection) needs a bound for the static buffers; a frame
+# that reaches it is reported (EposPipeline.collect warns once per run).
+DETECTION_INSTANCE_CAP = 16
+
+
 def str2bool(v):
   return str(v).lower() in ('1', 'true', 'yes', 'y')
 
@@ -437,6 +442,12 @@ def main(argv=None):
     raise NotImplementedError(
         '--vis_gt_frag_fields needs the ground-truth fragment fields of the training '
         'pipeline (datagen.py:478-544), which the inference reader does not build.')
+  if args.vis and args.vis_gt_obj_labels:
+    # the GT label map comes from the instance masks of the training reader
+    # (datagen.py:478-544); the inference reader holds none, so that tile is left out --
+    # said once here instead of silently (scripts/infer.py:150-291 draws it)
+    print('note: --vis_gt_obj_labels has no ground-truth label map at inference; the tile '
+          'is omitted (use --vis_gt_obj_labels=False to silence this)', file=sys.stderr)
   checkpoint_dir = os.path.join(model_dir, 'train')             # infer.py:570
   infer_dir = os.path.join(model_dir, 'infer')
   os.makedirs(infer_dir, exist_ok=True)
@@ -518,7 +529,16 @@ def main(argv=None):
     store.models = ply.load_models(bop, args.dataset, 'eval',
                                    obj_ids=store.dp_model['obj_ids'])
   B = args.batch
-  max_inst = args.max_instances_to_fit or 4
+  # Instances per object (infer.py:456-468 of the reference): localization fits as many as
+  # the frame's annotations hold -- the plan is sized for the largest count among the frames
+  # read, nothing is clamped; detection ("all found", -1) is bounded by a stated cap, and
+  # reaching it is reported. --max_instances_to_fit lowers both, as in the reference.
+  if args.task_type == pipeline.LOCALIZATION:
+    max_inst = max([1] + [int(c) for f in frames for c in f[4].values()])
+  else:
+    max_inst = DETECTION_INSTANCE_CAP
+  if args.max_instances_to_fit is not None:
+    max_inst = max(1, min(max_inst, args.max_instances_to_fit))
   depth = max(1, args.pipeline_depth)
   if operator_path or args.save_corresp or args.vis:
     depth = 1                      # those paths read the plan's buffers after the step
@@ -544,7 +564,7 @@ def main(argv=None):
         poses_all.append(p)
     if args.save_corresp:
       from epos_amd import corresp as ecorresp
-      pred = pipe.net.forward()
+      pred = pipe.net.outputs() if not pipe.sparse_heads else pipe.net.forward()
       for b, f in enumerate(chunk[:n_real]):
         c = ecorresp.establish_many_to_many(
             pred['pred_obj_conf'][b], pred['pred_frag_conf'][b],
@@ -555,7 +575,8 @@ def main(argv=None):
                              rt.get('total', 0.0))
     if args.vis:                                # infer.py:540-552, <model>/vis (:577)
       from epos_amd import vis as evis
-      pred = {k: v.cpu().numpy() for k, v in pipe.net.forward().items()}
+      pred = {k: v.cpu().numpy() for k, v in
+              (pipe.net.outputs() if not pipe.sparse_heads else pipe.net.forward()).items()}
       flags = {k: getattr(args, k) for k in vars(args) if k.startswith('vis_')}
       for b, f in enumerate(chunk[:n_real]):
         est = [p for p in poses if (p['scene_id'], p['im_id']) == (f[0], f[1])]

@@ -58,9 +58,11 @@
  * parallel HIP kernels can reproduce them bit for bit:
  *   - hypothesis scoring (one wavefront per hypothesis): 64 strided partial sums
  *     (partial l takes items l, l+64, ...) combined by a 6-level xor butterfly;
- *   - local optimisation (one 256-thread workgroup per object): 256 strided
- *     partial sums (partial q takes items q, q+256, ...), a 6-level xor butterfly
- *     inside each group of 64 and then (g0 + g1) + (g2 + g3).
+ *   - local optimisation of a proposal (round 3: FOUR 256-thread workgroups per object):
+ *     1024 strided partial sums (partial q takes items q, q+1024, ...), a 6-level xor
+ *     butterfly inside each group of 64, (g0 + g1) + (g2 + g3) inside each group of 256,
+ *     then (W0 + W1) + (W2 + W3); the joint refinement (one workgroup per object) keeps
+ *     256 partials and stops after the second level.
  * The projection uses ONE reciprocal per point (iz = 1/Z, then multiplications) and
  * the MSAC term is 1 - e2 * (1/thr2): a division costs the GPU about ten fp64
  * instructions. Only + - * / sqrt are used (correctly rounded on both sides);
@@ -371,12 +373,21 @@ static void tree256(double* part, int stride, int nvals) {
     part[v] = (part[v] + part[64 * stride + v]) + (part[128 * stride + v] + part[192 * stride + v]);
 }
 
+/* 1024 partials (round 3: four workgroups of 256 per object in the local optimisation):
+ * tree256 inside each group of 256, then (W0 + W1) + (W2 + W3) */
+#define LO_P 1024
+static void tree1024(double* part, int stride, int nvals) {
+  for (int g = 0; g < 4; ++g) tree256(part + (size_t)g * 256 * stride, stride, nvals);
+  for (int v = 0; v < nvals; ++v)
+    part[v] = (part[v] + part[256 * stride + v]) + (part[512 * stride + v] + part[768 * stride + v]);
+}
+
 /* MSAC score and inlier count of a pose over the index list idx[0..m);
- * P = 64 (hypothesis scoring) or 256 (local optimisation) strided partials */
+ * P = 64 (hypothesis scoring), 256 or 1024 (local optimisation) strided partials */
 static double score_pose_p(const double* pose, const double* K, const double* xy,
                            const double* xyz, const int32_t* idx, int64_t m,
                            double thr2, int32_t* count, int P) {
-  double part[256];
+  double part[LO_P];
   const double inv_thr2 = 1.0 / thr2;
   int32_t cnt = 0;
   for (int l = 0; l < P; ++l) {
@@ -389,7 +400,9 @@ static double score_pose_p(const double* pose, const double* K, const double* xy
     }
     part[l] = acc;
   }
-  if (P == 64) tree64(part, 1, 1); else tree256(part, 1, 1);
+  if (P == 64) tree64(part, 1, 1);
+  else if (P == 256) tree256(part, 1, 1);
+  else tree1024(part, 1, 1);
   *count = cnt;
   return part[0];
 }
@@ -398,10 +411,10 @@ static double score_pose(const double* pose, const double* K, const double* xy,
                          double thr2, int32_t* count) {
   return score_pose_p(pose, K, xy, xyz, idx, m, thr2, count, 64);
 }
-static double score_pose256(const double* pose, const double* K, const double* xy,
+static double score_pose_lo(const double* pose, const double* K, const double* xy,
                             const double* xyz, const int32_t* idx, int64_t m,
                             double thr2, int32_t* count) {
-  return score_pose_p(pose, K, xy, xyz, idx, m, thr2, count, 256);
+  return score_pose_p(pose, K, xy, xyz, idx, m, thr2, count, LO_P);
 }
 
 /* b^e by binary exponentiation (multiplications only: the same bits everywhere) */
@@ -521,13 +534,14 @@ static int solve6(double H[6][6], const double* g, double* x) {
  * `next` */
 static int gn_step_sel(const double* pose, const double* K, const double* xy,
                        const double* xyz, const int32_t* idx, int64_t m, double thr2,
-                       const uint8_t* lab, int want, double* next) {
-  /* 27 accumulated quantities: 21 upper-triangular H entries + 6 of g */
-  static double part[256 * 27];
-  for (int l = 0; l < 256; ++l) {
+                       const uint8_t* lab, int want, double* next, int P) {
+  /* 27 accumulated quantities: 21 upper-triangular H entries + 6 of g; P = 1024 strided
+   * partials in the local optimisation of a proposal, 256 in the joint refinement */
+  static double part[LO_P * 27];
+  for (int l = 0; l < P; ++l) {
     double acc[27];
     for (int v = 0; v < 27; ++v) acc[v] = 0.0;
-    for (int64_t i = l; i < m; i += 256) {
+    for (int64_t i = l; i < m; i += P) {
       const int32_t p = idx[i];
       double e2, Xc[3], r[2];
       if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) continue;
@@ -559,7 +573,7 @@ static int gn_step_sel(const double* pose, const double* K, const double* xy,
     }
     for (int v = 0; v < 27; ++v) part[l * 27 + v] = acc[v];
   }
-  tree256(part, 27, 27);
+  if (P == 256) tree256(part, 27, 27); else tree1024(part, 27, 27);
   double H[6][6], g[6], x[6];
   int v = 0;
   for (int a = 0; a < 6; ++a)
@@ -587,7 +601,7 @@ static int gn_step_sel(const double* pose, const double* K, const double* xy,
 static int gn_step(const double* pose, const double* K, const double* xy,
                    const double* xyz, const int32_t* idx, int64_t m, double thr2,
                    double* next) {
-  return gn_step_sel(pose, K, xy, xyz, idx, m, thr2, NULL, 0, next);
+  return gn_step_sel(pose, K, xy, xyz, idx, m, thr2, NULL, 0, next, LO_P);
 }
 
 /* ------------------------------------------------ joint refinement (PEARL) -- */
@@ -689,7 +703,7 @@ static void pearl_refine(double* poses, int k, const double* K, const double* xy
       for (int64_t p = 0; p < n; ++p) cntm += lab[p] == m;
       if (cntm < prm->min_point_number) continue;
       double next[12];
-      if (!gn_step_sel(poses + 12 * m, K, xy, xyz, all, n, thr2, lab, m, next)) {
+      if (!gn_step_sel(poses + 12 * m, K, xy, xyz, all, n, thr2, lab, m, next, 256)) {
         memcpy(cand + 12 * m, next, sizeof(next));
         moved = 1;
       }
@@ -806,14 +820,14 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
       orthonormalize(best_pose);
       {
         int32_t cnt;
-        best_score = score_pose256(best_pose, K, xy, xyz, active, n_active, thr2, &cnt);
+        best_score = score_pose_lo(best_pose, K, xy, xyz, active, n_active, thr2, &cnt);
         best_count = cnt;
       }
       for (int li = 0; li < prm->lo_iters; ++li) {
         double cand[12];
         if (gn_step(best_pose, K, xy, xyz, active, n_active, thr2, cand)) break;
         int32_t cnt;
-        const double sc = score_pose256(cand, K, xy, xyz, active, n_active, thr2, &cnt);
+        const double sc = score_pose_lo(cand, K, xy, xyz, active, n_active, thr2, &cnt);
         if (!(sc > best_score)) break;
         const double gain = sc - best_score;
         best_score = sc; best_count = cnt;
@@ -826,9 +840,9 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
         gc_label(best_pose, K, xy, xyz, active, n_active, n, prm, lab, lab_tmp, gq);
         for (int li = 0; li < prm->lo_iters; ++li) {
           double cand[12];
-          if (gn_step_sel(best_pose, K, xy, xyz, active, n_active, thr2, lab, 1, cand)) break;
+          if (gn_step_sel(best_pose, K, xy, xyz, active, n_active, thr2, lab, 1, cand, LO_P)) break;
           int32_t cnt;
-          const double sc = score_pose256(cand, K, xy, xyz, active, n_active, thr2, &cnt);
+          const double sc = score_pose_lo(cand, K, xy, xyz, active, n_active, thr2, &cnt);
           if (!(sc > best_score)) break;
           const double gain = sc - best_score;
           best_score = sc; best_count = cnt;

@@ -282,3 +282,44 @@ def test_infer_two_ranks_with_an_odd_frame_count(tmp_path):
     assert (x['im_id'], x['obj_id']) == (y['im_id'], y['obj_id'])
     np.testing.assert_array_equal(x['R'], y['R'])
     np.testing.assert_array_equal(x['t'], y['t'])
+
+
+@pytest.mark.gpu
+def test_infer_eight_ranks_cover_32_frames_exactly_once(tmp_path):
+  """The C3 arrangement as a dry run on the one-GPU box: 32 frames over EIGHT torchrun
+  ranks (4 per rank, gloo for the gather, every rank on device 0). Every frame must be
+  processed by exactly one rank and the merged BOP CSV must equal the single-rank CSV row
+  for row (poses bit for bit) -- what tools/run_scale.sh will exercise over RCCL the day an
+  8-GPU node runs it."""
+  import socket
+  with socket.socket() as sck:
+    sck.bind(('127.0.0.1', 0))
+    port = sck.getsockname()[1]
+  (tmp_path / 'toy').mkdir()
+  (tmp_path / 'toy' / 'params.yml').write_text('infer_crop_size: "128,96"\n')
+  env = dict(os.environ, TF_MODELS_PATH=str(tmp_path), EPOS_DIST_BACKEND='gloo',
+             EPOS_FORCE_DEVICE='0')
+  common = [os.path.join(ROOT, 'infer.py'), '--model=toy', '--synthetic', '32',
+            '--num_objs', '3', '--batch', '4']
+  out = subprocess.run(
+      [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+       '--nproc-per-node', '8', '--master-addr', '127.0.0.1', '--master-port',
+       str(port)] + common + ['--infer_name', 'eight'],
+      env=env, capture_output=True, text=True, timeout=1500)
+  assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+  one = subprocess.run([sys.executable] + common + ['--infer_name', 'one'],
+                       env=env, capture_output=True, text=True, timeout=900)
+  assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+  from epos_amd import bop_io
+  a = bop_io.load_bop_results(str(tmp_path / 'toy' / 'infer' / 'estimated-poses_eight.csv'))
+  b = bop_io.load_bop_results(str(tmp_path / 'toy' / 'infer' / 'estimated-poses_one.csv'))
+  key = lambda r: (r['im_id'], r['obj_id'], r['score'])      # noqa: E731
+  assert len(a) == len(b) and len(a) > 0
+  assert len({r['im_id'] for r in b}) > 16                  # poses all over the 32 frames
+  seen = {}
+  for x, y in zip(sorted(a, key=key), sorted(b, key=key)):
+    assert (x['im_id'], x['obj_id']) == (y['im_id'], y['obj_id'])
+    np.testing.assert_array_equal(x['R'], y['R'])
+    np.testing.assert_array_equal(x['t'], y['t'])
+    seen[(x['im_id'], x['obj_id'], x['score'])] = seen.get((x['im_id'], x['obj_id'], x['score']), 0) + 1
+  assert max(seen.values()) == 1                            # no frame fitted twice

@@ -67,6 +67,21 @@ def gemm_family():
 ALGO_GFLOP_C2 = 455.0           # SURVEY.md App. A, per image
 
 
+def workload_name(args, B):
+  """BASELINE.json's config the flags describe (C2 is the metric's; the others are the
+  parity-test configurations, benched for BASELINE.md's table)."""
+  if args.model_variant == 'resnet_v1_101_beta':
+    return 'C5 (LM-O-shaped, ResNet-v1-101-beta, %d objects, batch %d)' % (args.num_objs, B)
+  if (args.height, args.width) == (540, 720) and args.num_objs == 30:
+    return 'C4 (T-LESS-shaped 720x540, 30 objects, %d instances per target object)' % args.instances
+  if (args.height, args.width) == (480, 640) and args.num_objs == 1:
+    return 'C1 (one object) on the GPU path'
+  if (args.height, args.width) == (480, 640) and args.num_objs == 21:
+    return ('C2' if B == 1 else 'C3 per-GPU shard (batch %d per GPU)' % B if B == 4
+            else 'C2-shaped, batch %d per GPU' % B)
+  return 'custom, batch %d per GPU' % B
+
+
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -80,6 +95,9 @@ def parse_args():
   ap.add_argument('--num-objs', type=int, default=21)
   ap.add_argument('--num-frags', type=int, default=64)
   ap.add_argument('--objs-per-image', type=int, default=5)
+  ap.add_argument('--instances', type=int, default=1,
+                  help='instances requested per target object (1 = C2/C3/C5: GC-RANSAC only; '
+                       '> 1 = the multi-instance search of config C4, T-LESS-like)')
   ap.add_argument('--model-variant', default='xception_65',
                   choices=['xception_65', 'resnet_v1_101_beta'],
                   help='backbone (the headline workload C2 is xception_65; '
@@ -390,7 +408,7 @@ def main():
   depth = max(1, args.pipeline_depth)
   pipes = [pipeline.EposPipeline(
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
-      capacity=1 << 21, max_instances=1, device=dev,
+      capacity=1 << 21, max_instances=max(1, args.instances), device=dev,
       use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads,
       model_options=mo, fitting_method=args.fitting_method)
            for j in range(depth)]
@@ -401,7 +419,8 @@ def main():
   for j in range(n_pool):
     idx = [rank * 100000 + j * B + b for b in range(B)]
     imgs = np.stack([synthetic.image(i, args.height, args.width) for i in idx])
-    tg = [synthetic.targets(i, args.num_objs, args.objs_per_image) for i in idx]
+    tg = [{o: args.instances for o in
+           synthetic.targets(i, args.num_objs, args.objs_per_image)} for i in idx]
     pool.append((torch.from_numpy(imgs).to(dev), tg, idx))
   Ks = np.tile(synthetic.YCBV_K, (B, 1, 1))
   lib = _lib.load()
@@ -433,7 +452,8 @@ def main():
       local += inflight.pop(0).collect()[0]
     # rank-independent record capacity: every target object of every image of the
     # `count` steps, two instances each
-    return edist.gather_poses(local, max(1, count * B * args.objs_per_image * 2))
+    return edist.gather_poses(local, max(1, count * B * args.objs_per_image * 2 *
+                                         max(1, args.instances)))
 
   # Set-up, not a step: every plan captures its hipGraph on first use, so each of the
   # `depth` plans is exercised once here (otherwise plans beyond the warm-up count
@@ -464,8 +484,7 @@ def main():
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
       'config': {
-          'workload': ('C2' if B == 1 else 'C3 per-GPU shard (batch %d per GPU)' % B if
-                       B == 4 else 'batch %d per GPU' % B) +
+          'workload': workload_name(args, B) +
                       ': synthetic %dx%d RGB, %s random-init ' % (
                           args.width, args.height, args.model_variant) +
                       '(reference initialisers, randomised BN statistics, logits '
@@ -510,8 +529,8 @@ def main():
   result['pipeline_depth'] = depth
   result['fit'] = {'method': args.fitting_method, 'max_iters': int(fitp.max_iters),
                    'lo_iters': int(fitp.lo_iters), 'gc_sweeps': int(fitp.gc_sweeps),
-                   'pearl_iters': int(fitp.pearl_iters), 'max_instances': 1,
-                   'rounds_per_step': 1}
+                   'pearl_iters': int(fitp.pearl_iters), 'max_instances': args.instances,
+                   'rounds_per_step': args.instances + (2 if args.instances > 1 else 0)}
   # Decomposition of the TIMED step (same pipelined regime, same steps): the plans' graphs
   # are re-captured without their GEMM / depthwise launches and the same `steps` steps are
   # timed again; step - that = what those kernels cost inside the step, overlap with the

@@ -36,6 +36,7 @@ class PointwiseArgs(ctypes.Structure):
       # ABI 5: fp16-pair GEMM (include/epos_hip.h)
       ('Wh', vp), ('a_amax', vp), ('a_amax2', vp),
       ('a_gain', ctypes.c_float), ('a_bias', ctypes.c_float),
+      ('a_presplit', ctypes.c_int32),
       ('c_amax', vp),
   ]
 
@@ -49,6 +50,9 @@ class DepthwiseArgs(ctypes.Structure):
       ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32), ('C', ctypes.c_int32),
       ('stride', ctypes.c_int32), ('rate', ctypes.c_int32),
       ('relu_in', ctypes.c_int32), ('relu_out', ctypes.c_int32),
+      # ABI 5: fp16-pair output (include/epos_hip.h)
+      ('y_h2', ctypes.c_int32), ('x_amax', vp), ('x_amax2', vp),
+      ('gain', ctypes.c_float), ('bias0', ctypes.c_float),
   ]
 
 

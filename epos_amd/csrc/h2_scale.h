@@ -1,0 +1,54 @@
+// fp16-pair representation shared by the depthwise kernels (which can write their output
+// already split) and the fp16-pair GEMM (pointwise_gemm_h2.hip): the power-of-two scale of
+// a tensor from the absmax slot(s) that bound it, and the split of scaled values.
+#pragma once
+#include "common.h"
+
+namespace epos {
+namespace {
+
+typedef _Float16 h2_f16x2 __attribute__((ext_vector_type(2)));
+typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
+
+// Scale of a tensor from the bound in its absmax slot(s) (include/epos_hip.h): a power of
+// two s with s * bound in [2^14, 2^15) (fp16 overflows at 65520), and its inverse. bound =
+// gain * max(slot, slot2) + bias (gain == 0 reads as 1, 0). A non-finite bound (an Inf / NaN
+// upstream) gives s = 1: such rows come out non-finite, the others right. Wave-wide; every
+// lane returns the same values.
+__device__ __forceinline__ void h2_scale(const unsigned* amax, const unsigned* amax2,
+                                         float gain, float bias, int lane, float& s,
+                                         float& inv) {
+  unsigned v = amax[lane];
+  if (amax2) {
+    const unsigned v2 = amax2[lane];
+    v = v2 > v ? v2 : v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned w = __shfl_xor(v, o, 64);
+    v = w > v ? w : v;
+  }
+  float bound = __uint_as_float(v);
+  if (gain != 0.f) bound = gain * bound + bias;
+  const unsigned e = __float_as_uint(bound) >> 23;            // bound >= 0: no sign bit
+  int sb = 268 - static_cast<int>(e);                         // 2^(14 - (e - 127)), biased
+  sb = sb > 253 ? 253 : sb;
+  if (e >= 255u) sb = 127;
+  s = __uint_as_float(static_cast<unsigned>(sb) << 23);
+  inv = __uint_as_float(static_cast<unsigned>(254 - sb) << 23);
+}
+
+// two fp32 values -> packed (hi, hi) and (mid, mid) fp16 pairs; s = the tensor's scale:
+//   t = x * s, hi = rn_fp16(t), mid = rn_fp16((t - hi) * 2^11)        (t - hi exact)
+__device__ __forceinline__ void h2_split_pair(float x0, float x1, float s, unsigned& hi,
+                                              unsigned& mid) {
+  const h2_f32x2 t = {x0 * s, x1 * s};
+  const h2_f16x2 h = __builtin_convertvector(t, h2_f16x2);        // v_cvt_pk_f16_f32 (RNE)
+  const h2_f32x2 r = (t - __builtin_convertvector(h, h2_f32x2)) * 2048.f;
+  const h2_f16x2 m = __builtin_convertvector(r, h2_f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  mid = __builtin_bit_cast(unsigned, m);
+}
+
+}  // namespace
+}  // namespace epos

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "h2_scale.h"
 
 namespace epos {
 namespace {
@@ -20,6 +21,20 @@ __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f),
                      fmaxf(v.w, 0.f));
 }
+// fp16-pair form of four outputs (EposDepthwiseArgs.y_h2): the same 16 bytes hold
+// [hi hi hi hi | mid mid mid mid] of y * s for the fp16-pair GEMM that reads them as its A
+typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_h2(float* p, float4 v, float s) {
+  dw_u32x4 o;
+  unsigned h0, h1, m0, m1;
+  h2_split_pair(v.x, v.y, s, h0, m0);
+  h2_split_pair(v.z, v.w, s, h1, m1);
+  o[0] = h0; o[1] = h1; o[2] = m0; o[3] = m1;
+  *reinterpret_cast<dw_u32x4*>(p) = o;
+}
+__device__ __forceinline__ void st4_any(float* p, float4 v, bool h2, float s) {
+  if (h2) st4_h2(p, v, s); else st4(p, v);
+}
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y),
                      fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
@@ -33,6 +48,9 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
                                                            int c4n,
                                                            int64_t total) {
   const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const bool h2 = p.y_h2 != 0;                 // uniform
+  float hs = 1.f, hinv;
+  if (h2) h2_scale(p.x_amax, p.x_amax2, p.gain, p.bias0, threadIdx.x & 63, hs, hinv);
   if (id >= total) return;
   const int c = static_cast<int>(id % c4n) * 4;
   int64_t pix = id / c4n;
@@ -57,7 +75,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
     }
   }
   if (p.relu_out) acc = relu4(acc);
-  st4(p.Y + ((static_cast<int64_t>(b) * p.Ho + yo) * p.Wo + xo) * p.ldy + c, acc);
+  st4_any(p.Y + ((static_cast<int64_t>(b) * p.Ho + yo) * p.Wo + xo) * p.ldy + c, acc, h2, hs);
 }
 
 // Stride-1 depthwise 3x3 with a SLIDING WINDOW: one thread = 4 channels x a run
@@ -132,6 +150,9 @@ template <int L, bool RELU_IN, bool RELU_OUT, int ROWS>
 __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN_BLOCKS)) void depthwise3x3_s1_kernel(
     EposDepthwiseArgs p, int c4n, int nres, int nchunk, int nrows, DwPartition part) {
   constexpr int NR = ROWS + 2;                 // input rows held per column
+  const bool h2 = p.y_h2 != 0;                 // uniform: fp16-pair output
+  float hs = 1.f, hinv;
+  if (h2) h2_scale(p.x_amax, p.x_amax2, p.gain, p.bias0, threadIdx.x & 63, hs, hinv);
   const int xcd = blockIdx.x & 7;
   const unsigned local = (blockIdx.x >> 3) * blockDim.x + threadIdx.x;
   int c, chunk, res, ys, b;
@@ -224,7 +245,7 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
           acc = fma4(col[j + 2][ky + rr], w[ky * 3 + 2], acc);
         }
         if (RELU_OUT) acc = relu4_1op(acc);
-        st4(yb + (static_cast<unsigned>((x0 + j * r) * ldy) + (rr ? yrow1 : 0u)), acc);
+        st4_any(yb + (static_cast<unsigned>((x0 + j * r) * ldy) + (rr ? yrow1 : 0u)), acc, h2, hs);
       }
     }
     continue;
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
         acc = fma4(col[j + 2][ky + rr], w[ky * 3 + 2], acc);
       }
       if (RELU_OUT) acc = relu4_1op(acc);
-      if (x < p.Wo) st4(yb + (static_cast<unsigned>(x * ldy) + (rr ? yrow1 : 0u)), acc);
+      if (x < p.Wo) st4_any(yb + (static_cast<unsigned>(x * ldy) + (rr ? yrow1 : 0u)), acc, h2, hs);
     }
   }
   }   // rep
@@ -555,6 +576,7 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
                "C, ldx, ldy must be multiples of 4");
   EPOS_REQUIRE(a->stride == 1 || (a->stride == 2 && a->rate == 1),
                "stride 2 requires rate 1");
+  EPOS_REQUIRE(!a->y_h2 || a->x_amax, "y_h2 needs the absmax slot of X (x_amax)");
   const int c4n = a->C / 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->stride == 1 && a->Hi == a->Ho && a->Wi == a->Wo) {

@@ -538,7 +538,7 @@ __device__ void orthonormalize(double* R) {
   cross3(R, R + 3, R + 6);
 }
 
-// Gaussian elimination with partial pivoting, the arithmetic of oracle/pnp_ref.c's solve6
+// Gaussian elimination with partial pivoting, the arithmetic of the C definition's solve6
 // operation for operation, but with every index a compile-time constant (the pivot row is
 // swapped in by selects): the 6 x 7 system stays in registers. The indexed form went
 // through scratch memory -- a dependent chain of ~300 private loads and stores that every
@@ -966,6 +966,9 @@ __device__ __forceinline__ void for_each_neighbour(const double* xy, const doubl
 #ifndef EPOS_GC_THREADS
 #define EPOS_GC_THREADS 256
 #endif
+#ifdef EPOS_GC_STATS              // tools/gc_stats.py: tiles visited, candidates streamed
+__device__ unsigned long long g_gc_stats[4];
+#endif
 struct GcCand {
   double x, y, X, Y, Z;
   int32_t q;          // fixed-point residual
@@ -1051,6 +1054,13 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
     }
     __syncthreads();
     const int64_t wlo = s_win[0], whi = s_win[1];
+#ifdef EPOS_GC_STATS
+    if (t == 0) {
+      atomicAdd(&g_gc_stats[0], 1ull);
+      atomicAdd(&g_gc_stats[1], static_cast<unsigned long long>(whi - wlo));
+      atomicAdd(&g_gc_stats[2], static_cast<unsigned long long>(n));
+    }
+#endif
     int deg = 0, n0 = 0;
     int64_t S = 0;
     for (int64_t c0 = wlo; c0 < whi; c0 += GC_T) {
@@ -1760,3 +1770,14 @@ extern "C" int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
     if (d[i]) (void)hipFree(d[i]);
   return rc ? rc : k;
 }
+
+#ifdef EPOS_GC_STATS
+extern "C" int epos_debug_gc_stats(unsigned long long* out4, int reset) {
+  int rc = static_cast<int>(hipMemcpyFromSymbol(out4, HIP_SYMBOL(epos::g_gc_stats), 32));
+  if (reset) {
+    const unsigned long long z[4] = {0, 0, 0, 0};
+    rc |= static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(epos::g_gc_stats), z, 32));
+  }
+  return rc;
+}
+#endif

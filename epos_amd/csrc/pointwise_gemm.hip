@@ -545,6 +545,11 @@ int validate(const EposPointwiseArgs* a) {
   EPOS_REQUIRE(a->K % 4 == 0 && a->lda % 4 == 0, "K and lda must be multiples of 4");
   EPOS_REQUIRE((reinterpret_cast<uintptr_t>(a->A) & 15) == 0, "A must be 16-byte aligned");
   EPOS_REQUIRE(a->sub >= 1, "sub must be >= 1");
+  // a pre-split A operand (fp16 pairs written by the depthwise kernel) can only be read by
+  // the fp16-pair kernel, with the scale its producer used
+  EPOS_REQUIRE(!a->a_presplit || (a->Wh && a->a_amax && a->relu_in == 0 && a->M > 8 &&
+                                  a->sub == 1),
+               "a_presplit needs Wh, a_amax, relu_in == 0, sub == 1 and M > 8");
   if (a->c_amax) {
     // the absmax of the output is taken in the float4 epilogue of the LDS-DMA kernels
     bool ok = a->relu_in == 0 && a->M > 8 && (a->N & 3) == 0 && (a->ldc & 3) == 0 &&
@@ -690,6 +695,10 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
   // matrix-pipe work; taken whenever the caller supplied the fp16-pair weights.
   // EPOS_GEMM_H2=0 falls through to the bf16 x 6 kernel.
   if (h2_eligible(args, count)) return launch_grouped_h2(args, count, s);
+  for (int i = 0; i < count; ++i)
+    EPOS_REQUIRE(!args[i].a_presplit,
+                 "a pre-split A operand needs the fp16-pair kernel (every problem of the "
+                 "group with Wh; EPOS_GEMM_H2 / EPOS_GEMM_SPLIT not 0)");
   if (split_eligible(args, count)) return launch_grouped_split(args, count, s);
   // LDS-DMA kernel: the default whenever no pre-activation ReLU has to be applied to
   // A on the way into LDS (measured with warm clocks: 8-30 % faster than the

@@ -40,14 +40,13 @@
 // and the float4 epilogue are the split kernel's.
 #include <string.h>
 
+#include "h2_scale.h"
 #include "pointwise_gemm.h"
 
 namespace epos {
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __attribute__((aligned(16))) float g_zero_chunk_h2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -66,40 +65,13 @@ __device__ __forceinline__ void mfma_f16(const u32x4& a, const u32x4& b, f32x16&
                                              __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// two fp32 values -> packed (hi, hi), (mid, mid) fp16 pairs; s = the tensor's scale
 __device__ __forceinline__ void split_pair(float x0, float x1, float s, unsigned& hi,
                                            unsigned& mid) {
-  const f32x2 t = {x0 * s, x1 * s};
-  const f16x2 h = __builtin_convertvector(t, f16x2);          // v_cvt_pk_f16_f32 (RNE)
-  const f32x2 r = (t - __builtin_convertvector(h, f32x2)) * 2048.f;   // exact residual
-  const f16x2 m = __builtin_convertvector(r, f16x2);
-  hi = __builtin_bit_cast(unsigned, h);
-  mid = __builtin_bit_cast(unsigned, m);
+  h2_split_pair(x0, x1, s, hi, mid);
 }
-
-// Scale of the A operand from the bound in the absmax slot(s): a power of two s with
-// s * bound in [2^14, 2^15) (fp16 overflows at 65520), and its inverse. A non-finite bound
-// (an Inf / NaN upstream) gives s = 1: such rows come out non-finite, the others right.
 __device__ __forceinline__ void a_scale(const EposPointwiseArgs& p, int lane, float& s,
                                         float& inv) {
-  unsigned v = p.a_amax[lane];
-  if (p.a_amax2) {
-    const unsigned v2 = p.a_amax2[lane];
-    v = v2 > v ? v2 : v;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned w = __shfl_xor(v, o, 64);
-    v = w > v ? w : v;
-  }
-  float bound = __uint_as_float(v);
-  if (p.a_gain != 0.f) bound = p.a_gain * bound + p.a_bias;
-  const unsigned e = __float_as_uint(bound) >> 23;            // bound >= 0: no sign bit
-  int sb = 268 - static_cast<int>(e);                         // 2^(14 - (e - 127)), biased
-  sb = sb > 253 ? 253 : sb;
-  if (e >= 255u) sb = 127;
-  s = __uint_as_float(static_cast<unsigned>(sb) << 23);
-  inv = __uint_as_float(static_cast<unsigned>(254 - sb) << 23);
+  h2_scale(p.a_amax, p.a_amax2, p.a_gain, p.a_bias, lane, s, inv);
 }
 
 // Epilogue of the h2 kernel: value = (acc + corr * 2^-11) * 2^-e_n * 2^-e_a + bias
@@ -159,7 +131,9 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
   if (p.c_amax) amax_publish(p.c_amax, amax, lane, salt);
 }
 
-template <bool HAS_RES, bool SINGLE, bool CONV>
+// PRESPLIT: every problem of the launch has its A operand already as fp16 pairs
+// (EposPointwiseArgs.a_presplit; the plan does not mix the two kinds in one group).
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT>
 __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x;
@@ -311,6 +285,20 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
 #pragma unroll
     for (int j = 0; j < 2; ++j) xa[j] = *reinterpret_cast<const float4*>(s + a_off[j]);
   };
+  // A already split by its producer (EposPointwiseArgs.a_presplit): a 16-byte chunk holds
+  // [4 hi | 4 mid] fp16 of four consecutive k, so the lane's two chunks give the MFMA
+  // operands directly -- four 8-byte reads into the halves of (hi, mid), no conversion
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto read_a_ps = [&](int stage, u32x4& hi, u32x4& mid) {
+    const float* s = smem + stage * (H2_STAGE / 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u32x2 h2v = *reinterpret_cast<const u32x2*>(s + a_off[j]);
+      const u32x2 m2v = *reinterpret_cast<const u32x2*>(s + a_off[j] + 2);
+      hi[2 * j] = h2v[0]; hi[2 * j + 1] = h2v[1];
+      mid[2 * j] = m2v[0]; mid[2 * j + 1] = m2v[1];
+    }
+  };
   auto read_b = [&](int stage, auto cb_tag) {
     constexpr int cb = decltype(cb_tag)::value;
     const float* s = smem + stage * (H2_STAGE / 4);
@@ -335,27 +323,31 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   else if (nks > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  read_a(0);
+  u32x4 ah, am;
+  if constexpr (PRESPLIT) {
+    read_a_ps(0, ah, am);
+  } else {
+    read_a(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* x = reinterpret_cast<const float*>(&xa[u >> 1]);
+      unsigned hh, mm;
+      split_pair(x[(u & 1) * 2], x[(u & 1) * 2 + 1], sa, hh, mm);
+      ah[u] = hh; am[u] = mm;
+    }
+  }
   read_b(0, std::integral_constant<int, 0>{});
   read_b(0, std::integral_constant<int, 1>{});
   read_b(0, std::integral_constant<int, 2>{});
   read_b(0, std::integral_constant<int, 3>{});
-
-  u32x4 ah, am;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const float* x = reinterpret_cast<const float*>(&xa[u >> 1]);
-    unsigned hh, mm;
-    split_pair(x[(u & 1) * 2], x[(u & 1) * 2 + 1], sa, hh, mm);
-    ah[u] = hh; am[u] = mm;
-  }
   // MODE 0: issue tile kt+4 (full)   1: issue tile kt+4 (the last, maybe partial)
   //      2: kt+3 is the last tile    3: kt+2 is the last    4: kt+1 is the last   5: last
   // LIVE: column blocks that hold any column < N (4, or 3 for the last column tile of
   // e.g. N = 728: every wave of the workgroup then skips the same quarter of its MFMAs)
-  auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag) {
+  auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag, auto ps_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     constexpr int LIVE = decltype(live_tag)::value;
+    constexpr bool PS = decltype(ps_tag)::value;       // A pre-split: no conversion
     const int s4 = stage + 4 >= H2_NST ? stage + 4 - H2_NST : stage + 4;
     const int s1 = stage + 1 >= H2_NST ? stage + 1 - H2_NST : stage + 1;
     u32x4 nh, nm;
@@ -394,7 +386,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
                     std::integral_constant<bool, MODE == 1>{});
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (SPL >= 0 && SPL < 4 && MODE != 5) {
+      if constexpr (!PS && SPL >= 0 && SPL < 4 && MODE != 5) {
         __builtin_amdgcn_sched_barrier(0);
         split_unit(std::integral_constant<int, SPL>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -424,7 +416,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
       __builtin_amdgcn_s_barrier();
 #endif
 #ifndef EPOS_H2_ABL_NOREAD
-      read_a(s1);
+      if constexpr (PS) read_a_ps(s1, nh, nm); else read_a(s1);
       read_b(s1, std::integral_constant<int, 0>{});
       read_b(s1, std::integral_constant<int, 1>{});
 #endif
@@ -442,7 +434,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
       step(ah, bp[2][1], corr[2], N_{}, I0{});
       step(am, bp[2][0], corr[2], N_{}, I1{});
       step(ah, bp[2][0], acc[2], N_{}, I2{});
-      if constexpr (MODE != 5) split_unit(I3{});
+      if constexpr (!PS && MODE != 5) split_unit(I3{});
     }
     if constexpr (MODE != 5) {
 #ifndef EPOS_H2_ABL_NOREAD
@@ -452,8 +444,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
       ah = nh; am = nm;
     }
   };
-  auto k_loop = [&](auto live_tag) {
+  auto k_loop = [&](auto live_tag, auto ps_tag) {
     using LV = decltype(live_tag);
+    using PS = decltype(ps_tag);
     using M0 = std::integral_constant<int, 0>;
     using M1 = std::integral_constant<int, 1>;
     using M2 = std::integral_constant<int, 2>;
@@ -462,23 +455,23 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     using M5 = std::integral_constant<int, 5>;
     int kt = 0;
     for (; kt + 9 < nks; kt += 5) {        // every LDS offset an immediate
-      tile(kt, 0, M0{}, LV{});
-      tile(kt + 1, 1, M0{}, LV{});
-      tile(kt + 2, 2, M0{}, LV{});
-      tile(kt + 3, 3, M0{}, LV{});
-      tile(kt + 4, 4, M0{}, LV{});
+      tile(kt, 0, M0{}, LV{}, PS{});
+      tile(kt + 1, 1, M0{}, LV{}, PS{});
+      tile(kt + 2, 2, M0{}, LV{}, PS{});
+      tile(kt + 3, 3, M0{}, LV{}, PS{});
+      tile(kt + 4, 4, M0{}, LV{}, PS{});
     }
     int stage = 0;                          // kt is a multiple of 5 here
     auto next = [&] { stage = stage + 1 == H2_NST ? 0 : stage + 1; ++kt; };
-    for (; kt + 5 < nks;) { tile(kt, stage, M0{}, LV{}); next(); }
-    if (kt + 5 == nks) { tile(kt, stage, M1{}, LV{}); next(); }
-    if (kt + 4 == nks) { tile(kt, stage, M2{}, LV{}); next(); }
-    if (kt + 3 == nks) { tile(kt, stage, M3{}, LV{}); next(); }
-    if (kt + 2 == nks) { tile(kt, stage, M4{}, LV{}); next(); }
-    tile(kt, stage, M5{}, LV{});
+    for (; kt + 5 < nks;) { tile(kt, stage, M0{}, LV{}, PS{}); next(); }
+    if (kt + 5 == nks) { tile(kt, stage, M1{}, LV{}, PS{}); next(); }
+    if (kt + 4 == nks) { tile(kt, stage, M2{}, LV{}, PS{}); next(); }
+    if (kt + 3 == nks) { tile(kt, stage, M3{}, LV{}, PS{}); next(); }
+    if (kt + 2 == nks) { tile(kt, stage, M4{}, LV{}, PS{}); next(); }
+    tile(kt, stage, M5{}, LV{}, PS{});
   };
-  if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{});   // uniform
-  else k_loop(std::integral_constant<int, 4>{});
+  if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{}, std::integral_constant<bool, PRESPLIT>{});
+  else k_loop(std::integral_constant<int, 4>{}, std::integral_constant<bool, PRESPLIT>{});
 
   // ---- epilogue --------------------------------------------------------------
   const float* cscale = reinterpret_cast<const float*>(
@@ -520,9 +513,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   }
 }
 
-template <bool HAS_RES, bool SINGLE, bool CONV>
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false>
 int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV>;
+  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -554,6 +547,23 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* X, int64_t ldx
     }
   }
   amax_publish(slot, m, threadIdx.x & 63, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// Zeroing slots is a KERNEL, not hipMemsetAsync: inside a captured hipGraph the memset node
+// was observed to run late relative to the kernel nodes that follow it when several graphs
+// replay on several streams (ROCm 7.2: the first slot's words were wiped after conv1_1 had
+// published into them -- tools/diag_concurrent.py, profiles/r03/), a kernel node is ordered.
+__global__ __launch_bounds__(256) void amax_clear_kernel(unsigned* slots, int64_t words) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < words) slots[i] = 0u;
+}
+
+int launch_amax_clear(unsigned* slots, int64_t n_slots, hipStream_t s) {
+  const int64_t words = n_slots * EPOS_AMAX_WORDS;
+  if (words <= 0) return EPOS_OK;
+  hipLaunchKernelGGL(amax_clear_kernel, dim3(static_cast<unsigned>(ceil_div(words, 256))),
+                     dim3(256), 0, s, slots, words);
+  return launch_status("amax_clear_kernel");
 }
 
 int launch_absmax(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsigned* slot,
@@ -605,6 +615,7 @@ bool h2_eligible(const EposPointwiseArgs* args, int count) {
     if (!a.Wh || a.relu_in != 0 || a.M <= 8 || (a.K & 3) != 0 || (a.lda & 3) != 0 ||
         (reinterpret_cast<uintptr_t>(a.A) & 15) != 0)
       return false;
+    if (a.a_presplit && !a.a_amax) return false;   // rejected by the entry point
     const int64_t rows = a.sub > 1 ? static_cast<int64_t>(a.M) / (static_cast<int64_t>(a.Ho) * a.Wo) *
                                          a.Hi * a.Wi
                                    : a.M;
@@ -638,8 +649,7 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                                           args[i].Hi * args[i].Wi
                                     : args[i].M;
       const int64_t cols = conv_cin ? conv_cin[i] : args[i].K;
-      int rc = check_hip(hipMemsetAsync(slot, 0, sizeof(unsigned) * EPOS_AMAX_WORDS, s),
-                         "hipMemsetAsync(absmax slot)");
+      int rc = launch_amax_clear(slot, 1, s);
       if (rc) return rc;
       rc = launch_absmax(args[i].A, args[i].lda, rows, cols, slot, s);
       if (rc) return rc;
@@ -657,7 +667,19 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
   for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
   const bool res = args[0].R != nullptr;
   const bool single = count == 1;
+  const bool ps = args[0].a_presplit != 0;
+  for (int i = 1; i < count; ++i)
+    if ((args[i].a_presplit != 0) != ps) {
+      set_error("launch_grouped_h2: the problems of a group must agree on a_presplit");
+      return EPOS_E_INVALID;
+    }
   if (conv_cin) return launch_h2_tt<false, true, true>(g, total, s);
+  if (ps) {
+    if (res) return single ? launch_h2_tt<true, true, false, true>(g, total, s)
+                           : launch_h2_tt<true, false, false, true>(g, total, s);
+    return single ? launch_h2_tt<false, true, false, true>(g, total, s)
+                  : launch_h2_tt<false, false, false, true>(g, total, s);
+  }
   if (res) return single ? launch_h2_tt<true, true, false>(g, total, s)
                          : launch_h2_tt<true, false, false>(g, total, s);
   return single ? launch_h2_tt<false, true, false>(g, total, s)
@@ -669,9 +691,7 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
 extern "C" int epos_amax_clear(uint32_t* slots, int64_t n_slots, void* stream) {
   using namespace epos;
   EPOS_REQUIRE(slots && n_slots >= 0, "bad argument");
-  return check_hip(hipMemsetAsync(slots, 0, sizeof(uint32_t) * EPOS_AMAX_WORDS * n_slots,
-                                  static_cast<hipStream_t>(stream)),
-                   "hipMemsetAsync(absmax slots)");
+  return launch_amax_clear(slots, n_slots, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int epos_absmax_f32(const float* X, int64_t ldx, int64_t rows, int64_t cols,

@@ -113,6 +113,19 @@ class EposNet(object):
     self._n_slots = 0
     self._bounds = {}
     self.h2_layers, self.h2_refused = [], []
+    # fp16-pair GEMM switches of the library (A/B runs): with either off no layer gets
+    # fp16-pair weights. EPOS_H2_PRESPLIT=1 (opt-in): the depthwise kernels write their
+    # outputs already split (fp16 pairs), so each activation is converted once instead of
+    # once per column tile of the GEMM and the GEMM loop carries no conversion. Bit-identical
+    # results; per launch the GEMM gains 12-17 % (tools/bench_gemm_h2_abl.py), but in the
+    # pipelined step the depthwise launches pay it back (+0.07 ms of depthwise slot time vs
+    # -0.02 ms of GEMM): 409.6 / 411.5 vs 409.3 images/s, same box (profiles/r03/
+    # presplit_ab.txt) -- measured neutral, kept off.
+    self.use_h2 = (os.environ.get('EPOS_GEMM_H2', '1') != '0' and
+                   os.environ.get('EPOS_GEMM_SPLIT', '1') != '0')
+    self.use_presplit = self.use_h2 and os.environ.get('EPOS_H2_PRESPLIT', '0') == '1'
+    self._dw_h2 = {}           # id(depthwise output) -> its (mutable) launch arguments
+    self.presplit_layers = []
     # Structure trace: one record per parametrised layer and a canonical expression per
     # buffer (channel slices of concat buffers separately), in the grammar of
     # tests/golden/tf_recorder.py -- what each launch computes, written down from the very
@@ -312,11 +325,21 @@ class EposNet(object):
         eout = 'add(%s)' % ','.join(sorted([eout, self._expr_of(res, res_off, n)]))
       self._set_expr(c, self._relu_expr(eout) if relu else eout, c_off, n)
     # fp16-pair weights when the A operand has a bound; the output's slot
-    ab = self._bound_of(a)
+    ab = self._bound_of(a) if self.use_h2 else None
     wh = None
     if ab is not None and not relu_in and m > 8:
       wh = self._pack_h2(w_kn, scale)
       (self.h2_layers if wh is not None else self.h2_refused).append(name)
+    # A = the output of a depthwise conv that was set up to write fp16 pairs: keep that
+    # only if this GEMM really runs on the fp16-pair kernel (the packer may have refused
+    # the weights); the depthwise arguments are the very struct its launch closure holds
+    dwa = self._dw_h2.pop(id(a), None)
+    presplit = False
+    if dwa is not None:
+      presplit = wh is not None and sub == 1 and a_off == 0
+      dwa.y_h2 = int(presplit)
+      if presplit:
+        self.presplit_layers.append(name)
     track = track_out and not relu_in and m > 8 and (res is None or ldr % 4 == 0)
     cslot = self._out_slot(c, n, ldc, c_off) if track else None
     args = _lib.PointwiseArgs(
@@ -330,6 +353,7 @@ class EposNet(object):
         a_amax2=self._slot_ptr(ab[1]) if wh is not None else None,
         a_gain=ab[2] if wh is not None else 0.0,
         a_bias=ab[3] if wh is not None else 0.0,
+        a_presplit=int(presplit),
         c_amax=self._slot_ptr(cslot))
     lib = self.lib
     # fp32 activations in and out, weights once (4 B each: what the layer IS; the
@@ -369,6 +393,14 @@ class EposNet(object):
     """Launches the collected problems as one grouped GEMM (they must agree on
     relu_in / residual; callers group accordingly)."""
     if not group:
+      return
+    # problems whose A is already fp16 pairs run on another kernel instantiation than the
+    # ones that split their fp32 A themselves: one launch per kind
+    kinds = sorted({int(g[1].a_presplit) for g in group})
+    if len(kinds) > 1:
+      for kd in kinds:
+        self._flush_group([g for g in group if int(g[1].a_presplit) == kd])
+      del group[:]
       return
     name = '+'.join(g[0] for g in group)
     arr = (_lib.PointwiseArgs * len(group))(*[g[1] for g in group])
@@ -410,6 +442,14 @@ class EposNet(object):
         X=_ptr(x), ldx=ldx, w9c=_ptr(w9c), bias=_ptr(bias), Y=_ptr(y), ldy=c,
         B=self.B, Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c, stride=stride, rate=rate,
         relu_in=int(relu_in), relu_out=int(relu_out))
+    yb = self._bound_of(y)
+    if yb is not None and self.use_presplit and not defer:
+      # fp16-pair output, pending the consumer's decision (_pointwise): scale from the
+      # bound of |Y| = gain * max|X| + max|bias| (the same numbers the GEMM gets)
+      args.y_h2 = 1
+      args.x_amax, args.x_amax2 = self._slot_ptr(yb[0]), self._slot_ptr(yb[1])
+      args.gain, args.bias0 = yb[2], yb[3]
+      self._dw_h2[id(y)] = args
     lib = self.lib
     if defer:
       return y, ho, wo, (name, args, 2 * 9 * self.B * ho * wo * c)

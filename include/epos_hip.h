@@ -94,7 +94,7 @@ int64_t epos_pack_pointwise_weights_h2(const float* w_kn, int K, int N, void* ds
  * a slot is 64 uint32 words [device] holding the bit patterns of non-negative floats; the
  * bound is the maximum over the 64 words. Producers combine into a slot with atomic max
  * (the GEMM epilogues do when c_amax is given; epos_absmax_f32 does for any other tensor);
- * the caller zeroes a slot (hipMemsetAsync) before the first producer of the step runs.
+ * the caller zeroes a slot (epos_amax_clear) before the first producer of the step runs.
  * Any upper bound is valid (max-pool / subsample / bilinear resize outputs may reuse their
  * input's slot); a bound that is too large by 2^j costs j of the ~27 octaves below the
  * bound within which elements keep full precision. Overflow is impossible by construction.
@@ -103,7 +103,8 @@ int64_t epos_pack_pointwise_weights_h2(const float* w_kn, int K, int N, void* ds
 #define EPOS_AMAX_WORDS 64
 int epos_absmax_f32(const float* X, int64_t ldx, int64_t rows, int64_t cols,
                     uint32_t* slot, void* stream);
-/* Zeroes n_slots consecutive slots (hipMemsetAsync on `stream`). */
+/* Zeroes n_slots consecutive slots (a kernel on `stream`: a memset NODE of a captured graph
+ * is not reliably ordered before the kernel nodes behind it when graphs replay concurrently). */
 int epos_amax_clear(uint32_t* slots, int64_t n_slots, void* stream);
 
 /* out[m, n] = act( sum_k A[row(m), k] * W[k, n] + bias[n] (+ R[m, n]) )
@@ -141,6 +142,8 @@ typedef struct EposPointwiseArgs {
   float a_gain, a_bias; /* bound = a_gain * slot + a_bias (a_gain == 0 reads as 1, 0):
                        * A = a depthwise conv of the tensor the slot describes,
                        * a_gain = max_c sum_taps |w|, a_bias = max_c |bias| */
+  int32_t a_presplit; /* A is already fp16 pairs (EposDepthwiseArgs.y_h2 wrote it with the
+                       * same a_amax / a_amax2 / a_gain / a_bias): needs Wh and a_amax */
   uint32_t* c_amax;   /* optional [device]: slot that receives max|C| over the elements
                        * this call writes (atomic max). Needs the float4 epilogue:
                        * N % 4 == 0, ldc % 4 == 0, C (and R) 16-byte aligned, relu_in == 0,
@@ -209,6 +212,19 @@ typedef struct EposDepthwiseArgs {
   int32_t B, Hi, Wi, Ho, Wo, C;
   int32_t stride, rate;
   int32_t relu_in, relu_out;
+  /* ---- ABI 5: fp16-pair OUTPUT for the fp16-pair GEMM that consumes Y (its A operand).
+   * y_h2 != 0: instead of 4 fp32 values per 16 bytes the kernel writes, for the same 4
+   * channels c..c+3, [hi(c) hi(c+1) hi(c+2) hi(c+3) | mid(c) .. mid(c+3)] (8 fp16 = the same
+   * 16 bytes, same addresses, same ldy): hi = rn_fp16(y * s), mid = rn_fp16((y * s - hi) *
+   * 2^11), s = the power of two that puts the BOUND  gain * max(x_amax, x_amax2) + bias0
+   * into [2^14, 2^15). The bound must hold for |Y| (gain = max_c sum_taps |w|, bias0 =
+   * max_c |bias| with x_amax bounding |X|); the GEMM (EposPointwiseArgs.a_presplit, same
+   * slots / gain / bias) derives the same s. Each activation is then split ONCE instead of
+   * once per column tile of the GEMM, and the GEMM's loop carries no conversion at all. */
+  int32_t y_h2;
+  const uint32_t* x_amax;
+  const uint32_t* x_amax2;   /* optional second slot */
+  float gain, bias0;
 } EposDepthwiseArgs;
 int epos_depthwise3x3_f32(const EposDepthwiseArgs* args, void* stream);
 

@@ -374,3 +374,79 @@ def test_h2_fp16_denormal_pieces_are_not_flushed(lib):
   ref = a.astype(np.float64) @ w.astype(np.float64)
   c = _gemm(lib, a, w, 'h2').astype(np.float64)
   assert np.abs(c - ref).max() <= 2.0 ** -18 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('hi,wi,c,stride,rate,relu_in,relu_out', [
+    (17, 23, 32, 1, 1, 0, 0), (60, 80, 728, 1, 2, 1, 0), (16, 24, 64, 2, 1, 0, 0),
+    (30, 40, 256, 1, 12, 0, 1), (15, 21, 8, 2, 1, 1, 0), (24, 32, 304, 1, 1, 0, 1)])
+def test_depthwise_fp16_pair_output_and_presplit_gemm(lib, hi, wi, c, stride, rate, relu_in,
+                                                      relu_out):
+  """EposDepthwiseArgs.y_h2: the depthwise kernel writes its output as fp16 pairs under the
+  scale of its bound (gain * max|X| + max|bias|). (1) Decoded, the pairs reproduce the fp32
+  output of the same kernel to 2^-22 relative (window of full precision). (2) The fp16-pair
+  GEMM on that buffer (a_presplit) gives, BIT FOR BIT, what it gives on the fp32 buffer when
+  it splits A itself with the same slots -- the split is the same arithmetic, done once."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(hi * 7 + c)
+  b = 2
+  ho = hi if stride == 1 else (hi - 1) // 2 + 1
+  wo = wi if stride == 1 else (wi - 1) // 2 + 1
+  x = rng.standard_normal((b, hi, wi, c)).astype(np.float32)
+  w9c = (rng.standard_normal((9, c)) * 0.4).astype(np.float32)
+  bias = rng.standard_normal(c).astype(np.float32)
+  X = torch.from_numpy(x).cuda()
+  W9, Bd = torch.from_numpy(w9c).cuda(), torch.from_numpy(bias).cuda()
+  xs = _slot()
+  _lib.check(lib.epos_absmax_f32(_p(X), c, b * hi * wi, c, _p(xs), None))
+  gain = float(np.abs(w9c.astype(np.float64)).sum(0).max())
+  bias0 = float(np.abs(bias).max())
+  outs = {}
+  for h2 in (0, 1):
+    Y = torch.full((b, ho, wo, c), 7.0, device='cuda')
+    args = _lib.DepthwiseArgs(X=_p(X), ldx=c, w9c=_p(W9), bias=_p(Bd), Y=_p(Y), ldy=c, B=b,
+                              Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c, stride=stride, rate=rate,
+                              relu_in=relu_in, relu_out=relu_out, y_h2=h2, x_amax=_p(xs),
+                              gain=gain, bias0=bias0)
+    _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(args), None))
+    torch.cuda.synchronize()
+    outs[h2] = Y
+  y32 = outs[0].cpu().numpy()
+  raw = outs[1].cpu().numpy().view(np.float16).reshape(b, ho, wo, c // 4, 2, 4)
+  hi16, mid16 = raw[..., 0, :].astype(np.float64), raw[..., 1, :].astype(np.float64)
+  bound = gain * np.abs(x).max() + bias0
+  assert np.abs(y32).max() <= bound                      # the bound holds
+  s = 2.0 ** (14 - np.floor(np.log2(bound)))
+  dec = ((hi16 + mid16 / 2048.0) / s).reshape(b, ho, wo, c)
+  assert np.abs(hi16).max() < 2.0 ** 15
+  big = np.abs(y32) >= 2.0 ** -26 * bound
+  assert (np.abs(dec - y32)[big] <= 2.0 ** -22 * np.abs(y32)[big]).all()
+  assert (np.abs(dec - y32)[~big] <= 2.0 ** -49 * bound).all()
+  # (2) the GEMM on either form
+  n = 136
+  wk = (rng.standard_normal((c, n)) / np.sqrt(c)).astype(np.float32)
+  Wp, Wh = _pack(lib, wk), _pack(lib, wk, 'h2')
+  res = {}
+  for h2 in (0, 1):
+    C = torch.zeros(b * ho * wo, n, device='cuda')
+    a = _lib.PointwiseArgs(A=_p(outs[h2]), lda=c, Wp=_p(Wp), bias=None, R=None, ldr=0, C=_p(C),
+                           ldc=n, M=b * ho * wo, N=n, K=c, relu=0, relu_in=0, sub=1,
+                           Wh=_p(Wh), a_amax=_p(xs), a_gain=gain, a_bias=bias0, a_presplit=h2)
+    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+    torch.cuda.synchronize()
+    res[h2] = C.cpu().numpy()
+  assert np.array_equal(res[0], res[1])
+  ref = y32.reshape(-1, c).astype(np.float64) @ wk.astype(np.float64)
+  np.testing.assert_allclose(res[1], ref, rtol=2e-5, atol=2e-5)
+
+
+def test_presplit_needs_the_fp16_pair_kernel(lib):
+  """a_presplit without Wh / a_amax is refused (no other kernel can read fp16 pairs)."""
+  from epos_amd import _lib
+  A = torch.zeros(64, 32, device='cuda')
+  C = torch.zeros(64, 32, device='cuda')
+  w = np.eye(32, dtype=np.float32)
+  Wp = _pack(lib, w)
+  a = _lib.PointwiseArgs(A=_p(A), lda=32, Wp=_p(Wp), bias=None, R=None, ldr=0, C=_p(C), ldc=32,
+                         M=64, N=32, K=32, relu=0, relu_in=0, sub=1, a_presplit=1)
+  with pytest.raises(_lib.EposError):
+    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))

@@ -10,7 +10,7 @@
 #   (gfx950 x2 correction on FETCH_SIZE; PMC passes never share a run with trace options);
 # - the RANSAC-only microbenchmark.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
@@ -19,6 +19,12 @@ python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/bench_driver_cmd.err | tai
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_100steps.json
 python bench.py --steps 100 --warmup 10 --sparse-heads --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_sparse_heads.json
 EPOS_GEMM_SPLIT=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_fp32_mfma.json
+EPOS_GEMM_H2=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_bf16x6.json
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_100steps_b.json
+# the other BASELINE configurations
+python bench.py --steps 60 --warmup 5 --num-objs 1 --objs-per-image 1 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c1.json
+python bench.py --steps 40 --warmup 5 --height 540 --width 720 --num-objs 30 --objs-per-image 8 --instances 2 --pipeline-depth 3 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c4.json
+python bench.py --steps 20 --warmup 3 --model-variant resnet_v1_101_beta --num-objs 15 --batch-per-gpu 8 --pipeline-depth 2 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c5.json
 python bench.py --steps 40 --warmup 5 --batch-per-gpu 4 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c3_shard_batch4.json
 for d in 4 1; do
   mkdir -p $OUT/kt$d

@@ -274,8 +274,8 @@ def depthwise_roofline(pipe, steps):
           'avg_launch_us': round(ms * 1e3 / len(evs), 2),
           'algorithmic_bytes_per_launch': round(nbytes / len(evs)),
           'note': 'HIP events around 8-16 us kernels include ~4 us of launch gap per launch '
-                  '(rocprofv3 kernel trace of the same plan: 9.5-9.6 us, 16.5 for the '
-                  '2048-channel tensors -> 3.4 TB/s = 0.43, profiles/r02/rocprofv3_kernel_'
+                  '(rocprofv3 kernel trace of the same plan: 9.5-11 us, 15-16.5 for the '
+                  '2048-channel tensors -> ~3.2 TB/s = 0.40, profiles/r03/rocprofv3_kernel_'
                   'stats_depth1.csv); tensors of 4-60 MB, mostly served by the 256 MB '
                   'Infinity Cache; a plain device copy of the same tensors runs at '
                   '6.4-7.0 TB/s (profiles/r02/depthwise_threads_ab.txt)'}
@@ -338,7 +338,7 @@ def gemm_roofline(pipe, steps):
   # (measure_traffic_live: two rocprofv3 --pmc child runs); the committed summary of the
   # last collection is the fallback when rocprofv3 is unavailable (--traffic static).
   traffic, traffic_src = None, None
-  for rnd in ('r02', 'r01'):
+  for rnd in ('r03', 'r02', 'r01'):
     tpath = os.path.join(ROOT, 'profiles', rnd, 'gemm_hbm_traffic_pmc.json')
     if os.path.exists(tpath):
       with open(tpath) as f:
@@ -638,9 +638,11 @@ def main():
           'gemm_ms_per_step': round(g_ms, 3), 'depthwise_ms_per_step': round(d_ms, 3),
           'rest_ms_per_step': round(max(step_ms - g_ms - d_ms, 0.0), 3),
           'ms_per_step': step_ms,
-          'avg_launch_us': round(g_ms * 1e3 / max(nl, 1), 2),
-          'achieved': round(gemm_gflop * B / max(g_ms, 1e-9), 2),
-          'frac': round(gemm_gflop * B / max(g_ms, 1e-9) / roof['peak'], 4),
+          # (a step that is not bound by its GEMMs -- e.g. one object per image, where the
+          # serial fitting chain sets the pace -- shows no GEMM cost here: reported as null)
+          'avg_launch_us': round(g_ms * 1e3 / max(nl, 1), 2) if g_ms > 0.02 else None,
+          'achieved': round(gemm_gflop * B / g_ms, 2) if g_ms > 0.02 else None,
+          'frac': round(gemm_gflop * B / g_ms / roof['peak'], 4) if g_ms > 0.02 else None,
           'how': 'the same %d pipelined steps timed again with the GEMM (resp. depthwise) '
                  'launches removed from every plan\'s graph: step - that = the kernels\' '
                  'cost inside the timed regime; launches x avg_launch_us = gemm_ms_per_step '

@@ -609,6 +609,12 @@ __device__ __forceinline__ int ep_update_niters(double p, double ep, int max_ite
   double num = 1.0 - p;
   if (num < DBL_MIN) num = DBL_MIN;
   const double w = 1.0 - ep;
+  // OpenCV's RANSACUpdateNumIters takes pow(1 - ep, modelPoints) from libm; the fifth power
+  // is written out here (and in the C oracle) because a device pow() and a host pow() need not
+  // agree in the last bit, which would break the kernel == oracle identity the tests hold.
+  // The two forms can differ by an ulp of w^5; through log / cvRound that changes the
+  // iteration cap only when num / denom falls within ~1e-15 of a half-integer -- a known,
+  // documented deviation from cv2 (not checkable here: cv2 is not installable).
   double denom = 1.0 - (w * w) * (w * w) * w;
   if (denom < DBL_MIN) return 0;
   num = log(num);

@@ -483,6 +483,7 @@ __global__ __launch_bounds__(256) void ransac_hypotheses(
     const double* xyz = xyz_all + 3 * base;
     const int32_t* active = w.active + base;
     const int64_t n_active = w.n_active[s];
+    const int64_t n = slot_base[s + 1] - base;
     double K[9];
     for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
     int64_t m = n_active;
@@ -511,7 +512,10 @@ __global__ __launch_bounds__(256) void ransac_hypotheses(
       int32_t* hc = w.hyp_count + (static_cast<int64_t>(s) * prm.max_iters + it) * MAX_SOL;
       double sc[MAX_SOL];
       int cnt[MAX_SOL];
-      score_poses(sols, ns, K, xy, xyz, active, n_active, thr2, lane, sc, cnt);
+      // while nothing has been removed the active list is the identity (ransac_init): the
+      // scoring passes then index the points directly -- one dependent load per item less
+      score_poses(sols, ns, K, xy, xyz, n_active == n ? nullptr : active, n_active, thr2, lane,
+                  sc, cnt);
 #pragma unroll
       for (int q = 0; q < MAX_SOL; ++q) {
         if (q < ns) {
@@ -862,12 +866,13 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   // each pass scores a pose AND takes the Gauss-Newton step from it: the step of an
   // accepted candidate is already there when the next refit starts
   double cand[12];
-  int fail = lo_pass<true>(pose, K, xy, xyz, active, n_active, thr2, t, sy, &s_lo, nullptr, 1,
+  const int32_t* idx = n_active == n ? nullptr : active;   // identity while nothing is removed
+  int fail = lo_pass<true>(pose, K, xy, xyz, idx, n_active, thr2, t, sy, &s_lo, nullptr, 1,
                            &best_score, &best_count, cand);
   for (int li = 0; li < prm.lo_iters && !fail; ++li) {
     double sc, cand2[12];
     int cnt;
-    const int fail2 = lo_pass<true>(cand, K, xy, xyz, active, n_active, thr2, t, sy, &s_lo,
+    const int fail2 = lo_pass<true>(cand, K, xy, xyz, idx, n_active, thr2, t, sy, &s_lo,
                                     nullptr, 1, &sc, &cnt, cand2);
     if (!(sc > best_score)) break;
     const double gain = sc - best_score;
@@ -1173,12 +1178,13 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
     // the first step on the labelled set starts from the accepted pose (its score is
     // known); from then on each pass scores a candidate and steps from it
     double cand[12];
-    int fail = lo_pass<false>(pose, K, xy, xyz, active, n_active, thr2, t, sy, &s_lo, lab, 1,
+    const int32_t* idx = n_active == n ? nullptr : active;
+    int fail = lo_pass<false>(pose, K, xy, xyz, idx, n_active, thr2, t, sy, &s_lo, lab, 1,
                               nullptr, nullptr, cand);
     for (int li = 0; li < prm.lo_iters && !fail; ++li) {
       double sc, cand2[12];
       int cnt;
-      const int fail2 = lo_pass<true>(cand, K, xy, xyz, active, n_active, thr2, t, sy, &s_lo,
+      const int fail2 = lo_pass<true>(cand, K, xy, xyz, idx, n_active, thr2, t, sy, &s_lo,
                                       lab, 1, &sc, &cnt, cand2);
       if (!(sc > best_score)) break;
       const double gain = sc - best_score;

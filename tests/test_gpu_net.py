@@ -25,20 +25,21 @@ def test_net_matches_oracle(h, w, num_objs, batch):
 
   def nhwc(t):
     return t.permute(0, 2, 3, 1).numpy()
-  # intermediate check points (plan buffers)
-  np.testing.assert_allclose(net.encoder.cpu().numpy(), nhwc(ep['encoder']),
-                             rtol=2e-4, atol=2e-4)
-  np.testing.assert_allclose(net.aspp_concat.cpu().numpy(),
-                             nhwc(ep['aspp_concat']), rtol=2e-4, atol=2e-4)
-  np.testing.assert_allclose(net.decoder_concat.cpu().numpy(),
-                             nhwc(ep['decoder_concat']), rtol=2e-4, atol=2e-4)
-  np.testing.assert_allclose(net.decoder_out.cpu().numpy(),
-                             nhwc(ep['decoder/decoder_conv1']), rtol=2e-4,
-                             atol=2e-4)
+  # intermediate check points (plan buffers) and the heads: the bar of the full-size
+  # configuration tests (tests/test_gpu_configs.py), rtol = 1e-4 with an absolute term of
+  # 1e-4 of the tensor's scale (two fp32 evaluations of a 65-layer network differ by a few
+  # 1e-6 of the scale; the intermediates of a random-init network reach 1e1 .. 1e2)
+  def close(a, b, what):
+    scale = max(1.0, float(np.abs(b).max()))
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * scale, err_msg=what)
+  close(net.encoder.cpu().numpy(), nhwc(ep['encoder']), 'encoder')
+  close(net.aspp_concat.cpu().numpy(), nhwc(ep['aspp_concat']), 'aspp_concat')
+  close(net.decoder_concat.cpu().numpy(), nhwc(ep['decoder_concat']), 'decoder_concat')
+  close(net.decoder_out.cpu().numpy(), nhwc(ep['decoder/decoder_conv1']), 'decoder_out')
   for k in ['pred_obj_conf', 'pred_frag_conf', 'pred_frag_loc']:
     a = out[k].cpu().numpy()
     assert a.shape == ref[k].shape and a.dtype == ref[k].dtype, k
-    np.testing.assert_allclose(a, ref[k], rtol=2e-4, atol=2e-4, err_msg=k)
+    np.testing.assert_allclose(a, ref[k], rtol=1e-4, atol=1e-4, err_msg=k)
   lab = out['pred_obj_label'].cpu().numpy()
   assert lab.dtype == np.int64 and lab.shape == ref['pred_obj_label'].shape
   conf = np.sort(ref['pred_obj_conf'], axis=-1)
@@ -81,10 +82,10 @@ def test_resnet_v1_101_beta_matches_oracle():
   torch.cuda.synchronize()
   enc = ref['_end_points']['encoder'].permute(0, 2, 3, 1).numpy()
   scale = float(np.abs(enc).max())
-  np.testing.assert_allclose(net.encoder.cpu().numpy(), enc, rtol=2e-4,
-                             atol=2e-4 * max(scale, 1.0))
+  np.testing.assert_allclose(net.encoder.cpu().numpy(), enc, rtol=1e-4,
+                             atol=1e-4 * max(scale, 1.0))
   for k in ['pred_obj_conf', 'pred_frag_conf', 'pred_frag_loc']:
-    np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=3e-4, atol=3e-4,
+    np.testing.assert_allclose(out[k].cpu().numpy(), ref[k], rtol=1e-4, atol=1e-4,
                                err_msg=k)
 
 

@@ -408,7 +408,7 @@ def main():
   depth = max(1, args.pipeline_depth)
   pipes = [pipeline.EposPipeline(
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
-      capacity=1 << 21, max_instances=max(1, args.instances), device=dev,
+      capacity=1 << 20, max_instances=max(1, args.instances), device=dev,
       use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads,
       model_options=mo, fitting_method=args.fitting_method)
            for j in range(depth)]

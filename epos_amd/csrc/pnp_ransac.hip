@@ -391,6 +391,11 @@ struct Work {
   uint8_t* lab_b;        // [N] labels, pong
   const int32_t* yorder; // [N] correspondences of a slot sorted by image y (or null:
   const int32_t* ypos;   //     they already are), and the inverse permutation
+  // neighbour lists of the 5-D graph (built once per call: the graph depends on neither
+  // labels nor rounds), per POSITION of the row-sorted order
+  uint16_t* nb_cnt;      // [N][GC_W] entries of the point's GC_W sub-lists
+  int16_t* nb_pool;      // [N][GC_W][NB_SUB] position deltas
+  int32_t* nb_ok;        // [S] 1: lists complete; 0: overflow -> the sweeps scan windows
   // cooperative local optimisation (LO_G workgroups per slot)
   unsigned* lo_cnt;      // [S][lo_launches(max_k)] arrival counters, zeroed by ransac_init
   double* lo_data;       // [S][2][LO_G * 4][LO_NV] wave sums, double buffered
@@ -441,10 +446,12 @@ __device__ void round_failed(int s, const Work& w, const EposFitParams& prm, int
 __global__ __launch_bounds__(256) void ransac_init(const int64_t* slot_base, int S,
                                                    Work w, int32_t* labels,
                                                    int32_t* num_models,
-                                                   int min_pts, int64_t n_capacity, int n_lo) {
+                                                   int min_pts, int64_t n_capacity, int n_lo,
+                                                   int build_nb) {
   const int s = blockIdx.x;
   for (int i = threadIdx.x; i < n_lo; i += blockDim.x)
     w.lo_cnt[static_cast<int64_t>(s) * n_lo + i] = 0u;
+  if (threadIdx.x == 0) w.nb_ok[s] = build_nb;
   if (s == 0 && threadIdx.x == 0) *w.lo_timeout = 0;
   const int64_t base = slot_base[s];
   // A slot whose rows would end beyond the pooled arrays (the correspondence stage
@@ -924,6 +931,14 @@ __device__ __forceinline__ bool gc_neighbours(const double* xy, const double* xy
   return d2 <= r2;
 }
 
+// a slot's neighbour lists (null cnt: not available, scan the window)
+constexpr int NB_W = 4;            // sub-lists per point (= waves of a sweep workgroup)
+constexpr int NB_SUB = 80;         // entries per sub-list: 320 neighbours per point
+struct NbLists {
+  const uint16_t* cnt;
+  const int16_t* pool;
+};
+
 __device__ __forceinline__ int64_t butterfly_sum_i64(int64_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -936,9 +951,21 @@ __device__ __forceinline__ void for_each_neighbour(const double* xy, const doubl
                                                    int64_t n, int32_t p,
                                                    const int32_t* yorder, const int32_t* ypos,
                                                    double rad, double s2, double r2, int lane,
-                                                   F f) {
+                                                   const NbLists& nl, F f) {
   const double yp = xy[2 * p + 1];
   const int64_t pos = ypos ? ypos[p] : p;
+  if (nl.cnt) {              // the slot's neighbour lists are complete: walk the point's
+#pragma unroll
+    for (int g = 0; g < NB_W; ++g) {
+      const int cntp = nl.cnt[pos * NB_W + g];
+      const int16_t* lst = nl.pool + (pos * NB_W + g) * NB_SUB;
+      for (int i = lane; i < cntp; i += 64) {
+        const int64_t op = pos + lst[i];
+        f(yorder ? yorder[op] : static_cast<int32_t>(op));
+      }
+    }
+    return;
+  }
   for (int dir = 0; dir < 2; ++dir) {
     for (int64_t j0 = dir ? pos + 1 : pos - 1; dir ? j0 < n : j0 >= 0; j0 += dir ? 64 : -64) {
       const int64_t j = dir ? j0 + lane : j0 - lane;
@@ -981,12 +1008,21 @@ struct GcCand {
 };
 constexpr int GC_T = EPOS_GC_THREADS;  // threads per tile workgroup
 constexpr int GC_W = GC_T / 64;       // waves: each takes every GC_W-th candidate
+// BUILD = true (ransac_nb_build, once per call, right after ransac_init): the same tiles and
+// windows, but instead of relabelling every found neighbour is appended to the point's list
+// -- GC_W sub-lists of NB_SUB entries per point, sub-list g written by the wave that tests
+// every GC_W-th candidate from g on; position deltas, 2 bytes each. The sweeps of every
+// round and the joint refinement walk those lists (100-300 gathers per point on EPOS's
+// many-to-many sets) instead of repeating ~1 100 pair tests per point and sweep; results are
+// the same integers. A slot in which some sub-list does not fit (more than NB_SUB entries, a
+// delta beyond 16 bits) keeps nb_ok = 0 and its sweeps scan the windows as before.
+template <bool BUILD>
 __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
     const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
     const int64_t* __restrict__ slot_base, EposFitParams prm, Work w,
     const uint8_t* __restrict__ lab_in_all, uint8_t* __restrict__ lab_out_all) {
   const int s = blockIdx.y;
-  if (w.state[s] != 1) return;
+  if (BUILD ? w.done[s] != 0 : w.state[s] != 1) return;
   // one 48-byte record per candidate = three ds_read_b128 (round 3; eight separate
   // arrays before: the reads of a candidate were serialised behind one another, ~1000
   // cycles per candidate and wave -- profiles/r03/gc_sweep_ablation.txt)
@@ -1000,10 +1036,13 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
   const int64_t n = slot_base[s + 1] - base;
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
-  const uint8_t* lab_in = lab_in_all + base;
-  uint8_t* lab_out = lab_out_all + base;
+  const uint8_t* lab_in = BUILD ? nullptr : lab_in_all + base;
+  uint8_t* lab_out = BUILD ? nullptr : lab_out_all + base;
   const int32_t* gq = w.gq + base;
   const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
+  uint16_t* nb_cnt = w.nb_cnt + base * GC_W;
+  int16_t* nb_pool = w.nb_pool + base * (GC_W * NB_SUB);
+  const bool use_lists = !BUILD && w.nb_ok[s] != 0;        // uniform over the slot
   const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
   const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
   const double r2 = rad * rad;
@@ -1012,10 +1051,41 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
     const int64_t pos = pos0 + pt;
     const bool valid = pos < n;
     const int32_t p = valid ? (yorder ? yorder[pos] : static_cast<int32_t>(pos)) : 0;
-    const uint8_t lp = valid ? lab_in[p] : 2;
-    const bool act = lp != 2;
+    const uint8_t lp = BUILD ? 0 : (valid ? lab_in[p] : 2);
+    const bool act = BUILD ? valid : lp != 2;
+    int deg = 0, n0 = 0;
+    int64_t S = 0;
+    if (use_lists) {
+      // ---- the point's neighbour list: this wave walks the sub-list it wrote ----------
+      if (valid && act) {
+        const int cntp = nb_cnt[pos * GC_W + sub];
+        const int16_t* lst = nb_pool + (pos * GC_W + sub) * NB_SUB;
+        for (int i0 = 0; i0 < cntp; i0 += 4) {
+          int32_t o[4];
+          int ok4[4], lo4[4], q4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            ok4[u] = i < cntp;
+            const int64_t op = pos + lst[ok4[u] ? i : 0];
+            o[u] = yorder ? yorder[op] : static_cast<int32_t>(op);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { lo4[u] = lab_in[o[u]]; q4[u] = gq[o[u]]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int nb = ok4[u] & static_cast<int>(lo4[u] != 2);
+            deg += nb;
+            S += nb ? q4[u] : 0;
+            n0 += nb & static_cast<int>(lo4[u] == 0);
+          }
+        }
+      }
+    } else {
     const double px = xy[2 * p], py = xy[2 * p + 1];
     const double pX = xyz[3 * p], pY = xyz[3 * p + 1], pZ = xyz[3 * p + 2];
+    int nlist = 0;                 // BUILD: entries in this thread's sub-list
+    bool ovf = false;
     {
       // window of sorted positions whose row can hold a neighbour of a point of the tile:
       // GC_T-ary searches (every thread probes one position per step: two or three
@@ -1066,8 +1136,6 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
       atomicAdd(&g_gc_stats[2], static_cast<unsigned long long>(n));
     }
 #endif
-    int deg = 0, n0 = 0;
-    int64_t S = 0;
     for (int64_t c0 = wlo; c0 < whi; c0 += GC_T) {
       const int64_t c = c0 + t;
       if (c < whi) {
@@ -1075,8 +1143,8 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
         GcCand r;
         r.x = xy[2 * o]; r.y = xy[2 * o + 1];
         r.X = xyz[3 * o]; r.Y = xyz[3 * o + 1]; r.Z = xyz[3 * o + 2];
-        r.q = gq[o];
-        r.ol = o | (static_cast<int32_t>(lab_in[o]) << 30);
+        r.q = BUILD ? 0 : gq[o];
+        r.ol = o | (static_cast<int32_t>(BUILD ? 0 : lab_in[o]) << 30);
         c_rec[t] = r;
       }
       __syncthreads();
@@ -1106,13 +1174,32 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
           const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
           const int nb = okj[u] & static_cast<int>(act) & static_cast<int>(lo_ != 2) &
                          static_cast<int>(co != p) & static_cast<int>(d2 <= r2);
-          deg += nb;
-          S += nb ? cq : 0;
-          n0 += nb & static_cast<int>(lo_ == 0);
+          if (BUILD) {
+            if (nb) {              // position of the candidate: c0 + j
+              const int64_t dl = c0 + (j0 + u * GC_W) - pos;
+              if (nlist < NB_SUB && dl >= -32768 && dl <= 32767)
+                nb_pool[(pos * GC_W + sub) * NB_SUB + nlist] = static_cast<int16_t>(dl);
+              else
+                ovf = true;
+              ++nlist;
+            }
+          } else {
+            deg += nb;
+            S += nb ? cq : 0;
+            n0 += nb & static_cast<int>(lo_ == 0);
+          }
         }
       }
       __syncthreads();
     }
+    if (BUILD) {
+      if (valid) nb_cnt[pos * GC_W + sub] = static_cast<uint16_t>(ovf ? 0 : nlist);
+      if (__any(valid && ovf) && pt == 0)
+        __hip_atomic_store(w.nb_ok + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      continue;
+    }
+    }   // !use_lists
     s_deg[sub][pt] = deg; s_n0[sub][pt] = n0; s_S[sub][pt] = S;
     __syncthreads();
     if (sub == 0 && valid) {
@@ -1340,13 +1427,15 @@ __global__ __launch_bounds__(256) void pearl_energy(
   const int64_t d_out = static_cast<int64_t>((thr2 / tthr2) * static_cast<double>(GC_Q));
   const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
   const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
+  NbLists nl = {nullptr, nullptr};
+  if (w.nb_ok[s]) { nl.cnt = w.nb_cnt + base * NB_W; nl.pool = w.nb_pool + base * (NB_W * NB_SUB); }
   const int nwaves = gridDim.x * 4;
   unsigned long long data = 0, smooth = 0;
   for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nwaves) {
     const int lp = lab[p];
     int diff = 0, deg = 0;
     for_each_neighbour(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2, lane,
-                       [&](int32_t o) { ++deg; diff += lab[o] != lp; });
+                       nl, [&](int32_t o) { ++deg; diff += lab[o] != lp; });
     diff = butterfly_sum_i(diff);
     deg = butterfly_sum_i(deg);
     if (lane == 0) {
@@ -1389,13 +1478,15 @@ __global__ __launch_bounds__(256) void pearl_sweep(
   const int64_t d_out = static_cast<int64_t>((thr2 / tthr2) * static_cast<double>(GC_Q));
   const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
   const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
+  NbLists nl = {nullptr, nullptr};
+  if (w.nb_ok[s]) { nl.cnt = w.nb_cnt + base * NB_W; nl.pool = w.nb_pool + base * (NB_W * NB_SUB); }
   const int nwaves = gridDim.x * 4;
   for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nwaves) {
     int cnt[PEARL_MAX_K + 1];
 #pragma unroll
     for (int m = 0; m <= PEARL_MAX_K; ++m) cnt[m] = 0;
     for_each_neighbour(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2, lane,
-                       [&](int32_t o) {
+                       nl, [&](int32_t o) {
                          const int lo = lab_in[o];
 #pragma unroll
                          for (int m = 0; m <= PEARL_MAX_K; ++m) cnt[m] += lo == m;
@@ -1500,6 +1591,7 @@ struct Layout {
   int64_t cur_pose, cur_score, cur_count, state, tries, last_new, gq, lab_a, lab_b;
   int64_t pearl_pose, pearl_acc, pearl_state, pearl_moved;
   int64_t lo_cnt, lo_data, lo_timeout;
+  int64_t nb_cnt, nb_pool, nb_ok;
 };
 
 // cooperating launches per call: select + refit of every round (max_k + 2 rounds at most)
@@ -1529,6 +1621,9 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.lo_cnt = off; off = align_up(off + static_cast<int64_t>(S + 1) * lo_launches(max_k) * 4);
   L.lo_data = off; off = align_up(off + static_cast<int64_t>(S + 1) * 2 * LO_G * 4 * LO_NV * 8);
   L.lo_timeout = off; off = align_up(off + 8);
+  L.nb_cnt = off; off = align_up(off + (n_cap + 1) * NB_W * 2);
+  L.nb_pool = off; off = align_up(off + (n_cap + 1) * NB_W * NB_SUB * 2);
+  L.nb_ok = off; off = align_up(off + (S + 1) * 4);
   L.pearl_pose = off; off = align_up(off + (S + 1) * PEARL_MAX_K * 12 * 8);
   L.pearl_acc = off; off = align_up(off + (S + 1) * 4 * 8);
   L.pearl_state = off; off = align_up(off + (S + 1) * 4);
@@ -1570,18 +1665,32 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   w.lo_cnt = reinterpret_cast<unsigned*>(wb + L.lo_cnt);
   w.lo_data = reinterpret_cast<double*>(wb + L.lo_data);
   w.lo_timeout = reinterpret_cast<int32_t*>(wb + L.lo_timeout);
+  w.nb_cnt = reinterpret_cast<uint16_t*>(wb + L.nb_cnt);
+  w.nb_pool = reinterpret_cast<int16_t*>(wb + L.nb_pool);
+  w.nb_ok = reinterpret_cast<int32_t*>(wb + L.nb_ok);
   w.pearl_pose = reinterpret_cast<double*>(wb + L.pearl_pose);
   w.pearl_acc = reinterpret_cast<unsigned long long*>(wb + L.pearl_acc);
   w.pearl_state = reinterpret_cast<int32_t*>(wb + L.pearl_state);
   w.pearl_moved = reinterpret_cast<int32_t*>(wb + L.pearl_moved);
   const int n_lo = lo_launches(max_k);
+  const bool gc = p->gc_sweeps > 0 && p->spatial_coherence_weight > 0.0 &&
+                  p->neighborhood_ball_radius > 0.0;
+  static const int use_nb = [] {            // EPOS_FIT_NB_LISTS=0: scan windows every sweep
+    const char* e = getenv("EPOS_FIT_NB_LISTS");
+    return e ? atoi(e) : 1;
+  }();
+  // building the lists costs one sweep's worth of pair tests (~100 us for 5 x 5 000
+  // correspondences), walking them less than half a sweep: it pays from the third
+  // neighbourhood pass of a call on (multi-instance searches, the joint refinement); the
+  // single-instance call of C2 (one round, two sweeps) breaks even and keeps the scans
+  const int nb_rounds = max_k + (max_k > 1 ? 2 : 0);
+  const int build_nb = gc && use_nb && GC_W == NB_W &&     // lists are laid out per wave
+                       nb_rounds * p->gc_sweeps > 2 ? 1 : 0;
   hipLaunchKernelGGL(ransac_init, dim3(S), dim3(256), 0, st, slot_base, S, w, labels,
-                     num_models, p->min_point_number, n_capacity, n_lo);
+                     num_models, p->min_point_number, n_capacity, n_lo, build_nb);
   int rc = launch_status("ransac_init");
   if (rc) return rc;
   const dim3 hgrid(static_cast<unsigned>(ceil_div(p->max_iters, 4)), S);
-  const bool gc = p->gc_sweeps > 0 && p->spatial_coherence_weight > 0.0 &&
-                  p->neighborhood_ball_radius > 0.0;
   // a multi-instance (Progressive-X) search may retry a failed proposal: two extra rounds
   const int rounds = max_k + (max_k > 1 ? 2 : 0);
   // joint refinement kernels: one wavefront per point and pass
@@ -1590,6 +1699,12 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   // labelling sweeps: one workgroup per tile of 64 points (grid-stride beyond 512 tiles)
   const int64_t tiles = ceil_div(per_slot, 64);
   const dim3 sgrid(static_cast<unsigned>(tiles < 1 ? 1 : tiles > 512 ? 512 : tiles), S);
+  if (build_nb) {       // the neighbourhood graph, once: neither labels nor rounds change it
+    hipLaunchKernelGGL(ransac_gc_sweep<true>, sgrid, dim3(GC_T), 0, st, xy, xyz, slot_base, *p,
+                       w, nullptr, nullptr);
+    rc = launch_status("ransac_nb_build");
+    if (rc) return rc;
+  }
   for (int round = 0; round < rounds; ++round) {
     hipLaunchKernelGGL(ransac_hypotheses, hgrid, dim3(256), 0, st, xy, xyz,
                        slot_base, Ks, seeds, max_models, num_models, *p, max_k,
@@ -1606,8 +1721,8 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
       for (int sw = 0; sw < p->gc_sweeps; ++sw) {
         const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
         uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
-        hipLaunchKernelGGL(ransac_gc_sweep, sgrid, dim3(GC_T), 0, st, xy, xyz, slot_base,
-                           *p, w, in, out);
+        hipLaunchKernelGGL(ransac_gc_sweep<false>, sgrid, dim3(GC_T), 0, st, xy, xyz,
+                           slot_base, *p, w, in, out);
         rc = launch_status("ransac_gc_sweep");
         if (rc) return rc;
         lab_final = out;

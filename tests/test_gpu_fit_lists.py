@@ -1,0 +1,55 @@
+"""The neighbour lists of the fitting stage (round 3: the 5-D neighbourhood graph is built
+once per call and walked by the spatial-coherence sweeps of every round and by the joint
+refinement) against the window scans they replace (EPOS_FIT_NB_LISTS=0, read once per
+process: a subprocess per mode). Labels, poses and scores must agree BIT FOR BIT -- the sums
+are integers -- on a sparse scene (lists fit), on a dense many-to-many scene (the lists of at
+least some tiles overflow their caps: that slot falls back to scanning) and on a two-instance
+scene (multi-round search + joint refinement)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import fit_scenes as fs
+from epos_amd import fitting
+out = {}
+rng = np.random.RandomState(5)
+scenes = {
+  'sparse': ([(fs.rand_rot(rng), np.array([20.0, -10.0, 800.0]))], dict(sigma3d=0.5, sym=0.0, outlier=0.1), 1),
+  'dense': ([(fs.rand_rot(rng), np.array([-30.0, 15.0, 520.0]))], dict(sigma3d=0.5, sym=1.0, outlier=1.0), 1),
+  'two': ([(fs.rand_rot(rng), np.array([-38.0, 10.0, 760.0])), (fs.rand_rot(rng), np.array([42.0, -5.0, 790.0]))],
+          dict(sigma3d=0.7, sym=1.0, outlier=0.2), 3),
+}
+for name, (inst, kw, k) in scenes.items():
+  xy, xyz, src, kind = fs.dense_scene(np.random.RandomState(9), inst, **kw)
+  P, lab, sc = fitting.find6DPoses(xy, xyz, fs.K_YCBV, max_model_number=k, seed=3)
+  out[name + '_P'] = np.zeros(0) if P is None else P
+  out[name + '_lab'] = lab
+  out[name + '_sc'] = np.zeros(0) if sc is None else np.asarray(sc)
+  out[name + '_n'] = np.array([len(xy)])
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_neighbour_lists_equal_window_scans(tmp_path):
+  res = {}
+  for mode in ('1', '0'):
+    path = str(tmp_path / ('fit_%s.npz' % mode))
+    r = subprocess.run([sys.executable, '-c', SCRIPT % (ROOT, os.path.join(ROOT, 'tests')), path],
+                       env=dict(os.environ, EPOS_FIT_NB_LISTS=mode), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res[mode] = dict(np.load(path))
+  for k in res['1']:
+    assert np.array_equal(res['1'][k], res['0'][k]), k
+  assert res['1']['sparse_P'].size and res['1']['dense_P'].size and res['1']['two_P'].shape[0] >= 6
+  assert res['1']['dense_n'][0] > 2 * res['1']['sparse_n'][0]

@@ -45,8 +45,9 @@ def build_variant(name, defines):
 
 def build(force=False, verbose=False):
   """Compiles every HIP source into epos_amd/lib/libepos_hip.so: one hipcc job per
-  translation unit (in parallel, objects cached by mtime under lib/obj/), then a link."""
-  if not force and not _stale():
+  translation unit (in parallel; objects cached under lib/obj/ by mtime AND by the compile
+  flags they were built with), then a link with the same target flags."""
+  if not force and not _stale() and _flags_stamp_ok():
     return LIB_PATH
   from concurrent.futures import ThreadPoolExecutor
   obj_dir = os.path.join(LIB_DIR, 'obj')
@@ -55,10 +56,11 @@ def build(force=False, verbose=False):
       os.path.join(HERE, '..', 'include', '*.h'))
   hdr_time = max(os.path.getmtime(h) for h in headers)
   cflags = [f for f in FLAGS if f != '-shared'] + ['-c', '-Wno-inline-asm']
+  flags_changed = not _flags_stamp_ok()
 
   def compile_one(src):
     obj = os.path.join(obj_dir, os.path.basename(src) + '.o')
-    if (not force and os.path.exists(obj) and
+    if (not force and not flags_changed and os.path.exists(obj) and
         os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time)):
       return obj
     cmd = [HIPCC] + cflags + ['-o', obj, src]
@@ -68,11 +70,29 @@ def build(force=False, verbose=False):
     return obj
   with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
     objs = list(ex.map(compile_one, sources()))
-  cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+  link = [f for f in FLAGS if f.startswith('--offload-arch') or f in ('-shared', '-fPIC')]
+  cmd = [HIPCC] + link + ['-o', LIB_PATH] + objs
   if verbose:
     print(' '.join(cmd))
   subprocess.check_call(cmd)
+  with open(_STAMP, 'w') as f:
+    f.write(_flags_key())
   return LIB_PATH
+
+
+_STAMP = os.path.join(LIB_DIR, 'obj', 'flags.stamp')
+
+
+def _flags_key():
+  return ' '.join([HIPCC] + FLAGS)
+
+
+def _flags_stamp_ok():
+  try:
+    with open(_STAMP) as f:
+      return f.read() == _flags_key()
+  except OSError:
+    return False
 
 
 if __name__ == '__main__':

@@ -15,7 +15,8 @@ _lib = None
 def lib():
   global _lib
   if _lib is None:
-    if not os.path.exists(_LIB_PATH):
+    src = os.path.join(_HERE, 'epnp_ref.c')
+    if not os.path.exists(_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_LIB_PATH):
       subprocess.check_call(['make', '-s', '-C', _HERE])
     _lib = ctypes.CDLL(_LIB_PATH)
     _lib.epnp_ref_solve_pnp_ransac.restype = ctypes.c_int

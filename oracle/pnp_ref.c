@@ -52,7 +52,9 @@
  * ARE the minimum cut on sparse neighbourhood graphs (<= 5 neighbours per point), within
  * 0-1.6 % of its energy at 10-14 neighbours; beyond 2 (1 - lambda) / lambda = 18 neighbours
  * the exact minimiser labels (nearly) everything an inlier and the sweeps are a bounded
- * step towards it.
+ * step towards it. gc_sweeps < 0 selects that exact minimiser here
+ * (gc_label_exact: max-flow; a checker-only mode the HIP product does not have), so that the
+ * tests can assert where sweeps and cut coincide.
  *
  * All sums over correspondences use canonical orders so that the wavefront-
  * parallel HIP kernels can reproduce them bit for bit:
@@ -90,7 +92,8 @@ typedef struct PnpRefParams {
   int32_t max_model_number_for_optimization;
   int32_t use_prosac;
   int32_t lo_iters;
-  int32_t gc_sweeps;     /* relabelling sweeps of the spatial-coherence step (0 = off) */
+  int32_t gc_sweeps;     /* relabelling sweeps of the spatial-coherence step (0 = off;
+                          * < 0 = exact s-t minimum cut, oracle only: gc_label_exact) */
   int32_t pearl_iters;   /* joint refinement iterations (0 = off) */
 } PnpRefParams;
 
@@ -443,6 +446,129 @@ static int gc_neighbours(const double* xy, const double* xyz, int32_t a, int32_t
   return d2 <= r2;
 }
 
+/* ---- exact mode (gc_sweeps < 0): s-t minimum cut of the labelling energy ------------
+ * The energy of gc_label below, times 2 Q GC_W / lambda so that every term is an integer:
+ *   unary    inlier: 0 | w Q        outlier: w (Q - q_p) | 0     (q_p < Q | q_p == Q),
+ *            w = round(GC_W 2 (1 - lambda) / lambda)   (18 GC_W at lambda = 0.1)
+ *   pairwise (in, in) GC_W (2 Q - (q_p + q_q)),  (out, out) GC_W (q_p + q_q),  mixed 2 Q GC_W
+ * It is submodular (V(0,0) + V(1,1) = 2 Q <= 4 Q = V(0,1) + V(1,0)), so the standard
+ * construction (Kolmogorov & Zabih, PAMI 2004, table 1: theta(x_i, x_j) = A + (C - A) x_i +
+ * (D - C) x_j + (B + C - A - D) [x_i = 0, x_j = 1]) turns it into a max-flow problem;
+ * Dinic's algorithm on int64 capacities. Source side = outlier; of all minimum cuts the one
+ * with the SMALLEST source side is returned (points not reachable from the source in the
+ * residual graph are inliers) -- the convention of tests/test_oracle_fit.py's scipy twin.
+ * The sweeps are what the HIP product runs; this mode exists so that the tests can say
+ * where the two coincide (sparse graphs) and by how much they differ elsewhere. */
+#define GC_W 1024
+typedef struct { int32_t to, next; int64_t cap; } FlowEdge;
+typedef struct { FlowEdge* e; int32_t* head; int32_t* level; int32_t* it; int32_t ne, nv; } FlowNet;
+
+static void flow_add(FlowNet* g, int32_t a, int32_t b, int64_t cab, int64_t cba) {
+  g->e[g->ne] = (FlowEdge){b, g->head[a], cab}; g->head[a] = g->ne++;
+  g->e[g->ne] = (FlowEdge){a, g->head[b], cba}; g->head[b] = g->ne++;
+}
+
+static int flow_bfs(FlowNet* g, int32_t s, int32_t t, int32_t* queue) {
+  for (int32_t v = 0; v < g->nv; ++v) g->level[v] = -1;
+  int32_t qh = 0, qt = 0;
+  queue[qt++] = s; g->level[s] = 0;
+  while (qh < qt) {
+    const int32_t v = queue[qh++];
+    for (int32_t i = g->head[v]; i >= 0; i = g->e[i].next)
+      if (g->e[i].cap > 0 && g->level[g->e[i].to] < 0) {
+        g->level[g->e[i].to] = g->level[v] + 1;
+        queue[qt++] = g->e[i].to;
+      }
+  }
+  return g->level[t] >= 0;
+}
+
+/* one augmenting path of the level graph (iterative DFS: the graphs are thousands of nodes
+ * deep in the worst case); returns the flow pushed, 0 when the level graph is exhausted */
+static int64_t flow_dfs(FlowNet* g, int32_t s, int32_t t, int32_t* path) {
+  int32_t depth = 0, v = s;
+  for (;;) {
+    if (v == t) {
+      int64_t f = INT64_MAX;
+      for (int32_t d = 0; d < depth; ++d) if (g->e[path[d]].cap < f) f = g->e[path[d]].cap;
+      for (int32_t d = 0; d < depth; ++d) { g->e[path[d]].cap -= f; g->e[path[d] ^ 1].cap += f; }
+      return f;
+    }
+    int advanced = 0;
+    for (int32_t* i = &g->it[v]; *i >= 0; *i = g->e[*i].next) {
+      const FlowEdge* ed = &g->e[*i];
+      if (ed->cap > 0 && g->level[ed->to] == g->level[v] + 1) {
+        path[depth++] = *i; v = ed->to; advanced = 1;
+        break;
+      }
+    }
+    if (advanced) continue;
+    if (depth == 0) return 0;
+    g->level[v] = -1;                                   /* dead end: prune */
+    --depth;
+    v = g->e[path[depth] ^ 1].to;
+  }
+}
+
+static void gc_label_exact(const double* xy, const double* xyz, const int32_t* active,
+                           int64_t n_active, double lam, double rad, double s2, double r2,
+                           const int32_t* q, uint8_t* lab) {
+  const int64_t m = n_active, Q = GC_Q;
+  if (m < 1) return;
+  const int64_t w = llround((double)GC_W * 2.0 * (1.0 - lam) / lam);
+  /* neighbour pairs (i < j in active order) */
+  int64_t n_pairs = 0, cap_pairs = 4 * m + 16;
+  int32_t* pa = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)cap_pairs);
+  for (int64_t i = 0; i < m; ++i)
+    for (int64_t j = i + 1; j < m; ++j) {
+      const int32_t p = active[i], o = active[j];
+      if (fabs(xy[2 * p + 1] - xy[2 * o + 1]) > rad) continue;
+      if (!gc_neighbours(xy, xyz, p, o, s2, r2)) continue;
+      if (n_pairs == cap_pairs) {
+        cap_pairs *= 2;
+        pa = (int32_t*)realloc(pa, sizeof(int32_t) * 2 * (size_t)cap_pairs);
+      }
+      pa[2 * n_pairs] = (int32_t)i; pa[2 * n_pairs + 1] = (int32_t)j; ++n_pairs;
+    }
+  int64_t* th1 = (int64_t*)calloc((size_t)m, sizeof(int64_t));   /* cost of label inlier  */
+  int64_t* th0 = (int64_t*)calloc((size_t)m, sizeof(int64_t));   /* cost of label outlier */
+  for (int64_t i = 0; i < m; ++i) {
+    const int64_t qp = q[active[i]];
+    if (qp < Q) th0[i] = w * (Q - qp); else th1[i] = w * Q;
+  }
+  FlowNet g;
+  g.nv = (int32_t)(m + 2);
+  g.ne = 0;
+  g.e = (FlowEdge*)malloc(sizeof(FlowEdge) * 2 * (size_t)(n_pairs + m));
+  g.head = (int32_t*)malloc(sizeof(int32_t) * (size_t)g.nv);
+  g.level = (int32_t*)malloc(sizeof(int32_t) * (size_t)g.nv);
+  g.it = (int32_t*)malloc(sizeof(int32_t) * (size_t)g.nv);
+  for (int32_t v = 0; v < g.nv; ++v) g.head[v] = -1;
+  for (int64_t k = 0; k < n_pairs; ++k) {
+    const int32_t i = pa[2 * k], j = pa[2 * k + 1];
+    const int64_t sq = (int64_t)q[active[i]] + q[active[j]];
+    const int64_t A = GC_W * sq, B = GC_W * 2 * Q, C = B, D = GC_W * (2 * Q - sq);
+    th1[i] += C - A;
+    th1[j] += D - C;
+    flow_add(&g, i, j, B + C - A - D, 0);
+  }
+  const int32_t src = (int32_t)m, snk = (int32_t)m + 1;
+  for (int64_t i = 0; i < m; ++i) {
+    const int64_t diff = th1[i] - th0[i];
+    if (diff > 0) flow_add(&g, src, (int32_t)i, diff, 0);
+    else if (diff < 0) flow_add(&g, (int32_t)i, snk, -diff, 0);
+  }
+  int32_t* scratch = (int32_t*)malloc(sizeof(int32_t) * (size_t)g.nv);
+  while (flow_bfs(&g, src, snk, scratch)) {
+    for (int32_t v = 0; v < g.nv; ++v) g.it[v] = g.head[v];
+    while (flow_dfs(&g, src, snk, scratch) > 0) {}
+  }
+  flow_bfs(&g, src, snk, scratch);                     /* level >= 0 <=> reachable from src */
+  for (int64_t i = 0; i < m; ++i) lab[active[i]] = g.level[i] >= 0 ? 0 : 1;
+  free(pa); free(th1); free(th0); free(g.e); free(g.head); free(g.level); free(g.it);
+  free(scratch);
+}
+
 /* GC-RANSAC's labelling energy (Barath & Matas CVPR'18, eq. 2-3, in the form of the
  * published implementation's GCRANSAC::labeling): with d_p = min(e_p^2 / (1.5 tau_r)^2, 1)
  *   unary   U_p(inlier) = 0, U_p(outlier) = (1 - lambda)(1 - d_p)   if d_p < 1
@@ -475,6 +601,10 @@ static void gc_label(const double* pose, const double* K, const double* xy,
   if (!(lam > 0.0) || !(rad > 0.0)) return;
   const double s2 = prm->scaling_from_millimeters * prm->scaling_from_millimeters;
   const double r2 = rad * rad;
+  if (prm->gc_sweeps < 0) {       /* checker-only mode: the exact minimiser of the same energy */
+    gc_label_exact(xy, xyz, active, n_active, lam, rad, s2, r2, q, lab);
+    return;
+  }
   for (int sweep = 0; sweep < prm->gc_sweeps; ++sweep) {
     for (int64_t i = 0; i < n_active; ++i) {
       const int32_t p = active[i];
@@ -643,7 +773,7 @@ static void pearl_refine(double* poses, int k, const double* K, const double* xy
                          int32_t* labels) {
   const double lam = prm->spatial_coherence_weight, rad = prm->neighborhood_ball_radius;
   if (k < 2 || k > 8 || k > prm->max_model_number_for_optimization || !(lam > 0.0) ||
-      !(rad > 0.0) || prm->gc_sweeps < 1)
+      !(rad > 0.0) || prm->gc_sweeps == 0)
     return;
   const double tthr = 1.5 * prm->threshold, tthr2 = tthr * tthr;
   const double thr2 = prm->threshold * prm->threshold;
@@ -675,7 +805,7 @@ static void pearl_refine(double* poses, int k, const double* K, const double* xy
     int64_t sm0;
     const int64_t da0 = pearl_energy(D, lab, n, k, xy, xyz, lam, s2, r2, rad, &sm0);
     const double e_before = (1.0 - lam) * (double)da0 + lam * (double)sm0;
-    for (int sweep = 0; sweep < prm->gc_sweeps; ++sweep) {
+    for (int sweep = 0; sweep < (prm->gc_sweeps < 0 ? 2 : prm->gc_sweeps); ++sweep) {
       for (int64_t p = 0; p < n; ++p) {
         int64_t cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         int64_t deg = 0;
@@ -835,7 +965,7 @@ int pnp_ref_find6d_poses(const double* xy, const double* xyz, int64_t n,
         if (!(gain > LO_MIN_GAIN * sc)) break;      /* converged: further steps are noise */
       }
       /* (ii): spatially coherent inlier set -> refits on it */
-      if (prm->gc_sweeps > 0 && prm->spatial_coherence_weight > 0.0 &&
+      if (prm->gc_sweeps != 0 && prm->spatial_coherence_weight > 0.0 &&
           prm->neighborhood_ball_radius > 0.0) {
         gc_label(best_pose, K, xy, xyz, active, n_active, n, prm, lab, lab_tmp, gq);
         for (int li = 0; li < prm->lo_iters; ++li) {

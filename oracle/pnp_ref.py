@@ -44,7 +44,8 @@ def build():
 def lib():
   global _lib
   if _lib is None:
-    if not os.path.exists(_LIB_PATH):
+    src = os.path.join(_HERE, 'pnp_ref.c')
+    if not os.path.exists(_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_LIB_PATH):
       build()
     _lib = ctypes.CDLL(_LIB_PATH)
     _lib.pnp_ref_find6d_poses.restype = ctypes.c_int

@@ -215,6 +215,32 @@ def test_fitting_on_epos_like_scenes_equals_oracle(seed, sigma3d, sym, outlier):
   _same_as_oracle(xy[perm], xyz[perm], seed, use_prosac=True)
 
 
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_fit_equals_oracle_with_exact_min_cuts_on_sparse_graphs(seed):
+  """The product labels by two synchronous sweeps; the C oracle has an exact s-t minimum-cut
+  mode (gc_sweeps < 0, oracle only -- the product refuses it). On sparse neighbourhood graphs
+  (<= 5 neighbours per point) the two coincide, so there the HIP fit equals the oracle's
+  fit WITH EXACT CUTS bit for bit -- the approximation named in DESIGN.md costs nothing."""
+  import sys
+  sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+  from helpers import fit_scenes as fs
+  from epos_amd import fitting
+  from epos_amd._lib import EposError
+  from oracle import pnp_ref
+  rng = np.random.RandomState(140 + seed)
+  R = fs.rand_rot(rng)
+  t = np.array([rng.uniform(-100, 100), rng.uniform(-60, 60), rng.uniform(600, 1000)])
+  xy, xyz, _, _ = fs.dense_scene(rng, [(R, t)], sigma3d=2.0, sym=0.3, outlier=0.3)
+  for rad in (5.0, 8.0):
+    got = fitting.find6DPoses(xy, xyz, K, seed=seed, max_poses=1, neighborhood_ball_radius=rad)
+    ref = pnp_ref.find6DPoses(xy, xyz, K, params=pnp_ref.default_params(
+        neighborhood_ball_radius=rad, gc_sweeps=-1), seed=seed, max_k=1)
+    assert got[0] is not None and np.array_equal(got[1], ref[1])
+    np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=1e-9)
+  with pytest.raises(EposError):
+    fitting.find6DPoses(xy, xyz, K, seed=seed, max_poses=1, gc_sweeps=-1)
+
+
 def test_two_close_instances_of_a_symmetric_object():
   """T-LESS-like (config C4): two instances of one symmetric object whose silhouettes
   touch, every pixel carrying the symmetric counterpart too. Multi-instance search with

@@ -288,3 +288,59 @@ def test_gc_label_against_the_exact_minimum_cut(seed):
   for sweeps in (1, 2, 4):
     got = pnp_ref.gc_label(P, xy, xyz, K, pnp_ref.default_params(gc_sweeps=sweeps)).astype(np.int64)
     assert e_exact <= _labelling_energy(got, q, nb)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 4, 5])
+def test_exact_mode_of_the_c_oracle_is_the_minimum_cut(seed):
+  """gc_sweeps < 0 selects pnp_ref.c's own exact mode (gc_label_exact: Dinic max-flow on the
+  integer energy). Pinned here against scipy's max-flow on graphs from ~1 to ~40 neighbours
+  per point (same labels: both return the minimum cut with the smallest source side), and
+  used to state where the product's two sweeps ARE the exact answer: every graph of at
+  most 5 neighbours per point on average."""
+  from oracle import pnp_ref
+  P, xy, xyz = _near_pose_scene(seed)
+  for rad in (5.0, 8.0, 12.0, 20.0):
+    q, nb, _ = _labelling_terms(P, xy, xyz, rad=rad)
+    exact = pnp_ref.gc_label(P, xy, xyz, K, pnp_ref.default_params(
+        gc_sweeps=-1, neighborhood_ball_radius=rad)).astype(np.int64)
+    assert np.array_equal(exact, _min_cut_labelling(q, nb)), rad
+    sweeps = pnp_ref.gc_label(P, xy, xyz, K, pnp_ref.default_params(
+        gc_sweeps=2, neighborhood_ball_radius=rad)).astype(np.int64)
+    if nb.sum() / len(q) <= 5.0:
+      assert np.array_equal(sweeps, exact), rad
+    else:
+      assert _labelling_energy(exact, q, nb) <= _labelling_energy(sweeps, q, nb)
+
+
+def test_exact_mode_handles_degenerate_graphs():
+  """No neighbours at all (radius below the pixel pitch): the cut is the unary decision
+  q < Q; one point; every point behind the camera."""
+  from oracle import pnp_ref
+  P, xy, xyz = _near_pose_scene(0, n_keep=60)
+  prm = pnp_ref.default_params(gc_sweeps=-1, neighborhood_ball_radius=0.5)
+  q, nb, _ = _labelling_terms(P, xy, xyz, rad=0.5)
+  assert nb.sum() == 0
+  got = pnp_ref.gc_label(P, xy, xyz, K, prm)
+  assert np.array_equal(got.astype(bool), q < (1 << 20))
+  assert pnp_ref.gc_label(P, xy[:1], xyz[:1], K, prm).shape == (1,)
+  back = P.copy()
+  back[:, 3] = [0.0, 0.0, -700.0]
+  assert not pnp_ref.gc_label(back, xy, xyz, K, pnp_ref.default_params(gc_sweeps=-1)).any()
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_fit_with_two_sweeps_equals_fit_with_exact_cuts_on_sparse_graphs(seed):
+  """The whole single-instance fit (proposal -> local optimisation -> labelled refits) with
+  the labelling done by two sweeps and by exact minimum cuts: the same labels and poses
+  on sparse neighbourhood graphs."""
+  from oracle import pnp_ref
+  rng = np.random.RandomState(140 + seed)
+  R = fs.rand_rot(rng)
+  t = np.array([rng.uniform(-100, 100), rng.uniform(-60, 60), rng.uniform(600, 1000)])
+  xy, xyz, _, _ = fs.dense_scene(rng, [(R, t)], sigma3d=2.0, sym=0.3, outlier=0.3)
+  for rad in (5.0, 8.0):
+    a = pnp_ref.find6DPoses(xy, xyz, K, params=pnp_ref.default_params(
+        neighborhood_ball_radius=rad, gc_sweeps=2), seed=seed, max_k=1)
+    b = pnp_ref.find6DPoses(xy, xyz, K, params=pnp_ref.default_params(
+        neighborhood_ball_radius=rad, gc_sweeps=-1), seed=seed, max_k=1)
+    assert a[0] is not None and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])

@@ -370,6 +370,29 @@ __device__ void bearing(const double* K, const double* xy, double* f) {
   f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
 }
 
+#ifdef EPOS_FIT_TRACE   // tools/fit_trace.py: time stamps (100 MHz) of slot 0's first workgroup
+__device__ unsigned long long g_fit_trace[8][32];
+__device__ int g_fit_trace_n[8];
+#define FIT_TRACE(K, COND)                                                      \
+  do {                                                                          \
+    if (COND) {                                                                 \
+      const int i_ = g_fit_trace_n[K];                                          \
+      if (i_ < 32) { g_fit_trace[K][i_] = wall_clock64(); g_fit_trace_n[K] = i_ + 1; } \
+    }                                                                           \
+  } while (0)
+#else
+#define FIT_TRACE(K, COND) do { } while (0)
+#endif
+
+// What a sweep needs of a candidate besides its static geometry. An inactive correspondence
+// carries Z = +inf: its 5-D distance to anything is +inf, so it fails `d2 <= r2` without a
+// label test.
+struct __attribute__((aligned(16))) GcDyn {
+  double Z;
+  int32_t q;            // fixed-point residual
+  int32_t out;          // 1: currently labelled outlier
+};
+
 struct Work {
   double* hyp_score;     // [S][iters][4]
   double* hyp_pose;      // [S][iters][4][12]
@@ -391,6 +414,11 @@ struct Work {
   uint8_t* lab_b;        // [N] labels, pong
   const int32_t* yorder; // [N] correspondences of a slot sorted by image y (or null:
   const int32_t* ypos;   //     they already are), and the inverse permutation
+  // the sweeps' candidate stream, per POSITION of the row-sorted order (ransac_gc_scan):
+  double* geo;           // [N][4] x, y, X, Y -- written once per call by ransac_init
+  int32_t* win;          // [words_total][2] candidate window of every tile of 64 positions
+  GcDyn* dyn_a;          // [N] Z (+inf: not active), residual, "labelled outlier": ping
+  GcDyn* dyn_b;          //     pong (a sweep reads one and writes the other)
   // neighbour lists of the 5-D graph (built once per call: the graph depends on neither
   // labels nor rounds), per POSITION of the row-sorted order
   uint16_t* nb_cnt;      // [N][GC_W] entries of the point's GC_W sub-lists
@@ -443,26 +471,80 @@ __device__ void round_failed(int s, const Work& w, const EposFitParams& prm, int
   if (stop) w.done[s] = 1;
 }
 
-__global__ __launch_bounds__(256) void ransac_init(const int64_t* slot_base, int S,
+__global__ __launch_bounds__(256) void ransac_init(const double* __restrict__ xy_all,
+                                                   const double* __restrict__ xyz_all,
+                                                   const int64_t* slot_base, int S,
                                                    Work w, int32_t* labels,
                                                    int32_t* num_models,
                                                    int min_pts, int64_t n_capacity, int n_lo,
-                                                   int build_nb) {
+                                                   int build_nb, int build_geo, double rad) {
   const int s = blockIdx.x;
-  for (int i = threadIdx.x; i < n_lo; i += blockDim.x)
-    w.lo_cnt[static_cast<int64_t>(s) * n_lo + i] = 0u;
-  if (threadIdx.x == 0) w.nb_ok[s] = build_nb;
-  if (s == 0 && threadIdx.x == 0) *w.lo_timeout = 0;
+  const bool first = blockIdx.y == 0;        // gridDim.y workgroups share the slot's rows
+  if (first) {
+    for (int i = threadIdx.x; i < n_lo; i += blockDim.x)
+      w.lo_cnt[static_cast<int64_t>(s) * n_lo + i] = 0u;
+    if (threadIdx.x == 0) w.nb_ok[s] = build_nb;
+    if (s == 0 && threadIdx.x == 0) *w.lo_timeout = 0;
+  }
   const int64_t base = slot_base[s];
   // A slot whose rows would end beyond the pooled arrays (the correspondence stage
   // raised its overflow flag and wrote nothing there) is fitted as EMPTY: no kernel of
   // this stage then touches a row >= n_capacity. The host reports the overflow.
   const int64_t n = slot_base[s + 1] <= n_capacity ? slot_base[s + 1] - base : 0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int64_t i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += blockDim.x * gridDim.y) {
     w.active[base + i] = static_cast<int32_t>(i);
     labels[base + i] = -1;
+    if (build_geo) {                  // static geometry of the sweeps' candidate stream
+      const int64_t o = w.yorder ? w.yorder[base + i] : i;
+      double* g = w.geo + 4 * (base + i);
+      g[0] = xy_all[2 * (base + o)]; g[1] = xy_all[2 * (base + o) + 1];
+      g[2] = xyz_all[3 * (base + o)]; g[3] = xyz_all[3 * (base + o) + 1];
+    }
   }
-  if (threadIdx.x == 0) {
+  if (build_geo) {
+    // The candidate window of every tile of 64 positions -- the positions whose image row
+    // can hold a neighbour of a point of the tile -- depends on the geometry only: found
+    // here once per call (one wavefront per tile, 64-ary searches over the sorted rows: three
+    // dependent loads per side) instead of by every sweep.
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t waves = static_cast<int64_t>(gridDim.y) * (blockDim.x >> 6);
+    const int32_t* yo = w.yorder ? w.yorder + base : nullptr;
+    const double* ys = xy_all + 2 * base + 1;
+    int32_t* win = w.win + 2 * (base / 64 + s);
+    for (int64_t tile = wave; tile * 64 < n; tile += waves) {
+      const int64_t pos0 = tile * 64;
+      const int64_t last = pos0 + 63 < n ? pos0 + 63 : n - 1;
+      const double ylo = ys[2 * (yo ? yo[pos0] : pos0)] - rad;
+      const double yhi = ys[2 * (yo ? yo[last] : last)] + rad;
+      for (int side = 0; side < 2; ++side) {
+        // side 0: first position in [0, pos0] with y >= ylo; side 1: first position in
+        // [last + 1, n] with y > yhi   (y is non-decreasing along the sorted order)
+        int64_t lo = side ? last + 1 : 0, hi = side ? n : pos0;
+        while (hi - lo > 0) {
+          const int64_t step = (hi - lo + 63) / 64;
+          const int64_t q = lo + lane * step;
+          bool pred = false;
+          if (q < hi) {
+            const double yq = ys[2 * (yo ? yo[q] : q)];
+            pred = side ? yq > yhi : yq >= ylo;
+          }
+          const unsigned long long b = __ballot(pred);
+          if (!b) {                 // no probe at or beyond the bound: it lies after the last
+            const int64_t tv = (hi - lo - 1) / step;
+            lo = lo + tv * step + 1;
+          } else {                  // the bound lies in (probe[first - 1], probe[first]]
+            const int f = __ffsll(static_cast<long long>(b)) - 1;
+            const int64_t qf = lo + static_cast<int64_t>(f) * step;
+            lo = f == 0 ? lo : lo + static_cast<int64_t>(f - 1) * step + 1;
+            hi = qf;
+          }
+        }
+        if (lane == 0) win[2 * tile + side] = static_cast<int32_t>(lo);
+      }
+    }
+  }
+  if (first && threadIdx.x == 0) {
     w.n_active[s] = static_cast<int32_t>(n);
     num_models[s] = 0;
     w.done[s] = (n < min_pts || n < 3) ? 1 : 0;      // infer.py:420-422
@@ -500,6 +582,7 @@ __global__ __launch_bounds__(256) void ransac_hypotheses(
       if (m < 3) m = 3;
       if (m > n_active) m = n_active;
     }
+    FIT_TRACE(0, s == 0 && it == 0 && lane == 0);
     int64_t smp[3];
     sample3(seeds[s], static_cast<uint32_t>(round), static_cast<uint32_t>(it), m, smp);
     double f[9], X[9], p2[6];
@@ -513,7 +596,9 @@ __global__ __launch_bounds__(256) void ransac_hypotheses(
                                    (p2[3] - p2[1]) * (p2[4] - p2[0]));
     if (!(area < prm.min_triangle_area)) {
       double sols[MAX_SOL * 12];
+      FIT_TRACE(0, s == 0 && it == 0 && lane == 0);
       ns = p3p(f, X, sols);
+      FIT_TRACE(0, s == 0 && it == 0 && lane == 0);
       const double thr2 = prm.threshold * prm.threshold;
       double* hp = w.hyp_pose + (static_cast<int64_t>(s) * prm.max_iters + it) * MAX_SOL * 12;
       int32_t* hc = w.hyp_count + (static_cast<int64_t>(s) * prm.max_iters + it) * MAX_SOL;
@@ -536,6 +621,7 @@ __global__ __launch_bounds__(256) void ransac_hypotheses(
   }
   if (lane == 0)
     for (int q = ns; q < MAX_SOL; ++q) hs[q] = -1.0;     // no hypothesis
+  FIT_TRACE(0, s == 0 && it == 0 && lane == 0);
 }
 
 // ------------------------------------------------- local optimisation --
@@ -619,6 +705,7 @@ constexpr int LO_NV = 32;            // doubles per wave row (27 sums, score, co
 constexpr unsigned LO_SPIN_MAX = 1u << 24;
 
 struct LoSync {
+  int trace = 0;        // EPOS_FIT_TRACE: this workgroup stamps the phases of its passes
   unsigned* cnt;        // this launch's counter of the slot (null: single workgroup)
   double* data;         // [2][LO_G * 4][LO_NV]
   int32_t* timeout;
@@ -695,6 +782,7 @@ __device__ int lo_pass(const double* pose, const double* K, const double* xy,
 #pragma unroll
   for (int v = 0; v < 29; ++v) acc[v] = 0.0;
   int cnt = 0;
+  FIT_TRACE(4, sy.trace && t == 0);
   for (int64_t i0 = static_cast<int64_t>(sy.g) * 256 + t; i0 < m;
        i0 += static_cast<int64_t>(stride) * PF) {
     PointBatch pb;
@@ -731,13 +819,16 @@ __device__ int lo_pass(const double* pose, const double* K, const double* xy,
     }
   }
   constexpr int NV = SCORE ? 29 : 27;
+  FIT_TRACE(4, sy.trace && t == 0);
 #pragma unroll
   for (int v = 0; v < 27; ++v) acc[v] = butterfly_sum(acc[v]);
   if (SCORE) {
     acc[27] = butterfly_sum(acc[27]);
     acc[28] = static_cast<double>(butterfly_sum_i(cnt));      // exact: counts < 2^31
   }
+  FIT_TRACE(4, sy.trace && t == 0);
   lo_combine(sy, acc, NV, t, lds->rows, lds->comb);
+  FIT_TRACE(4, sy.trace && t == 0);
   const double* tot = lds->comb;
   if (SCORE) {
     *score = tot[27];
@@ -772,6 +863,7 @@ __device__ int lo_pass(const double* pose, const double* K, const double* xy,
   bool bad = false;
 #pragma unroll
   for (int i = 0; i < 12; ++i) bad = bad || !(next[i] == next[i]);
+  FIT_TRACE(4, sy.trace && t == 0);
   return bad ? 1 : 0;
 }
 
@@ -792,6 +884,7 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   const int g = blockIdx.x;
   const int t = threadIdx.x;
   if (t == 0 && g == 0) w.state[s] = 0;
+  FIT_TRACE(1, s == 0 && g == 0 && t == 0);
   if (w.done[s]) return;                                   // uniform over the slot
   int want = max_models[s];
   if (want < 0 || want > max_k) want = max_k;
@@ -851,6 +944,7 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   double best_score = s_score[0];
   const int bi = s_index[0];
   int best_count = best_score > 0.0 ? hcnt[bi] : 0;
+  FIT_TRACE(1, s == 0 && g == 0 && t == 0);
   if (!(best_score > 0.0) || best_count < 3) {             // uniform
     if (t == 0 && g == 0) round_failed(s, w, prm, want, k, n_active);
     return;
@@ -861,6 +955,9 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   sy.timeout = w.lo_timeout;
   sy.g = g;
   sy.epoch = 0;
+#ifdef EPOS_FIT_TRACE
+  sy.trace = s == 0 && g == 0;
+#endif
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
   double K[9];
@@ -874,13 +971,16 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   // accepted candidate is already there when the next refit starts
   double cand[12];
   const int32_t* idx = n_active == n ? nullptr : active;   // identity while nothing is removed
+  FIT_TRACE(1, s == 0 && g == 0 && t == 0);
   int fail = lo_pass<true>(pose, K, xy, xyz, idx, n_active, thr2, t, sy, &s_lo, nullptr, 1,
                            &best_score, &best_count, cand);
+  FIT_TRACE(1, s == 0 && g == 0 && t == 0);
   for (int li = 0; li < prm.lo_iters && !fail; ++li) {
     double sc, cand2[12];
     int cnt;
     const int fail2 = lo_pass<true>(cand, K, xy, xyz, idx, n_active, thr2, t, sy, &s_lo,
                                     nullptr, 1, &sc, &cnt, cand2);
+    FIT_TRACE(1, s == 0 && g == 0 && t == 0);
     if (!(sc > best_score)) break;
     const double gain = sc - best_score;
     best_score = sc; best_count = cnt;
@@ -904,16 +1004,33 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   int32_t* gq = w.gq + base;
   const int32_t* labels = labels_all + base;
   const double tthr = 1.5 * prm.threshold, tthr2 = tthr * tthr;
+  GcDyn* dyn = w.dyn_a + base;
+  const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
   for (int64_t p = static_cast<int64_t>(g) * 256 + t; p < n; p += 256 * LO_G) {
-    if (labels[p] >= 0) { lab[p] = 2; continue; }
+    const int64_t pos = ypos ? ypos[p] : p;
+    GcDyn dn;
+    dn.Z = xyz[3 * p + 2]; dn.q = GC_Q; dn.out = 1;
+    if (labels[p] >= 0) {
+      lab[p] = 2;
+      dn.Z = __builtin_huge_val(); dn.q = 0; dn.out = 0;
+      dyn[pos] = dn;
+      continue;
+    }
     double e2, Xc[3], r[2];
-    if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) { gq[p] = GC_Q; lab[p] = 0; continue; }
+    if (reproj(pose, K, xy + 2 * p, xyz + 3 * p, &e2, Xc, r)) {
+      gq[p] = GC_Q; lab[p] = 0; dyn[pos] = dn;
+      continue;
+    }
     double d = e2 / tthr2;
     if (!(d < 1.0)) d = 1.0;
-    gq[p] = static_cast<int32_t>(d * static_cast<double>(GC_Q));
+    dn.q = static_cast<int32_t>(d * static_cast<double>(GC_Q));
+    dn.out = e2 < thr2 ? 0 : 1;
+    gq[p] = dn.q;
     lab[p] = e2 < thr2 ? 1 : 0;
+    dyn[pos] = dn;
   }
   if (t == 0 && g == 0) w.state[s] = 1;
+  FIT_TRACE(1, s == 0 && g == 0 && t == 0);
 }
 
 // ---- round, step 3 (gc_sweeps launches): one synchronous relabelling sweep of the
@@ -995,6 +1112,9 @@ __device__ __forceinline__ void for_each_neighbour(const double* xy, const doubl
 // 256 threads per tile: 1024 (16 waves share a tile's window) is 20 % faster for one
 // image at a time (fitting 0.55 vs 0.66 ms) but costs throughput with several images in
 // flight (310 vs 320 images/s, same box: the large workgroups displace GEMM workgroups)
+#ifndef EPOS_GS_WAVES
+#define EPOS_GS_WAVES 16
+#endif
 #ifndef EPOS_GC_THREADS
 #define EPOS_GC_THREADS 256
 #endif
@@ -1221,6 +1341,159 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
   }
 }
 
+// ---- the same sweep with the candidates in SCALAR registers (round 3). A candidate is the
+// same for all 64 points of a tile, so it does not belong in vector registers or LDS at all:
+// every wave walks a contiguous quarter (1 / GS_W) of the tile's window through s_load
+// (32 bytes of static geometry from w.geo + 16 bytes of GcDyn per candidate, position
+// ordered) and the fifteen fp64 operations of the distance take the candidate's fields as
+// SGPR operands. No staging through LDS, no barriers inside the window, no per-candidate
+// index arithmetic; "not active" is Z = +inf instead of a label test, the point itself is
+// counted like any other candidate and taken out once at the end, the residual sum runs
+// in 32 bits per block of GS_BLOCK candidates. Same integers as ransac_gc_sweep<false>
+// (tests/test_gpu_fit_lists.py runs both), ~3x faster: the LDS version spent its time on
+// ds_read latency and on bookkeeping around the 60 cycles of fp64 work per candidate.
+constexpr int GS_W = EPOS_GS_WAVES;      // waves per tile workgroup
+constexpr int GS_T = GS_W * 64;
+constexpr int GS_BLOCK = 2048;           // 2048 x 2^20 < 2^32: the 32-bit sum cannot wrap
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32));
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+struct __attribute__((aligned(32))) GcGeo { double x, y, X, Y; };
+typedef double GsGeoV __attribute__((ext_vector_type(4)));      // x, y, X, Y
+typedef int32_t GsDynV __attribute__((ext_vector_type(4)));     // Z (two words), q, out
+
+__global__ __launch_bounds__(GS_T) void ransac_gc_scan(
+    const int64_t* __restrict__ slot_base, EposFitParams prm, Work w,
+    const GcGeo* __restrict__ geo_all, const GcDyn* __restrict__ dyn_in_all,
+    GcDyn* __restrict__ dyn_out_all, const uint8_t* __restrict__ lab_in_all,
+    uint8_t* __restrict__ lab_out_all) {
+  const int s = blockIdx.y;
+  if (w.state[s] != 1) return;
+  __shared__ int s_deg[GS_W][64], s_n0[GS_W][64];
+  __shared__ int64_t s_S[GS_W][64];
+  const int t = threadIdx.x, pt = t & 63;
+  const int sub = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int64_t base = slot_base[s];
+  const int64_t n = slot_base[s + 1] - base;
+  const GcGeo* __restrict__ geo = geo_all + base;
+  const GcDyn* __restrict__ dyn_in = dyn_in_all + base;
+  GcDyn* __restrict__ dyn_out = dyn_out_all + base;
+  const uint8_t* lab_in = lab_in_all + base;
+  uint8_t* lab_out = lab_out_all + base;
+  const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
+  const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
+  const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
+  const double r2 = rad * rad;
+  FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
+  for (int64_t tile = blockIdx.x; tile * 64 < n; tile += gridDim.x) {
+    const int64_t pos0 = tile * 64;
+    const int64_t pos = pos0 + pt;
+    const bool valid = pos < n;
+    const int64_t posc = valid ? pos : n - 1;
+    const GcGeo me = geo[posc];
+    const GcDyn md = dyn_in[posc];
+    const int32_t p = yorder ? yorder[posc] : static_cast<int32_t>(posc);
+    const bool act = valid && lab_in[p] != 2;
+    // the tile's candidate window: found once per call by ransac_init
+    const int32_t* wn = w.win + 2 * (base / 64 + s + tile);
+    const int64_t wlo = uniform64(wn[0]), whi = uniform64(wn[1]);
+#ifdef EPOS_GC_STATS
+    if (t == 0) {
+      atomicAdd(&g_gc_stats[0], 1ull);
+      atomicAdd(&g_gc_stats[1], static_cast<unsigned long long>(whi - wlo));
+      atomicAdd(&g_gc_stats[2], static_cast<unsigned long long>(n));
+    }
+#endif
+    FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
+    const int64_t chunk = (whi - wlo + GS_W - 1) / GS_W;
+    const int64_t ca = wlo + sub * chunk;
+    const int64_t cb = ca + chunk < whi ? ca + chunk : whi;
+    uint32_t deg = 0, n0 = 0;
+    int64_t S = 0;
+    const double px = me.x, py = me.y, pX = me.X, pY = me.Y, pZ = md.Z;
+// one candidate: its geometry (x, y, X, Y) and dynamic record (Z | q, out) arrive as whole
+// 32- and 16-byte scalar loads; five VALU instructions of bookkeeping (the 0/1 of the
+// test, then 24-bit multiply-adds: q <= 2^20)
+#define EPOS_GS_TEST(G, D)                                                              \
+    {                                                                                   \
+      const double cZ = __builtin_bit_cast(double, (D).xy);                             \
+      const double dx = px - (G).x, dy = py - (G).y;                                    \
+      const double dX = pX - (G).z, dY = pY - (G).w, dZ = pZ - cZ;                      \
+      const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);     \
+      const uint32_t nb = d2 <= r2 ? 1u : 0u;                                           \
+      deg += nb;                                                                        \
+      S32 += __umul24(nb, static_cast<uint32_t>((D).z));                                \
+      n0 += __umul24(nb, static_cast<uint32_t>((D).w));                                 \
+    }
+    const GsGeoV* __restrict__ gv = reinterpret_cast<const GsGeoV*>(geo);
+    const GsDynV* __restrict__ dv = reinterpret_cast<const GsDynV*>(dyn_in);
+    const int64_t clast = n - 1;
+    for (int64_t c0 = ca; c0 < cb; c0 += GS_BLOCK) {
+      const int64_t c1 = c0 + GS_BLOCK < cb ? c0 + GS_BLOCK : cb;
+      uint32_t S32 = 0;
+      int64_t c = c0;
+      // two candidates in flight while two are tested (reads past the block are clamped to
+      // the slot and never tested)
+      GsGeoV ga0 = gv[c < clast ? c : clast], ga1 = gv[c + 1 < clast ? c + 1 : clast];
+      GsDynV da0 = dv[c < clast ? c : clast], da1 = dv[c + 1 < clast ? c + 1 : clast];
+      for (; c + 4 <= c1; c += 4) {
+        const GsGeoV gb0 = gv[c + 2], gb1 = gv[c + 3];
+        const GsDynV db0 = dv[c + 2], db1 = dv[c + 3];
+        EPOS_GS_TEST(ga0, da0)
+        EPOS_GS_TEST(ga1, da1)
+        const int64_t e0 = c + 4 < clast ? c + 4 : clast, e1 = c + 5 < clast ? c + 5 : clast;
+        ga0 = gv[e0]; ga1 = gv[e1]; da0 = dv[e0]; da1 = dv[e1];
+        EPOS_GS_TEST(gb0, db0)
+        EPOS_GS_TEST(gb1, db1)
+      }
+      if (c < c1) {                       // up to three left: ga0 / ga1 hold c, c + 1
+        EPOS_GS_TEST(ga0, da0)
+        if (c + 1 < c1) EPOS_GS_TEST(ga1, da1)
+        if (c + 2 < c1) { const GsGeoV g2 = gv[c + 2]; const GsDynV d2_ = dv[c + 2]; EPOS_GS_TEST(g2, d2_) }
+      }
+      S += S32;
+    }
+    FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
+    if (sub == 0) {          // the point met itself in the window: take it out again
+      uint32_t S32 = 0;
+      uint32_t dself = 0, nself = 0;
+      const GsGeoV mg = gv[posc];
+      const GsDynV mdv = dv[posc];
+      { uint32_t deg = 0, n0 = 0; EPOS_GS_TEST(mg, mdv) dself = deg; nself = n0; }
+      deg -= dself; n0 -= nself; S -= S32;
+    }
+#undef EPOS_GS_TEST
+    s_deg[sub][pt] = static_cast<int>(deg); s_n0[sub][pt] = static_cast<int>(n0); s_S[sub][pt] = S;
+    __syncthreads();
+    if (sub == 0 && valid) {
+      GcDyn nd;
+      nd.Z = md.Z; nd.q = md.q; nd.out = 0;
+      if (!act) {
+        lab_out[p] = 2;
+      } else {
+        int64_t dg = 0, z0 = 0, Ss = 0;
+#pragma unroll
+        for (int g = 0; g < GS_W; ++g) { dg += s_deg[g][pt]; z0 += s_n0[g][pt]; Ss += s_S[g][pt]; }
+        const int64_t qp = md.q;
+        const int64_t T = 2 * static_cast<int64_t>(GC_Q) * z0 - (dg * qp + Ss);
+        const int64_t u = qp < GC_Q ? -2 * (static_cast<int64_t>(GC_Q) - qp)
+                                    : 2 * static_cast<int64_t>(GC_Q);
+        const double val = (1.0 - lam) * static_cast<double>(u) + lam * static_cast<double>(T);
+        const int inl = val < 0.0 ? 1 : 0;
+        lab_out[p] = static_cast<uint8_t>(inl);
+        nd.out = 1 - inl;
+      }
+      dyn_out[pos] = nd;
+    }
+    __syncthreads();
+    FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
+  }
+}
+
 // ---- round, step 4: local optimisation (ii) on the labelled inliers, the instance
 // acceptance tests, labelling + removal of the explained correspondences.
 __global__ __launch_bounds__(256) void ransac_refit_accept(
@@ -1233,6 +1506,7 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
   const int g = blockIdx.x;          // LO_G workgroups refit together; workgroup 0 accepts
   const int t = threadIdx.x;
   const int state = w.state[s];
+  FIT_TRACE(2, s == 0 && g == 0 && t == 0);
   if (state == 0) return;                                  // uniform over the slot
   int want = max_models[s];
   if (want < 0 || want > max_k) want = max_k;
@@ -1266,13 +1540,16 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
     // known); from then on each pass scores a candidate and steps from it
     double cand[12];
     const int32_t* idx = n_active == n ? nullptr : active;
+    FIT_TRACE(2, s == 0 && g == 0 && t == 0);
     int fail = lo_pass<false>(pose, K, xy, xyz, idx, n_active, thr2, t, sy, &s_lo, lab, 1,
                               nullptr, nullptr, cand);
+    FIT_TRACE(2, s == 0 && g == 0 && t == 0);
     for (int li = 0; li < prm.lo_iters && !fail; ++li) {
       double sc, cand2[12];
       int cnt;
       const int fail2 = lo_pass<true>(cand, K, xy, xyz, idx, n_active, thr2, t, sy, &s_lo,
                                       lab, 1, &sc, &cnt, cand2);
+      FIT_TRACE(2, s == 0 && g == 0 && t == 0);
       if (!(sc > best_score)) break;
       const double gain = sc - best_score;
       best_score = sc; best_count = cnt;
@@ -1282,76 +1559,128 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
     }
   }
   if (g != 0) return;          // the siblings only helped with the sums
+  FIT_TRACE(2, s == 0 && t == 0);
   if (best_count < prm.min_point_number) {
     if (t == 0) round_failed(s, w, prm, want, k, n_active);
     return;
   }
-  // ---- inliers over ALL correspondences of the slot -> bitset (chunk c: wave c % 4) --
+  // ---- inliers over ALL correspondences of the slot -> bitset (chunk c: wave c % 4);
+  //      four chunks per trip: their loads are issued together (one dependent round trip
+  //      per trip instead of per chunk -- this loop is latency, not arithmetic)
   const int64_t words = (n + 63) / 64;
   const int64_t wbase = base / 64 + s;
   uint64_t* cur = w.inl_bits + static_cast<int64_t>(k) * w.words_total + wbase;
   int n_inl = 0, n_new = 0;
-  for (int64_t c = wave; c < words; c += 4) {
-    const int64_t i = c * 64 + lane;
-    bool inl = false, fresh = false;
-    if (i < n) {
-      double e2, Xc[3], r[2];
-      if (!reproj(pose, K, xy + 2 * i, xyz + 3 * i, &e2, Xc, r)) inl = e2 < thr2;
-      fresh = inl && labels[i] < 0;
+  for (int64_t c0 = wave; c0 < words; c0 += 16) {
+    double x2[4][2], x3[4][3];
+    int32_t lb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = (c0 + 4 * u) * 64 + lane;
+      const int64_t ic = i < n ? i : n - 1;
+      x2[u][0] = xy[2 * ic]; x2[u][1] = xy[2 * ic + 1];
+      x3[u][0] = xyz[3 * ic]; x3[u][1] = xyz[3 * ic + 1]; x3[u][2] = xyz[3 * ic + 2];
+      lb[u] = labels[ic];
     }
-    const uint64_t bits = __ballot(inl);
-    n_inl += __popcll(bits);
-    n_new += __popcll(__ballot(fresh));
-    if (lane == 0) cur[c] = bits;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t c = c0 + 4 * u;
+      if (c >= words) break;                               // wave-uniform
+      const int64_t i = c * 64 + lane;
+      bool inl = false;
+      double e2, Xc[3], r[2];
+      if (i < n && !reproj(pose, K, x2[u], x3[u], &e2, Xc, r)) inl = e2 < thr2;
+      const bool fresh = inl && lb[u] < 0;
+      const uint64_t bits = __ballot(inl);
+      n_inl += __popcll(bits);
+      n_new += __popcll(__ballot(fresh));
+      if (lane == 0) cur[c] = bits;
+    }
   }
+  __shared__ int s_ok;
+  __shared__ int s_keep[4][4];
   if (lane == 0) { s_inl[wave] = n_inl; s_new[wave] = n_new; }
   __threadfence_block();
   __syncthreads();
-  if (t >= 64) return;                                     // wave 0 finishes the round
+  FIT_TRACE(2, s == 0 && t == 0);
   n_inl = s_inl[0] + s_inl[1] + s_inl[2] + s_inl[3];
   n_new = s_new[0] + s_new[1] + s_new[2] + s_new[3];
-  __threadfence_block();
-  bool ok = n_inl > 0;
-  for (int j = 0; j < k && ok; ++j) {
-    const uint64_t* pj = w.inl_bits + static_cast<int64_t>(j) * w.words_total + wbase;
-    int inter = 0, uni = 0;
-    for (int64_t c = lane; c < words; c += 64) {
-      const uint64_t a = cur[c], b = pj[c];
-      inter += __popcll(a & b);
-      uni += __popcll(a | b);
+  if (wave == 0) {                                         // the acceptance tests
+    bool ok = n_inl > 0;
+    for (int j = 0; j < k && ok; ++j) {
+      const uint64_t* pj = w.inl_bits + static_cast<int64_t>(j) * w.words_total + wbase;
+      int inter = 0, uni = 0;
+      for (int64_t c = lane; c < words; c += 64) {
+        const uint64_t a = cur[c], b = pj[c];
+        inter += __popcll(a & b);
+        uni += __popcll(a | b);
+      }
+      inter = butterfly_sum_i(inter);
+      uni = butterfly_sum_i(uni);
+      if (static_cast<double>(inter) >= prm.max_tanimoto_similarity * static_cast<double>(uni)) ok = false;
     }
-    inter = butterfly_sum_i(inter);
-    uni = butterfly_sum_i(uni);
-    if (static_cast<double>(inter) >= prm.max_tanimoto_similarity * static_cast<double>(uni)) ok = false;
+    if (ok && static_cast<double>(n_new) < prm.min_coverage * static_cast<double>(n_inl)) ok = false;
+    if (lane == 0) s_ok = ok ? 1 : 0;
   }
-  if (ok && static_cast<double>(n_new) < prm.min_coverage * static_cast<double>(n_inl)) ok = false;
-  if (!ok) { if (lane == 0) round_failed(s, w, prm, want, k, n_active); return; }
-  // ---- accept: write the pose, label + remove its inliers (stable compaction) --
-  if (lane < 12) poses[(static_cast<int64_t>(s) * max_k + k) * 12 + lane] = pose[lane];
-  if (lane == 0) scores[static_cast<int64_t>(s) * max_k + k] = best_score;
+  __syncthreads();
+  FIT_TRACE(2, s == 0 && t == 0);
+  if (!s_ok) { if (t == 0) round_failed(s, w, prm, want, k, n_active); return; }
+  // ---- accept: write the pose, label + remove its inliers. Stable compaction of the
+  //      active list IN PLACE by the whole workgroup, 1024 entries per trip: every entry
+  //      of the trip is read before any is written, and a trip only writes below its own
+  //      start + what it kept (positions that have all been read).
+  if (t < 12) poses[(static_cast<int64_t>(s) * max_k + k) * 12 + t] = pose[t];
+  if (t == 0) scores[static_cast<int64_t>(s) * max_k + k] = best_score;
   int64_t wpos = 0;
-  for (int64_t c0 = 0; c0 < n_active; c0 += 64) {
-    const int64_t i = c0 + lane;
-    int32_t p = 0;
-    bool keep = false;
-    if (i < n_active) {
-      p = active[i];
-      const bool inl = (cur[p >> 6] >> (p & 63)) & 1ull;
-      if (inl) labels[p] = k;
-      keep = !inl;
+  for (int64_t c0 = 0; c0 < n_active; c0 += 1024) {
+    int32_t pv[4];
+    bool keep[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = c0 + u * 256 + t;
+      pv[u] = i < n_active ? active[i] : 0;
     }
-    const uint64_t kb = __ballot(keep);
-    const int rank = __popcll(kb & ((1ull << lane) - 1ull));
-    if (keep) active[wpos + rank] = p;
-    wpos += __popcll(kb);
+    uint64_t cw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cw[u] = cur[pv[u] >> 6];
+    int rank[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = c0 + u * 256 + t;
+      const bool inl = i < n_active && ((cw[u] >> (pv[u] & 63)) & 1ull);
+      if (inl) labels[pv[u]] = k;
+      keep[u] = i < n_active && !inl;
+      const uint64_t kb = __ballot(keep[u]);
+      rank[u] = __popcll(kb & ((1ull << lane) - 1ull));
+      if (lane == 0) s_keep[u][wave] = __popcll(kb);
+    }
+    __syncthreads();                       // every entry of the trip has been read
+    int total = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int g2 = 0; g2 < 4; ++g2) total += s_keep[u][g2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int off = 0;
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu)
+#pragma unroll
+        for (int g2 = 0; g2 < 4; ++g2)
+          if (uu * 4 + g2 < u * 4 + wave) off += s_keep[uu][g2];
+      if (keep[u]) active[wpos + off + rank[u]] = pv[u];
+    }
+    wpos += total;
+    __syncthreads();                       // s_keep is reused by the next trip
   }
-  if (lane == 0) {
+  if (t == 0) {
     w.n_active[s] = static_cast<int32_t>(wpos);
     w.tries[s] = 0;
     w.last_new[s] = n_new;
     num_models[s] = k + 1;
     if (k + 1 >= want) w.done[s] = 1;
   }
+  FIT_TRACE(2, s == 0 && t == 0);
 }
 
 // ------------------------------------------------ joint refinement (PEARL's role) --
@@ -1592,6 +1921,7 @@ struct Layout {
   int64_t pearl_pose, pearl_acc, pearl_state, pearl_moved;
   int64_t lo_cnt, lo_data, lo_timeout;
   int64_t nb_cnt, nb_pool, nb_ok;
+  int64_t geo, dyn_a, dyn_b, win;
 };
 
 // cooperating launches per call: select + refit of every round (max_k + 2 rounds at most)
@@ -1624,6 +1954,10 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.nb_cnt = off; off = align_up(off + (n_cap + 1) * NB_W * 2);
   L.nb_pool = off; off = align_up(off + (n_cap + 1) * NB_W * NB_SUB * 2);
   L.nb_ok = off; off = align_up(off + (S + 1) * 4);
+  L.geo = off; off = align_up(off + (n_cap + 1) * 32);
+  L.dyn_a = off; off = align_up(off + (n_cap + 1) * 16);
+  L.dyn_b = off; off = align_up(off + (n_cap + 1) * 16);
+  L.win = off; off = align_up(off + L.words_total * 2 * 4);
   L.pearl_pose = off; off = align_up(off + (S + 1) * PEARL_MAX_K * 12 * 8);
   L.pearl_acc = off; off = align_up(off + (S + 1) * 4 * 8);
   L.pearl_state = off; off = align_up(off + (S + 1) * 4);
@@ -1668,6 +2002,10 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   w.nb_cnt = reinterpret_cast<uint16_t*>(wb + L.nb_cnt);
   w.nb_pool = reinterpret_cast<int16_t*>(wb + L.nb_pool);
   w.nb_ok = reinterpret_cast<int32_t*>(wb + L.nb_ok);
+  w.geo = reinterpret_cast<double*>(wb + L.geo);
+  w.dyn_a = reinterpret_cast<GcDyn*>(wb + L.dyn_a);
+  w.dyn_b = reinterpret_cast<GcDyn*>(wb + L.dyn_b);
+  w.win = reinterpret_cast<int32_t*>(wb + L.win);
   w.pearl_pose = reinterpret_cast<double*>(wb + L.pearl_pose);
   w.pearl_acc = reinterpret_cast<unsigned long long*>(wb + L.pearl_acc);
   w.pearl_state = reinterpret_cast<int32_t*>(wb + L.pearl_state);
@@ -1683,11 +2021,22 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   // correspondences), walking them less than half a sweep: it pays from the third
   // neighbourhood pass of a call on (multi-instance searches, the joint refinement); the
   // single-instance call of C2 (one round, two sweeps) breaks even and keeps the scans
+  // Round 3, later: with the candidates in scalar registers (ransac_gc_scan) a window scan
+  // costs less than walking the lists, so the binary sweeps always scan and the lists are
+  // only built for the joint refinement, whose passes gather per point (EPOS_FIT_SCAN=0:
+  // the LDS sweeps and the rule above).
+  static const int use_scan = [] {
+    const char* e = getenv("EPOS_FIT_SCAN");
+    return e ? atoi(e) : 1;
+  }();
   const int nb_rounds = max_k + (max_k > 1 ? 2 : 0);
+  const bool nb_pays = use_scan ? (max_k >= 2 && p->pearl_iters > 0)
+                                : nb_rounds * p->gc_sweeps > 2;
   const int build_nb = gc && use_nb && GC_W == NB_W &&     // lists are laid out per wave
-                       nb_rounds * p->gc_sweeps > 2 ? 1 : 0;
-  hipLaunchKernelGGL(ransac_init, dim3(S), dim3(256), 0, st, slot_base, S, w, labels,
-                     num_models, p->min_point_number, n_capacity, n_lo, build_nb);
+                       nb_pays ? 1 : 0;
+  hipLaunchKernelGGL(ransac_init, dim3(S, 24), dim3(256), 0, st, xy, xyz, slot_base, S, w, labels,
+                     num_models, p->min_point_number, n_capacity, n_lo, build_nb, gc ? 1 : 0,
+                     p->neighborhood_ball_radius);
   int rc = launch_status("ransac_init");
   if (rc) return rc;
   const dim3 hgrid(static_cast<unsigned>(ceil_div(p->max_iters, 4)), S);
@@ -1721,8 +2070,14 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
       for (int sw = 0; sw < p->gc_sweeps; ++sw) {
         const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
         uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
-        hipLaunchKernelGGL(ransac_gc_sweep<false>, sgrid, dim3(GC_T), 0, st, xy, xyz,
-                           slot_base, *p, w, in, out);
+        if (use_scan)
+          hipLaunchKernelGGL(ransac_gc_scan, sgrid, dim3(GS_T), 0, st, slot_base, *p, w,
+                             reinterpret_cast<const GcGeo*>(w.geo),
+                             (sw & 1) ? w.dyn_b : w.dyn_a, (sw & 1) ? w.dyn_a : w.dyn_b, in,
+                             out);
+        else
+          hipLaunchKernelGGL(ransac_gc_sweep<false>, sgrid, dim3(GC_T), 0, st, xy, xyz,
+                             slot_base, *p, w, in, out);
         rc = launch_status("ransac_gc_sweep");
         if (rc) return rc;
         lab_final = out;
@@ -1891,6 +2246,18 @@ extern "C" int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
     if (d[i]) (void)hipFree(d[i]);
   return rc ? rc : k;
 }
+
+#ifdef EPOS_FIT_TRACE
+extern "C" int epos_debug_fit_trace(unsigned long long* out /*[8][32]*/, int* n8, int reset) {
+  int rc = static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(epos::g_fit_trace), 8 * 32 * 8));
+  rc |= static_cast<int>(hipMemcpyFromSymbol(n8, HIP_SYMBOL(epos::g_fit_trace_n), 32));
+  if (reset) {
+    const int z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    rc |= static_cast<int>(hipMemcpyToSymbol(HIP_SYMBOL(epos::g_fit_trace_n), z, 32));
+  }
+  return rc;
+}
+#endif
 
 #ifdef EPOS_GC_STATS
 extern "C" int epos_debug_gc_stats(unsigned long long* out4, int reset) {

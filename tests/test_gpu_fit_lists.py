@@ -41,15 +41,21 @@ np.savez(sys.argv[1], **out)
 
 
 def test_neighbour_lists_equal_window_scans(tmp_path):
+  """Four builds of the same labelling: window scans with the candidates in scalar registers
+  (the default), the LDS-staged scans they replaced (EPOS_FIT_SCAN=0), each with and without
+  the neighbour lists."""
   res = {}
-  for mode in ('1', '0'):
-    path = str(tmp_path / ('fit_%s.npz' % mode))
+  modes = [('1', '1'), ('1', '0'), ('0', '1'), ('0', '0')]          # (scan, lists)
+  for mode in modes:
+    path = str(tmp_path / ('fit_%s%s.npz' % mode))
     r = subprocess.run([sys.executable, '-c', SCRIPT % (ROOT, os.path.join(ROOT, 'tests')), path],
-                       env=dict(os.environ, EPOS_FIT_NB_LISTS=mode), capture_output=True,
-                       text=True, timeout=600)
+                       env=dict(os.environ, EPOS_FIT_SCAN=mode[0], EPOS_FIT_NB_LISTS=mode[1]),
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     res[mode] = dict(np.load(path))
-  for k in res['1']:
-    assert np.array_equal(res['1'][k], res['0'][k]), k
-  assert res['1']['sparse_P'].size and res['1']['dense_P'].size and res['1']['two_P'].shape[0] >= 6
-  assert res['1']['dense_n'][0] > 2 * res['1']['sparse_n'][0]
+  ref = res[modes[0]]
+  for mode in modes[1:]:
+    for k in ref:
+      assert np.array_equal(ref[k], res[mode][k]), (mode, k)
+  assert ref['sparse_P'].size and ref['dense_P'].size and ref['two_P'].shape[0] >= 6
+  assert ref['dense_n'][0] > 2 * ref['sparse_n'][0]

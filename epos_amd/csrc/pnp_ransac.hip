@@ -641,46 +641,36 @@ __device__ void orthonormalize(double* R) {
 // through scratch memory -- a dependent chain of ~300 private loads and stores that every
 // thread of the workgroup repeated in every refit pass (~6 us of each ~17 us pass).
 __device__ int solve6(const double* H /*[36]*/, const double* g, double* x) {
-  double A[6][7];
+  // H = J^T J is symmetric positive (semi)definite: elimination WITHOUT pivoting is stable
+  // for it, and one reciprocal per pivot serves the column and the back-substitution (round
+  // 3: the pivot search + row swaps through selects and 21 fp64 divisions were 2.5 us of
+  // every 10 us refit pass; the oracle's solve6 is the same arithmetic)
+  double A[6][7], inv[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) A[i][j] = H[i * 6 + j];
     A[i][6] = -g[i];
   }
+  bool bad = false;
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    int piv = c;
-    double best = fabs(A[c][c]);
+    bad = bad || !(A[c][c] > 1e-300);
+    inv[c] = 1.0 / A[c][c];
 #pragma unroll
     for (int r = c + 1; r < 6; ++r) {
-      const double v = fabs(A[r][c]);
-      if (v > best) { best = v; piv = r; }
-    }
-    if (!(best > 1e-300)) return 1;
+      const double fct = A[r][c] * inv[c];
 #pragma unroll
-    for (int r = c + 1; r < 6; ++r) {
-      const bool sw = piv == r;
-#pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const double tc = A[c][j], tr = A[r][j];
-        A[c][j] = sw ? tr : tc;
-        A[r][j] = sw ? tc : tr;
-      }
-    }
-#pragma unroll
-    for (int r = c + 1; r < 6; ++r) {
-      const double fct = A[r][c] / A[c][c];
-#pragma unroll
-      for (int j = c; j < 7; ++j) A[r][j] -= fct * A[c][j];
+      for (int j = c + 1; j < 7; ++j) A[r][j] -= fct * A[c][j];
     }
   }
+  if (bad) return 1;
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
     double sacc = A[i][6];
 #pragma unroll
     for (int j = i + 1; j < 6; ++j) sacc -= A[i][j] * x[j];
-    x[i] = sacc / A[i][i];
+    x[i] = sacc * inv[i];
   }
   return 0;
 }
@@ -713,44 +703,85 @@ struct LoSync {
   unsigned epoch;       // exchanges done so far in this launch
 };
 
-// wv[0..nv): this WAVE's sums (uniform over its lanes). Returns the canonical totals in
-// comb[0..nv) (LDS, valid for every thread after the call). s_rows: LDS [4][LO_NV].
-__device__ void lo_combine(LoSync& sy, const double* wv, int nv, int t, double* s_rows,
+// The wave sums of up to 32 quantities at once. A butterfly per quantity (butterfly_sum:
+// xor 32, 16, ... 1, every lane ends with the total) moves 6 x 2 words per quantity; here the
+// first five levels HALVE the set instead -- at the level of xor-distance d a lane keeps the
+// quantities whose next index bit equals its own bit d and receives its partner's copies of
+// exactly those -- so 16 + 8 + 4 + 2 + 1 + 1 values cross lanes instead of 6 x 32. Every
+// quantity is still summed over the same pairs in the same order (a + b == b + a bit for
+// bit), i.e. the canonical tree of the oracle's tree64. Lane l ends with the total of
+// quantity lo_owned(l).
+__device__ __forceinline__ int lo_owned(int lane) {        // bits 5..1 of the lane, reversed
+  return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) |
+         (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4);
+}
+__device__ __forceinline__ double reduce_scatter32(double (&a)[32], int lane) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int off = 32 >> k;
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < (16 >> k); ++i) {
+      const double keep = up ? a[2 * i + 1] : a[2 * i];
+      const double send = up ? a[2 * i] : a[2 * i + 1];
+      a[i] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  return a[0] + __shfl_xor(a[0], 1, 64);
+}
+
+// val: the total over this WAVE of quantity lo_owned(lane) (reduce_scatter32). Returns the
+// canonical totals in comb[0..nv) (LDS, valid for every thread after the call). s_rows:
+// LDS [4][LO_NV].
+__device__ void lo_combine(LoSync& sy, double val, int nv, int t, double* s_rows,
                            double* comb) {
   const int lane = t & 63, wave = t >> 6;
+  const int own = lo_owned(lane);
+  const bool writer = (lane & 1) == 0 && own < nv;
   if (sy.cnt == nullptr) {                       // one workgroup: through LDS only
-    if (lane == 0)
-      for (int v = 0; v < nv; ++v) s_rows[wave * LO_NV + v] = wv[v];
+    if (writer) s_rows[wave * LO_NV + own] = val;
     __syncthreads();
     if (t < nv)
       comb[t] = (s_rows[t] + s_rows[LO_NV + t]) + (s_rows[2 * LO_NV + t] + s_rows[3 * LO_NV + t]);
     __syncthreads();
     return;
   }
-  double* buf = sy.data + (sy.epoch & 1u) * (LO_G * 4 * LO_NV);
-  if (lane == 0)
-    for (int v = 0; v < nv; ++v) buf[(sy.g * 4 + wave) * LO_NV + v] = wv[v];
+  // The exchanged words are written and read by AGENT-SCOPE ATOMIC stores / loads (sc1: they
+  // are coherent across the XCDs' L2s by themselves), so the hand-off needs no release /
+  // acquire fence -- on this part a fence is a write-back / invalidate of the whole L2,
+  // which costs microseconds while other streams' GEMMs keep it dirty: every storing wave
+  // waits for its stores to complete, the workgroup meets, ONE relaxed ticket, relaxed
+  // polling, and the reads are issued after the poll returned (they depend on it).
+  unsigned long long* buf = reinterpret_cast<unsigned long long*>(sy.data) +
+                            (sy.epoch & 1u) * (LO_G * 4 * LO_NV);
+  if (writer)
+    __hip_atomic_store(buf + (sy.g * 4 + wave) * LO_NV + own,
+                       __builtin_bit_cast(unsigned long long, val), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
   __syncthreads();
   if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(sy.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = LO_G * (sy.epoch + 1u);
     unsigned spins = 0;
     while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > LO_SPIN_MAX) { *sy.timeout = 1; break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   __syncthreads();
   if (t < nv) {
     double W[LO_G];
 #pragma unroll
     for (int g = 0; g < LO_G; ++g) {
-      const double* r = buf + (g * 4) * LO_NV + t;
-      W[g] = (r[0] + r[LO_NV]) + (r[2 * LO_NV] + r[3 * LO_NV]);
+      const unsigned long long* r = buf + (g * 4) * LO_NV + t;
+      double r4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        r4[q] = __builtin_bit_cast(double, __hip_atomic_load(r + q * LO_NV, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+      W[g] = (r4[0] + r4[1]) + (r4[2] + r4[3]);
     }
     comb[t] = (W[0] + W[1]) + (W[2] + W[3]);
   }
@@ -778,9 +809,9 @@ __device__ int lo_pass(const double* pose, const double* K, const double* xy,
   const int G = sy.cnt ? LO_G : 1;
   const int stride = 256 * G;
   const double inv_thr2 = 1.0 / thr2;
-  double acc[29];
+  double acc[32];
 #pragma unroll
-  for (int v = 0; v < 29; ++v) acc[v] = 0.0;
+  for (int v = 0; v < 32; ++v) acc[v] = 0.0;
   int cnt = 0;
   FIT_TRACE(4, sy.trace && t == 0);
   for (int64_t i0 = static_cast<int64_t>(sy.g) * 256 + t; i0 < m;
@@ -820,14 +851,10 @@ __device__ int lo_pass(const double* pose, const double* K, const double* xy,
   }
   constexpr int NV = SCORE ? 29 : 27;
   FIT_TRACE(4, sy.trace && t == 0);
-#pragma unroll
-  for (int v = 0; v < 27; ++v) acc[v] = butterfly_sum(acc[v]);
-  if (SCORE) {
-    acc[27] = butterfly_sum(acc[27]);
-    acc[28] = static_cast<double>(butterfly_sum_i(cnt));      // exact: counts < 2^31
-  }
+  if (SCORE) acc[28] = static_cast<double>(cnt);     // exact in any order: counts < 2^31
+  const double mine = reduce_scatter32(acc, t & 63);
   FIT_TRACE(4, sy.trace && t == 0);
-  lo_combine(sy, acc, NV, t, lds->rows, lds->comb);
+  lo_combine(sy, mine, NV, t, lds->rows, lds->comb);
   FIT_TRACE(4, sy.trace && t == 0);
   const double* tot = lds->comb;
   if (SCORE) {
@@ -1115,6 +1142,9 @@ __device__ __forceinline__ void for_each_neighbour(const double* xy, const doubl
 #ifndef EPOS_GS_WAVES
 #define EPOS_GS_WAVES 16
 #endif
+#ifndef EPOS_GS_POINTS
+#define EPOS_GS_POINTS 1
+#endif
 #ifndef EPOS_GC_THREADS
 #define EPOS_GC_THREADS 256
 #endif
@@ -1342,17 +1372,21 @@ __global__ __launch_bounds__(GC_T) void ransac_gc_sweep(
 }
 
 // ---- the same sweep with the candidates in SCALAR registers (round 3). A candidate is the
-// same for all 64 points of a tile, so it does not belong in vector registers or LDS at all:
-// every wave walks a contiguous quarter (1 / GS_W) of the tile's window through s_load
-// (32 bytes of static geometry from w.geo + 16 bytes of GcDyn per candidate, position
-// ordered) and the fifteen fp64 operations of the distance take the candidate's fields as
-// SGPR operands. No staging through LDS, no barriers inside the window, no per-candidate
-// index arithmetic; "not active" is Z = +inf instead of a label test, the point itself is
-// counted like any other candidate and taken out once at the end, the residual sum runs
-// in 32 bits per block of GS_BLOCK candidates. Same integers as ransac_gc_sweep<false>
-// (tests/test_gpu_fit_lists.py runs both), ~3x faster: the LDS version spent its time on
-// ds_read latency and on bookkeeping around the 60 cycles of fp64 work per candidate.
-constexpr int GS_W = EPOS_GS_WAVES;      // waves per tile workgroup
+// same for all points of a tile, so it does not belong in vector registers or LDS at all:
+// every wave walks a contiguous share (1 / GS_W) of the window through s_load (32 bytes of
+// static geometry from w.geo + 16 bytes of GcDyn per candidate, position ordered) and the
+// fifteen fp64 operations of the distance take the candidate's fields as SGPR operands. No
+// staging through LDS, no barriers inside the window, no per-candidate index arithmetic; "not
+// active" is Z = +inf instead of a label test, the point itself is counted like any other
+// candidate and taken out once at the end, the residual sum runs in 32 bits per block of
+// GS_BLOCK candidates. The scalar cache streams poorly (every line is a miss to L2 and few
+// misses are in flight: GS_P = 1 ran at ~0.5 bytes per ns and CU pair), so a lane holds
+// GS_P points -- a workgroup covers GS_P adjacent tiles, whose windows are nearly the same
+// rows -- and every loaded candidate is tested GS_P times. The waves' partial counts meet in
+// LDS by integer atomics (exact, order free). Same integers as ransac_gc_sweep<false>
+// (tests/test_gpu_fit_lists.py runs both).
+constexpr int GS_W = EPOS_GS_WAVES;      // waves per workgroup: shares of the window
+constexpr int GS_P = EPOS_GS_POINTS;     // points per lane: adjacent tiles per workgroup
 constexpr int GS_T = GS_W * 64;
 constexpr int GS_BLOCK = 2048;           // 2048 x 2^20 < 2^32: the 32-bit sum cannot wrap
 
@@ -1373,8 +1407,8 @@ __global__ __launch_bounds__(GS_T) void ransac_gc_scan(
     uint8_t* __restrict__ lab_out_all) {
   const int s = blockIdx.y;
   if (w.state[s] != 1) return;
-  __shared__ int s_deg[GS_W][64], s_n0[GS_W][64];
-  __shared__ int64_t s_S[GS_W][64];
+  __shared__ unsigned s_deg[GS_P * 64], s_n0[GS_P * 64];
+  __shared__ unsigned long long s_S[GS_P * 64];
   const int t = threadIdx.x, pt = t & 63;
   const int sub = __builtin_amdgcn_readfirstlane(t >> 6);
   const int64_t base = slot_base[s];
@@ -1388,19 +1422,20 @@ __global__ __launch_bounds__(GS_T) void ransac_gc_scan(
   const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
   const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
   const double r2 = rad * rad;
+  const GsGeoV* __restrict__ gv = reinterpret_cast<const GsGeoV*>(geo);
+  const GsDynV* __restrict__ dv = reinterpret_cast<const GsDynV*>(dyn_in);
+  const int64_t clast = n - 1;
+  const int64_t tiles = (n + 63) / 64;
   FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
-  for (int64_t tile = blockIdx.x; tile * 64 < n; tile += gridDim.x) {
-    const int64_t pos0 = tile * 64;
-    const int64_t pos = pos0 + pt;
-    const bool valid = pos < n;
-    const int64_t posc = valid ? pos : n - 1;
-    const GcGeo me = geo[posc];
-    const GcDyn md = dyn_in[posc];
-    const int32_t p = yorder ? yorder[posc] : static_cast<int32_t>(posc);
-    const bool act = valid && lab_in[p] != 2;
-    // the tile's candidate window: found once per call by ransac_init
-    const int32_t* wn = w.win + 2 * (base / 64 + s + tile);
-    const int64_t wlo = uniform64(wn[0]), whi = uniform64(wn[1]);
+  for (int64_t grp = blockIdx.x; grp * GS_P < tiles; grp += gridDim.x) {
+    const int64_t tile0 = grp * GS_P;
+    const int64_t tile1 = tile0 + GS_P - 1 < tiles - 1 ? tile0 + GS_P - 1 : tiles - 1;
+    const int64_t pos0 = tile0 * 64;
+    // the group's candidate window: first tile's lower bound .. last tile's upper bound
+    // (found once per call by ransac_init; the bounds are monotone along the order)
+    const int32_t* wn = w.win + 2 * (base / 64 + s);
+    const int64_t wlo = uniform64(wn[2 * tile0]), whi = uniform64(wn[2 * tile1 + 1]);
+    for (int i = t; i < GS_P * 64; i += GS_T) { s_deg[i] = 0u; s_n0[i] = 0u; s_S[i] = 0ull; }
 #ifdef EPOS_GC_STATS
     if (t == 0) {
       atomicAdd(&g_gc_stats[0], 1ull);
@@ -1408,38 +1443,66 @@ __global__ __launch_bounds__(GS_T) void ransac_gc_scan(
       atomicAdd(&g_gc_stats[2], static_cast<unsigned long long>(n));
     }
 #endif
+    double px[GS_P], py[GS_P], pX[GS_P], pY[GS_P], pZ[GS_P];
+    uint32_t deg[GS_P], n0[GS_P], S32[GS_P];
+    unsigned long long S[GS_P];
+#pragma unroll
+    for (int j = 0; j < GS_P; ++j) {
+      const int64_t pos = pos0 + j * 64 + pt;
+      const int64_t posc = pos < n ? pos : clast;
+      const GsGeoV mg = gv[posc];
+      const GsDynV md = dv[posc];
+      px[j] = mg.x; py[j] = mg.y; pX[j] = mg.z; pY[j] = mg.w;
+      pZ[j] = __builtin_bit_cast(double, md.xy);
+      deg[j] = 0; n0[j] = 0; S32[j] = 0; S[j] = 0;
+    }
+    __syncthreads();                                 // the LDS counters are zero
     FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
     const int64_t chunk = (whi - wlo + GS_W - 1) / GS_W;
     const int64_t ca = wlo + sub * chunk;
     const int64_t cb = ca + chunk < whi ? ca + chunk : whi;
-    uint32_t deg = 0, n0 = 0;
-    int64_t S = 0;
-    const double px = me.x, py = me.y, pX = me.X, pY = me.Y, pZ = md.Z;
 // one candidate: its geometry (x, y, X, Y) and dynamic record (Z | q, out) arrive as whole
-// 32- and 16-byte scalar loads; five VALU instructions of bookkeeping (the 0/1 of the
-// test, then 24-bit multiply-adds: q <= 2^20)
-#define EPOS_GS_TEST(G, D)                                                              \
-    {                                                                                   \
-      const double cZ = __builtin_bit_cast(double, (D).xy);                             \
-      const double dx = px - (G).x, dy = py - (G).y;                                    \
-      const double dX = pX - (G).z, dY = pY - (G).w, dZ = pZ - cZ;                      \
-      const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);     \
-      const uint32_t nb = d2 <= r2 ? 1u : 0u;                                           \
-      deg += nb;                                                                        \
-      S32 += __umul24(nb, static_cast<uint32_t>((D).z));                                \
-      n0 += __umul24(nb, static_cast<uint32_t>((D).w));                                 \
+// 32- and 16-byte scalar loads and are tested against the lane's GS_P points
+#define EPOS_GS_TEST(G, D)                                                                \
+    {                                                                                     \
+      const double cZ = __builtin_bit_cast(double, (D).xy);                               \
+      _Pragma("unroll") for (int j = 0; j < GS_P; ++j) {                                  \
+        const double dx = px[j] - (G).x, dy = py[j] - (G).y;                              \
+        const double dX = pX[j] - (G).z, dY = pY[j] - (G).w, dZ = pZ[j] - cZ;             \
+        const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);     \
+        const uint32_t nb = d2 <= r2 ? 1u : 0u;                                           \
+        deg[j] += nb;                                                                     \
+        S32[j] += __umul24(nb, static_cast<uint32_t>((D).z));                             \
+        n0[j] += __umul24(nb, static_cast<uint32_t>((D).w));                              \
+      }                                                                                   \
     }
-    const GsGeoV* __restrict__ gv = reinterpret_cast<const GsGeoV*>(geo);
-    const GsDynV* __restrict__ dv = reinterpret_cast<const GsDynV*>(dyn_in);
-    const int64_t clast = n - 1;
     for (int64_t c0 = ca; c0 < cb; c0 += GS_BLOCK) {
       const int64_t c1 = c0 + GS_BLOCK < cb ? c0 + GS_BLOCK : cb;
-      uint32_t S32 = 0;
       int64_t c = c0;
       // two candidates in flight while two are tested (reads past the block are clamped to
       // the slot and never tested)
       GsGeoV ga0 = gv[c < clast ? c : clast], ga1 = gv[c + 1 < clast ? c + 1 : clast];
       GsDynV da0 = dv[c < clast ? c : clast], da1 = dv[c + 1 < clast ? c + 1 : clast];
+#if defined(EPOS_GS_ABL_NOLOAD)   // ablation (tools/): the arithmetic alone, one candidate reused
+      const GsGeoV gb0 = gv[c + 2 < clast ? c + 2 : clast], gb1 = gv[c + 3 < clast ? c + 3 : clast];
+      const GsDynV db0 = dv[c + 2 < clast ? c + 2 : clast], db1 = dv[c + 3 < clast ? c + 3 : clast];
+      for (; c + 4 <= c1; c += 4) {
+        EPOS_GS_TEST(ga0, da0)
+        EPOS_GS_TEST(ga1, da1)
+        EPOS_GS_TEST(gb0, db0)
+        EPOS_GS_TEST(gb1, db1)
+        asm volatile("" ::: "memory");
+      }
+#elif defined(EPOS_GS_ABL_NOMATH)  // ablation: the scalar loads alone
+      for (; c + 4 <= c1; c += 4) {
+        const GsGeoV gb0 = gv[c + 2], gb1 = gv[c + 3];
+        const GsDynV db0 = dv[c + 2], db1 = dv[c + 3];
+        deg[0] += (ga0.x == 1e300 ? 1u : 0u) + (ga1.x == 1e300 ? 1u : 0u) + (da0.z == -5 ? 1u : 0u) + (da1.z == -5 ? 1u : 0u);
+        const int64_t e0 = c + 4 < clast ? c + 4 : clast, e1 = c + 5 < clast ? c + 5 : clast;
+        ga0 = gv[e0]; ga1 = gv[e1]; da0 = dv[e0]; da1 = dv[e1];
+        deg[0] += (gb0.x == 1e300 ? 1u : 0u) + (gb1.x == 1e300 ? 1u : 0u) + (db0.z == -5 ? 1u : 0u) + (db1.z == -5 ? 1u : 0u);
+      }
+#else
       for (; c + 4 <= c1; c += 4) {
         const GsGeoV gb0 = gv[c + 2], gb1 = gv[c + 3];
         const GsDynV db0 = dv[c + 2], db1 = dv[c + 3];
@@ -1450,35 +1513,46 @@ __global__ __launch_bounds__(GS_T) void ransac_gc_scan(
         EPOS_GS_TEST(gb0, db0)
         EPOS_GS_TEST(gb1, db1)
       }
+#endif
       if (c < c1) {                       // up to three left: ga0 / ga1 hold c, c + 1
         EPOS_GS_TEST(ga0, da0)
         if (c + 1 < c1) EPOS_GS_TEST(ga1, da1)
         if (c + 2 < c1) { const GsGeoV g2 = gv[c + 2]; const GsDynV d2_ = dv[c + 2]; EPOS_GS_TEST(g2, d2_) }
       }
-      S += S32;
-    }
-    FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
-    if (sub == 0) {          // the point met itself in the window: take it out again
-      uint32_t S32 = 0;
-      uint32_t dself = 0, nself = 0;
-      const GsGeoV mg = gv[posc];
-      const GsDynV mdv = dv[posc];
-      { uint32_t deg = 0, n0 = 0; EPOS_GS_TEST(mg, mdv) dself = deg; nself = n0; }
-      deg -= dself; n0 -= nself; S -= S32;
+#pragma unroll
+      for (int j = 0; j < GS_P; ++j) { S[j] += S32[j]; S32[j] = 0; }
     }
 #undef EPOS_GS_TEST
-    s_deg[sub][pt] = static_cast<int>(deg); s_n0[sub][pt] = static_cast<int>(n0); s_S[sub][pt] = S;
+    FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
+#pragma unroll
+    for (int j = 0; j < GS_P; ++j) {
+      atomicAdd(&s_deg[j * 64 + pt], deg[j]);
+      atomicAdd(&s_n0[j * 64 + pt], n0[j]);
+      atomicAdd(&s_S[j * 64 + pt], S[j]);
+    }
     __syncthreads();
-    if (sub == 0 && valid) {
+    // wave j (when there are fewer waves than tiles: j, j + GS_W, ...) decides tile j
+    for (int j = sub; j < GS_P; j += GS_W) {
+      const int64_t pos = pos0 + j * 64 + pt;
+      if (pos >= n) continue;
+      const GsGeoV mg = gv[pos];
+      const GsDynV md = dv[pos];
+      const int32_t p = yorder ? yorder[pos] : static_cast<int32_t>(pos);
+      const double mZ = __builtin_bit_cast(double, md.xy);
       GcDyn nd;
-      nd.Z = md.Z; nd.q = md.q; nd.out = 0;
-      if (!act) {
+      nd.Z = mZ; nd.q = md.z; nd.out = 0;
+      if (lab_in[p] == 2) {
         lab_out[p] = 2;
       } else {
-        int64_t dg = 0, z0 = 0, Ss = 0;
-#pragma unroll
-        for (int g = 0; g < GS_W; ++g) { dg += s_deg[g][pt]; z0 += s_n0[g][pt]; Ss += s_S[g][pt]; }
-        const int64_t qp = md.q;
+        // the point met itself in the window: take it out again (the same test on itself)
+        const double dx = mg.x - mg.x, dy = mg.y - mg.y;
+        const double dX = mg.z - mg.z, dY = mg.w - mg.w, dZ = mZ - mZ;
+        const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
+        const int64_t self = d2 <= r2 ? 1 : 0;
+        const int64_t qp = md.z;
+        const int64_t dg = static_cast<int64_t>(s_deg[j * 64 + pt]) - self;
+        const int64_t z0 = static_cast<int64_t>(s_n0[j * 64 + pt]) - self * md.w;
+        const int64_t Ss = static_cast<int64_t>(s_S[j * 64 + pt]) - self * qp;
         const int64_t T = 2 * static_cast<int64_t>(GC_Q) * z0 - (dg * qp + Ss);
         const int64_t u = qp < GC_Q ? -2 * (static_cast<int64_t>(GC_Q) - qp)
                                     : 2 * static_cast<int64_t>(GC_Q);
@@ -2071,7 +2145,9 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
         const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
         uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
         if (use_scan)
-          hipLaunchKernelGGL(ransac_gc_scan, sgrid, dim3(GS_T), 0, st, slot_base, *p, w,
+          hipLaunchKernelGGL(ransac_gc_scan,
+                             dim3(static_cast<unsigned>(ceil_div(sgrid.x, GS_P)), S), dim3(GS_T),
+                             0, st, slot_base, *p, w,
                              reinterpret_cast<const GcGeo*>(w.geo),
                              (sw & 1) ? w.dyn_b : w.dyn_a, (sw & 1) ? w.dyn_a : w.dyn_b, in,
                              out);

@@ -636,25 +636,28 @@ static void orthonormalize(double* R) {   /* Gram-Schmidt on rows, row2 = r0 x r
   cross3(R, R + 3, R + 6);
 }
 
-/* solve H x = -g for symmetric positive (semi)definite 6x6 by Gaussian
- * elimination with partial pivoting; returns 0 on success */
+/* solve H x = -g for the symmetric positive (semi)definite 6x6 H = J^T J by Gaussian
+ * elimination WITHOUT pivoting (stable for such matrices), one reciprocal per pivot
+ * (used for its column and in the back-substitution); returns 0 on success, 1 when a pivot
+ * is not positive. The HIP kernels run the same arithmetic (round 3: the pivot search of
+ * the first version cost the GPU more than the elimination). */
 static int solve6(double H[6][6], const double* g, double* x) {
-  double A[6][7];
+  double A[6][7], inv[6];
   for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) A[i][j] = H[i][j]; A[i][6] = -g[i]; }
+  int bad = 0;
   for (int c = 0; c < 6; ++c) {
-    int piv = c;
-    for (int r = c + 1; r < 6; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
-    if (!(fabs(A[piv][c]) > 1e-300)) return 1;
-    if (piv != c) for (int j = 0; j < 7; ++j) { double tmp = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = tmp; }
+    if (!(A[c][c] > 1e-300)) bad = 1;
+    inv[c] = 1.0 / A[c][c];
     for (int r = c + 1; r < 6; ++r) {
-      const double fct = A[r][c] / A[c][c];
-      for (int j = c; j < 7; ++j) A[r][j] -= fct * A[c][j];
+      const double fct = A[r][c] * inv[c];
+      for (int j = c + 1; j < 7; ++j) A[r][j] -= fct * A[c][j];
     }
   }
+  if (bad) return 1;
   for (int i = 5; i >= 0; --i) {
     double s = A[i][6];
     for (int j = i + 1; j < 6; ++j) s -= A[i][j] * x[j];
-    x[i] = s / A[i][i];
+    x[i] = s * inv[i];
   }
   return 0;
 }

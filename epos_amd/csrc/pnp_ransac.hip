@@ -393,6 +393,13 @@ struct __attribute__((aligned(16))) GcDyn {
   int32_t out;          // 1: currently labelled outlier
 };
 
+// Raw sums of a full scan over a point's window, the point itself included: the number of
+// neighbours, of neighbours labelled outlier, and the neighbours' fixed-point residuals.
+struct __attribute__((aligned(16))) GcAcc {
+  uint32_t deg, n0;
+  unsigned long long S;
+};
+
 struct Work {
   double* hyp_score;     // [S][iters][4]
   double* hyp_pose;      // [S][iters][4][12]
@@ -417,6 +424,9 @@ struct Work {
   // the sweeps' candidate stream, per POSITION of the row-sorted order (ransac_gc_scan):
   double* geo;           // [N][4] x, y, X, Y -- written once per call by ransac_init
   int32_t* win;          // [words_total][2] candidate window of every tile of 64 positions
+  GcAcc* acc;            // [N] raw neighbour sums of the last full scan (self included)
+  int8_t* flip_a;        // [N] label change of the last sweep per position: +1 became
+  int8_t* flip_b;        //     outlier, -1 became inlier, 0 unchanged / not active (ping, pong)
   GcDyn* dyn_a;          // [N] Z (+inf: not active), residual, "labelled outlier": ping
   GcDyn* dyn_b;          //     pong (a sweep reads one and writes the other)
   // neighbour lists of the 5-D graph (built once per call: the graph depends on neither
@@ -1404,7 +1414,7 @@ __global__ __launch_bounds__(GS_T) void ransac_gc_scan(
     const int64_t* __restrict__ slot_base, EposFitParams prm, Work w,
     const GcGeo* __restrict__ geo_all, const GcDyn* __restrict__ dyn_in_all,
     GcDyn* __restrict__ dyn_out_all, const uint8_t* __restrict__ lab_in_all,
-    uint8_t* __restrict__ lab_out_all) {
+    uint8_t* __restrict__ lab_out_all, int8_t* __restrict__ flip_out_all) {
   const int s = blockIdx.y;
   if (w.state[s] != 1) return;
   __shared__ unsigned s_deg[GS_P * 64], s_n0[GS_P * 64];
@@ -1418,6 +1428,7 @@ __global__ __launch_bounds__(GS_T) void ransac_gc_scan(
   GcDyn* __restrict__ dyn_out = dyn_out_all + base;
   const uint8_t* lab_in = lab_in_all + base;
   uint8_t* lab_out = lab_out_all + base;
+  int8_t* __restrict__ flip_out = flip_out_all + base;
   const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
   const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
   const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
@@ -1541,6 +1552,10 @@ __global__ __launch_bounds__(GS_T) void ransac_gc_scan(
       const double mZ = __builtin_bit_cast(double, md.xy);
       GcDyn nd;
       nd.Z = mZ; nd.q = md.z; nd.out = 0;
+      int8_t flip = 0;
+      GcAcc raw;
+      raw.deg = s_deg[j * 64 + pt]; raw.n0 = s_n0[j * 64 + pt]; raw.S = s_S[j * 64 + pt];
+      w.acc[base + pos] = raw;
       if (lab_in[p] == 2) {
         lab_out[p] = 2;
       } else {
@@ -1560,12 +1575,121 @@ __global__ __launch_bounds__(GS_T) void ransac_gc_scan(
         const int inl = val < 0.0 ? 1 : 0;
         lab_out[p] = static_cast<uint8_t>(inl);
         nd.out = 1 - inl;
+        flip = static_cast<int8_t>(nd.out - md.w);
       }
       dyn_out[pos] = nd;
+      flip_out[pos] = flip;
     }
     __syncthreads();
     FIT_TRACE(3, s == 0 && blockIdx.x == 0 && t == 0);
   }
+}
+
+// ---- every FURTHER sweep of a round: the labels changed only at the positions the previous
+// sweep flipped, and of a point's three sums only the count of outlier-labelled neighbours
+// depends on labels at all. So the sweep after a full scan tests every point against the
+// FLIPPED candidates of its window alone (typically a few percent of it):
+//   raw_n0' = raw_n0 + sum over flipped neighbours of (+1: became outlier, -1: became inlier)
+// -- integers, hence the same labels as another full scan (tests/test_gpu_fit_lists.py). One
+// workgroup per tile: the window's flip bytes are read in chunks of 256 positions, the
+// flipped candidates of a chunk are compacted into LDS with their geometry, wave g tests
+// entries g, g + 4, ...
+struct GdCand { double x, y, X, Y, Z; int32_t sign, pad; };
+
+__global__ __launch_bounds__(256) void ransac_gc_delta(
+    const int64_t* __restrict__ slot_base, EposFitParams prm, Work w,
+    const GcGeo* __restrict__ geo_all, const GcDyn* __restrict__ dyn_all,
+    const int8_t* __restrict__ flip_in_all, int8_t* __restrict__ flip_out_all,
+    const uint8_t* __restrict__ lab_in_all, uint8_t* __restrict__ lab_out_all) {
+  const int s = blockIdx.y;
+  if (w.state[s] != 1) return;
+  __shared__ __attribute__((aligned(16))) GdCand s_list[256];
+  __shared__ int s_wcnt[4];
+  __shared__ int s_dn0[64];
+  const int t = threadIdx.x, pt = t & 63, sub = t >> 6;
+  const int64_t base = slot_base[s];
+  const int64_t n = slot_base[s + 1] - base;
+  const GcGeo* __restrict__ geo = geo_all + base;
+  const GcDyn* __restrict__ dyn = dyn_all + base;       // Z and q: the round's dyn_a
+  const int8_t* __restrict__ flip_in = flip_in_all + base;
+  int8_t* __restrict__ flip_out = flip_out_all + base;
+  const uint8_t* lab_in = lab_in_all + base;
+  uint8_t* lab_out = lab_out_all + base;
+  GcAcc* acc = w.acc + base;
+  const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
+  const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
+  const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
+  const double r2 = rad * rad;
+  FIT_TRACE(5, s == 0 && blockIdx.x == 0 && t == 0);
+  for (int64_t tile = blockIdx.x; tile * 64 < n; tile += gridDim.x) {
+    const int64_t pos = tile * 64 + pt;
+    const bool valid = pos < n;
+    const int64_t posc = valid ? pos : n - 1;
+    const GcGeo me = geo[posc];
+    const GcDyn md = dyn[posc];
+    const int32_t* wn = w.win + 2 * (base / 64 + s + tile);
+    const int64_t wlo = wn[0], whi = wn[1];
+    if (t < 64) s_dn0[t] = 0;
+    int dn0 = 0;
+    for (int64_t c0 = wlo; c0 < whi; c0 += 256) {
+      const int64_t c = c0 + t;
+      const int f = c < whi ? flip_in[c] : 0;
+      const unsigned long long b = __ballot(f != 0);
+      if (pt == 0) s_wcnt[sub] = __popcll(b);
+      __syncthreads();                               // also: the list of the last chunk is done
+      int off = 0, cnt = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { off += g < sub ? s_wcnt[g] : 0; cnt += s_wcnt[g]; }
+      if (f != 0) {
+        const GcGeo cg = geo[c];
+        GdCand e;
+        e.x = cg.x; e.y = cg.y; e.X = cg.X; e.Y = cg.Y; e.Z = dyn[c].Z; e.sign = f; e.pad = 0;
+        s_list[off + __popcll(b & ((1ull << pt) - 1ull))] = e;
+      }
+      __syncthreads();
+      for (int e = sub; e < cnt; e += 4) {
+        const GdCand r = s_list[e];
+        const double dx = me.x - r.x, dy = me.y - r.y;
+        const double dX = me.X - r.X, dY = me.Y - r.Y, dZ = md.Z - r.Z;
+        const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
+        dn0 += d2 <= r2 ? r.sign : 0;
+      }
+      __syncthreads();
+    }
+    if (dn0 != 0) atomicAdd(&s_dn0[pt], dn0);
+    __syncthreads();
+    if (sub == 0 && valid) {
+      const int32_t p = yorder ? yorder[pos] : static_cast<int32_t>(pos);
+      const int prev = lab_in[p];
+      int8_t flip = 0;
+      if (prev == 2) {
+        lab_out[p] = 2;
+      } else {
+        GcAcc raw = acc[pos];
+        raw.n0 = static_cast<uint32_t>(static_cast<int>(raw.n0) + s_dn0[pt]);
+        acc[pos] = raw;                                // the next sweep continues from here
+        const int out_prev = 1 - prev;                 // label 1 = inlier
+        const double dx = me.x - me.x, dy = me.y - me.y;
+        const double dX = me.X - me.X, dY = me.Y - me.Y, dZ = md.Z - md.Z;
+        const double d2 = (dx * dx + dy * dy) + s2 * ((dX * dX + dY * dY) + dZ * dZ);
+        const int64_t self = d2 <= r2 ? 1 : 0;
+        const int64_t qp = md.q;
+        const int64_t dg = static_cast<int64_t>(raw.deg) - self;
+        const int64_t z0 = static_cast<int64_t>(raw.n0) - self * out_prev;
+        const int64_t Ss = static_cast<int64_t>(raw.S) - self * qp;
+        const int64_t T = 2 * static_cast<int64_t>(GC_Q) * z0 - (dg * qp + Ss);
+        const int64_t u = qp < GC_Q ? -2 * (static_cast<int64_t>(GC_Q) - qp)
+                                    : 2 * static_cast<int64_t>(GC_Q);
+        const double val = (1.0 - lam) * static_cast<double>(u) + lam * static_cast<double>(T);
+        const int inl = val < 0.0 ? 1 : 0;
+        lab_out[p] = static_cast<uint8_t>(inl);
+        flip = static_cast<int8_t>((1 - inl) - out_prev);
+      }
+      flip_out[pos] = flip;
+    }
+    __syncthreads();
+  }
+  FIT_TRACE(5, s == 0 && blockIdx.x == 0 && t == 0);
 }
 
 // ---- round, step 4: local optimisation (ii) on the labelled inliers, the instance
@@ -1995,7 +2119,7 @@ struct Layout {
   int64_t pearl_pose, pearl_acc, pearl_state, pearl_moved;
   int64_t lo_cnt, lo_data, lo_timeout;
   int64_t nb_cnt, nb_pool, nb_ok;
-  int64_t geo, dyn_a, dyn_b, win;
+  int64_t geo, dyn_a, dyn_b, win, acc, flip_a, flip_b;
 };
 
 // cooperating launches per call: select + refit of every round (max_k + 2 rounds at most)
@@ -2032,6 +2156,9 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.dyn_a = off; off = align_up(off + (n_cap + 1) * 16);
   L.dyn_b = off; off = align_up(off + (n_cap + 1) * 16);
   L.win = off; off = align_up(off + L.words_total * 2 * 4);
+  L.acc = off; off = align_up(off + (n_cap + 1) * 16);
+  L.flip_a = off; off = align_up(off + n_cap + 1);
+  L.flip_b = off; off = align_up(off + n_cap + 1);
   L.pearl_pose = off; off = align_up(off + (S + 1) * PEARL_MAX_K * 12 * 8);
   L.pearl_acc = off; off = align_up(off + (S + 1) * 4 * 8);
   L.pearl_state = off; off = align_up(off + (S + 1) * 4);
@@ -2080,6 +2207,9 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   w.dyn_a = reinterpret_cast<GcDyn*>(wb + L.dyn_a);
   w.dyn_b = reinterpret_cast<GcDyn*>(wb + L.dyn_b);
   w.win = reinterpret_cast<int32_t*>(wb + L.win);
+  w.acc = reinterpret_cast<GcAcc*>(wb + L.acc);
+  w.flip_a = reinterpret_cast<int8_t*>(wb + L.flip_a);
+  w.flip_b = reinterpret_cast<int8_t*>(wb + L.flip_b);
   w.pearl_pose = reinterpret_cast<double*>(wb + L.pearl_pose);
   w.pearl_acc = reinterpret_cast<unsigned long long*>(wb + L.pearl_acc);
   w.pearl_state = reinterpret_cast<int32_t*>(wb + L.pearl_state);
@@ -2101,6 +2231,10 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   // the LDS sweeps and the rule above).
   static const int use_scan = [] {
     const char* e = getenv("EPOS_FIT_SCAN");
+    return e ? atoi(e) : 1;
+  }();
+  static const int use_delta = [] {          // EPOS_FIT_DELTA=0: every sweep is a full scan
+    const char* e = getenv("EPOS_FIT_DELTA");
     return e ? atoi(e) : 1;
   }();
   const int nb_rounds = max_k + (max_k > 1 ? 2 : 0);
@@ -2144,13 +2278,18 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
       for (int sw = 0; sw < p->gc_sweeps; ++sw) {
         const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
         uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
-        if (use_scan)
+        if (use_scan && sw > 0 && use_delta)
+          hipLaunchKernelGGL(ransac_gc_delta, sgrid, dim3(256), 0, st, slot_base, *p, w,
+                             reinterpret_cast<const GcGeo*>(w.geo), w.dyn_a,
+                             (sw & 1) ? w.flip_a : w.flip_b, (sw & 1) ? w.flip_b : w.flip_a,
+                             in, out);
+        else if (use_scan)
           hipLaunchKernelGGL(ransac_gc_scan,
                              dim3(static_cast<unsigned>(ceil_div(sgrid.x, GS_P)), S), dim3(GS_T),
                              0, st, slot_base, *p, w,
                              reinterpret_cast<const GcGeo*>(w.geo),
                              (sw & 1) ? w.dyn_b : w.dyn_a, (sw & 1) ? w.dyn_a : w.dyn_b, in,
-                             out);
+                             out, (sw & 1) ? w.flip_b : w.flip_a);
         else
           hipLaunchKernelGGL(ransac_gc_sweep<false>, sgrid, dim3(GC_T), 0, st, xy, xyz,
                              slot_base, *p, w, in, out);

@@ -209,6 +209,8 @@ def test_fitting_on_epos_like_scenes_equals_oracle(seed, sigma3d, sym, outlier):
   # same instance up to the order-dependent sampling; with the SAME order but the
   # spatial step off, or a RANSAC confidence below 1, still identical to the oracle
   _same_as_oracle(xy, xyz, seed, gc_sweeps=0)
+  _same_as_oracle(xy, xyz, seed, gc_sweeps=1)                 # one full scan
+  _same_as_oracle(xy, xyz, seed, gc_sweeps=5)                 # ... followed by four delta sweeps
   _same_as_oracle(xy, xyz, seed, proposal_engine_conf=0.99)
   _same_as_oracle(xy, xyz, seed, spatial_coherence_weight=0.4, neighborhood_ball_radius=9.0)
   perm = rng.permutation(len(xy))

@@ -41,15 +41,18 @@ np.savez(sys.argv[1], **out)
 
 
 def test_neighbour_lists_equal_window_scans(tmp_path):
-  """Four builds of the same labelling: window scans with the candidates in scalar registers
-  (the default), the LDS-staged scans they replaced (EPOS_FIT_SCAN=0), each with and without
+  """Five builds of the same labelling: window scans with the candidates in scalar registers
+  followed by delta sweeps over the flipped candidates (the default), full scans every sweep
+  (EPOS_FIT_DELTA=0), the LDS-staged scans they replaced (EPOS_FIT_SCAN=0), with and without
   the neighbour lists."""
   res = {}
-  modes = [('1', '1'), ('1', '0'), ('0', '1'), ('0', '0')]          # (scan, lists)
+  # (scan, lists, delta): delta = the sweeps after the first only revisit flipped candidates
+  modes = [('1', '1', '1'), ('1', '1', '0'), ('1', '0', '1'), ('0', '1', '1'), ('0', '0', '1')]
   for mode in modes:
-    path = str(tmp_path / ('fit_%s%s.npz' % mode))
+    path = str(tmp_path / ('fit_%s%s%s.npz' % mode))
     r = subprocess.run([sys.executable, '-c', SCRIPT % (ROOT, os.path.join(ROOT, 'tests')), path],
-                       env=dict(os.environ, EPOS_FIT_SCAN=mode[0], EPOS_FIT_NB_LISTS=mode[1]),
+                       env=dict(os.environ, EPOS_FIT_SCAN=mode[0], EPOS_FIT_NB_LISTS=mode[1],
+                                EPOS_FIT_DELTA=mode[2]),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     res[mode] = dict(np.load(path))

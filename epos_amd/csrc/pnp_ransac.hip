@@ -440,7 +440,7 @@ struct Work {
   int32_t* lo_timeout;   // [1] sticky: a workgroup gave up waiting for its siblings
   // joint refinement
   double* pearl_pose;            // [S][8][12] candidate poses
-  unsigned long long* pearl_acc; // [S][4] data / smoothness sums before, after (exact)
+  unsigned long long* pearl_acc; // [S][4][PEARL_BINS] data / smoothness sums before, after (exact)
   int32_t* pearl_state;          // [S] 1: refining
   int32_t* pearl_moved;          // [S]
 };
@@ -965,18 +965,26 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
       const double v = hs[i];
       if (v > best) { best = v; best_i = i; }
     }
-    s_score[t] = best; s_index[t] = best_i;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (t < off) {
-        const double v = s_score[t + off];
-        const int vi = s_index[t + off];
-        if (v > s_score[t] || (v == s_score[t] && vi < s_index[t])) {
-          s_score[t] = v; s_index[t] = vi;
-        }
-      }
-      __syncthreads();
+    // (max score, lowest index) is associative and commutative: any reduction order gives
+    // the same winner -- a butterfly per wave, then the four wave winners through LDS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double v = __shfl_xor(best, off, 64);
+      const int vi = __shfl_xor(best_i, off, 64);
+      if (v > best || (v == best && vi < best_i)) { best = v; best_i = vi; }
     }
+    if ((t & 63) == 0) { s_score[t >> 6] = best; s_index[t >> 6] = best_i; }
+    __syncthreads();
+    best = s_score[0]; best_i = s_index[0];
+#pragma unroll
+    for (int g2 = 1; g2 < 4; ++g2) {
+      const double v = s_score[g2];
+      const int vi = s_index[g2];
+      if (v > best || (v == best && vi < best_i)) { best = v; best_i = vi; }
+    }
+    __syncthreads();
+    if (t == 0) { s_score[0] = best; s_index[0] = best_i; }
+    __syncthreads();
   }
   double best_score = s_score[0];
   const int bi = s_index[0];
@@ -1891,6 +1899,8 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
 // relabelling sweeps + one Gauss-Newton refit of every instance on its points, kept iff
 // the energy dropped (DESIGN.md "Pose fitting", step 6).
 constexpr int PEARL_MAX_K = 8;
+constexpr int PEARL_BINS = 64;    // bins per energy sum (the workgroups' atomics spread over them)
+static_assert(4 * PEARL_BINS == 256, "pearl_begin zeroes the bins with one 256-thread workgroup");
 
 __device__ __forceinline__ int64_t pearl_data_term(const double* pose, const double* K,
                                                    const double* xy2, const double* xyz3,
@@ -1923,7 +1933,7 @@ __global__ __launch_bounds__(256) void pearl_begin(const int64_t* slot_base,
     const int32_t l = labels_all[base + i];
     w.lab_a[base + i] = static_cast<uint8_t>(l >= 0 && l < k ? l : k);
   }
-  if (blockIdx.x == 0 && threadIdx.x < 4) w.pearl_acc[s * 4 + threadIdx.x] = 0ull;
+  if (blockIdx.x == 0) w.pearl_acc[s * (4 * PEARL_BINS) + threadIdx.x] = 0ull;   // 4 x 64 bins
   if (blockIdx.x == 0 && threadIdx.x == 0) w.pearl_moved[s] = 0;
 }
 
@@ -1956,7 +1966,16 @@ __global__ __launch_bounds__(256) void pearl_energy(
   const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
   NbLists nl = {nullptr, nullptr};
   if (w.nb_ok[s]) { nl.cnt = w.nb_cnt + base * NB_W; nl.pool = w.nb_pool + base * (NB_W * NB_SUB); }
-  const int nwaves = gridDim.x * 4;
+  // The two sums of a slot end in ONE pair of global atomics per workgroup, spread over
+  // PEARL_BINS addresses each (pearl_commit adds the bins: integers, order free), and only
+  // as many workgroups take part as give every wave ~4 points: with one point and one pair
+  // of atomics per wave (the grid is sized for the pool's capacity) the 130 000 same-address
+  // 64-bit atomics of a C4 image serialised at ~7 ns each -- 0.93 ms per launch, 6.4 ms of
+  // fitting per image (profiles/r03/kernel_stats_c4_depth1_before.csv).
+  const int64_t want = (n + 15) / 16;
+  const int wgs = static_cast<int>(want < 1 ? 1 : want < gridDim.x ? want : gridDim.x);
+  if (static_cast<int>(blockIdx.x) >= wgs) return;
+  const int nwaves = wgs * 4;
   unsigned long long data = 0, smooth = 0;
   for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nwaves) {
     const int lp = lab[p];
@@ -1973,10 +1992,17 @@ __global__ __launch_bounds__(256) void pearl_energy(
           lp < k ? pearl_data_term(pp + 12 * lp, K, xy + 2 * p, xyz + 3 * p, tthr2) : d_out);
     }
   }
+  __shared__ unsigned long long s_sum[2];
+  if (threadIdx.x < 2) s_sum[threadIdx.x] = 0ull;
+  __syncthreads();
   if (lane == 0) {
-    atomicAdd(&w.pearl_acc[s * 4 + 2 * which], data);
-    atomicAdd(&w.pearl_acc[s * 4 + 2 * which + 1], smooth);
+    atomicAdd(&s_sum[0], data);
+    atomicAdd(&s_sum[1], smooth);
   }
+  __syncthreads();
+  if (threadIdx.x < 2 && s_sum[threadIdx.x] != 0ull)
+    atomicAdd(&w.pearl_acc[(s * 4 + 2 * which + threadIdx.x) * PEARL_BINS +
+                           (blockIdx.x & (PEARL_BINS - 1))], s_sum[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void pearl_sweep(
@@ -2092,7 +2118,13 @@ __global__ __launch_bounds__(256) void pearl_commit(const int64_t* slot_base,
   const int t = threadIdx.x;
   const int k = num_models[s];
   const double lam = prm.spatial_coherence_weight;
-  const unsigned long long* a = w.pearl_acc + s * 4;
+  unsigned long long a[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned long long v = 0;
+    for (int b = 0; b < PEARL_BINS; ++b) v += w.pearl_acc[(s * 4 + q) * PEARL_BINS + b];
+    a[q] = v;
+  }
   const double e_before = (1.0 - lam) * static_cast<double>(static_cast<int64_t>(a[0])) +
                           lam * static_cast<double>(static_cast<int64_t>(a[1]));
   const double e_after = (1.0 - lam) * static_cast<double>(static_cast<int64_t>(a[2])) +
@@ -2160,7 +2192,7 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.flip_a = off; off = align_up(off + n_cap + 1);
   L.flip_b = off; off = align_up(off + n_cap + 1);
   L.pearl_pose = off; off = align_up(off + (S + 1) * PEARL_MAX_K * 12 * 8);
-  L.pearl_acc = off; off = align_up(off + (S + 1) * 4 * 8);
+  L.pearl_acc = off; off = align_up(off + (S + 1) * 4 * PEARL_BINS * 8);
   L.pearl_state = off; off = align_up(off + (S + 1) * 4);
   L.pearl_moved = off; off = align_up(off + (S + 1) * 4);
   L.total = off;

@@ -906,14 +906,17 @@ class EposNet(object):
     """sparse=False: the whole dense plan. sparse=True: trunk + object head +
     object softmax/argmax only (the fragment heads follow per target object).
     skip_kinds: op kinds left out (capture_alt: the plan WITHOUT its GEMM / depthwise
-    launches, for the step decomposition of bench.py -- results are then meaningless)."""
+    launches, for the step decomposition of bench.py). 'post' leaves out the in-place
+    softmax / argmax post-ops: without the GEMMs the head buffers keep the probabilities
+    of the last full run, and softmax applied to them again and again would flatten them
+    (the stages downstream would then see no -- or, with one object, all -- pixels)."""
     s = self._stream()
     if not sparse:
       for name, fn in self.ops:
         if self.op_kind.get(name) in skip_kinds:
           continue
         fn(s)
-      if with_post:
+      if with_post and 'post' not in skip_kinds:
         for _, fn in self.post_ops:
           fn(s)
       return

@@ -25,7 +25,14 @@ def mk_gemm():
     Ws = torch.from_numpy(d8).cuda()
     a = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Ws), bias=None, R=None, ldr=n, C=p(C), ldc=n, M=m, N=n, K=k,
                            relu=0, relu_in=0, sub=1, Ws=p(Ws))
-    return (A, C, Ws, None, a)
+    Wh = None
+    if os.environ.get('EPOS_GEMM_H2', '1') != '0':           # the fp16-pair kernel (default)
+      total = lib.epos_pack_pointwise_weights_h2(w.ctypes.data_as(ctypes.c_void_p), k, n, None); d8 = np.empty(max(total, 1), np.uint8)
+      if total > 0 and lib.epos_pack_pointwise_weights_h2(w.ctypes.data_as(ctypes.c_void_p), k, n,
+                                            d8.ctypes.data_as(ctypes.c_void_p)) > 0:
+        Wh = torch.from_numpy(d8).cuda()
+        a.Wh = p(Wh)
+    return (A, C, Ws, Wh, a)
   total = lib.epos_pack_pointwise_weights(None, k, n, None); dst = np.empty(total, np.float32)
   lib.epos_pack_pointwise_weights(w.ctypes.data_as(ctypes.c_void_p), k, n, dst.ctypes.data_as(ctypes.c_void_p))
   Wp = torch.from_numpy(dst).cuda(); b = torch.zeros((n + 127) // 128 * 128, device='cuda')

@@ -34,7 +34,7 @@ for d in 4 1; do
   [ -n "$f" ] && cp "$f" $OUT/rocprofv3_kernel_stats_depth$d.csv
   f=$(find $OUT/kt$d -name '*kernel_trace.csv' | head -1)
   [ -n "$f" ] && python tools/trace_overlap.py "$f" 0.5 > $OUT/kernel_trace_busy_union_depth$d.txt
-  tail -1 $OUT/kt$d.log > $OUT/bench_under_rocprof_depth$d.json
+  grep "^{\"metric\"" $OUT/kt$d.log | tail -1 > $OUT/bench_under_rocprof_depth$d.json
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p $OUT/pmc_$c

@@ -570,7 +570,36 @@ inline unsigned blocks_for(int64_t total, int threads) {
 
 using namespace epos;
 
+#ifdef EPOS_DW_ABL_LIGHT
+// ablation (tools/, WRONG results): the centre tap only -- one 16-byte load and one store per
+// thread, ~16 VGPRs: what would a depthwise kernel cost inside the pipelined step if it
+// co-resided with anything and issued next to nothing? (the same bytes move)
+namespace epos { namespace {
+__global__ __launch_bounds__(256) void dw_light_kernel(EposDepthwiseArgs p, int64_t total) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c4n = p.C / 4;
+  const int64_t pix = i / c4n;
+  const int c4 = static_cast<int>(i - pix * c4n);
+  const float4 x = *reinterpret_cast<const float4*>(p.X + pix * p.ldx + 4 * c4);
+  const float4 wv = *reinterpret_cast<const float4*>(p.w9c + 4 * p.C + 4 * c4);
+  const float4 b = *reinterpret_cast<const float4*>(p.bias + 4 * c4);
+  float4 y;
+  y.x = x.x * wv.x + b.x; y.y = x.y * wv.y + b.y; y.z = x.z * wv.z + b.z; y.w = x.w * wv.w + b.w;
+  *reinterpret_cast<float4*>(p.Y + pix * p.ldy + 4 * c4) = y;
+}
+} }
+#endif
+
 extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
+#ifdef EPOS_DW_ABL_LIGHT
+  if (a->stride == 1 && a->Hi == a->Ho && a->Wi == a->Wo && !a->y_h2) {
+    const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * (a->C / 4);
+    hipLaunchKernelGGL(epos::dw_light_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
+                       dim3(256), 0, static_cast<hipStream_t>(stream), *a, total);
+    return EPOS_OK;
+  }
+#endif
   EPOS_REQUIRE(a && a->X && a->w9c && a->bias && a->Y, "null pointer");
   EPOS_REQUIRE(a->C % 4 == 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0,
                "C, ldx, ldy must be multiples of 4");

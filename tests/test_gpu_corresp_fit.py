@@ -241,6 +241,19 @@ def test_fit_equals_oracle_with_exact_min_cuts_on_sparse_graphs(seed):
     np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=1e-9)
   with pytest.raises(EposError):
     fitting.find6DPoses(xy, xyz, K, seed=seed, max_poses=1, gc_sweeps=-1)
+  # ... and at the DEFAULT radius (dense graphs, where two sweeps are not the minimum cut)
+  # the whole fit still comes out the same as with exact cuts: the labelling only feeds
+  # refits that are kept when the quality grows (tests/test_oracle_fit.py has the sample)
+  rng = np.random.RandomState(500 + seed)
+  R = fs.rand_rot(rng)
+  t = np.array([rng.uniform(-100, 100), rng.uniform(-60, 60), rng.uniform(600, 1000)])
+  xy, xyz, _, _ = fs.dense_scene(rng, [(R, t)], sigma3d=rng.uniform(0.3, 2.5),
+                                 sym=rng.uniform(0, 1), outlier=rng.uniform(0.1, 0.6))
+  got = fitting.find6DPoses(xy, xyz, K, seed=seed, max_poses=1)
+  ref = pnp_ref.find6DPoses(xy, xyz, K, params=pnp_ref.default_params(gc_sweeps=-1), seed=seed,
+                            max_k=1)
+  assert got[0] is not None and np.array_equal(got[1], ref[1])
+  np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=1e-9)
 
 
 def test_two_close_instances_of_a_symmetric_object():

@@ -2,19 +2,34 @@
 // pyprogressivex.find6DPoses call of scripts/infer.py:470-488 (the un-vendored
 // danini/progressive-x C++ module). Algorithm definition: DESIGN.md "Pose
 // fitting" (P3P minimal solver, MSAC quality, Gauss-Newton local optimisation of
-// the best hypothesis, sequential multi-instance with Tanimoto / coverage tests).
+// the best hypothesis, spatial-coherence labelling, sequential multi-instance with
+// Tanimoto / coverage tests, joint refinement).
 //
-// Mapping to the hardware:
-//   * ransac_hypotheses: ONE HYPOTHESIS SET PER WAVEFRONT. The 64 lanes compute
-//     the (wave-uniform) P3P solve redundantly, then stride over the slot's
-//     correspondences; inliers are counted with popcount, the MSAC sum is reduced
-//     with a fixed xor-butterfly so the result does not depend on scheduling.
-//     Grid = (max_iters / 4, slots): all objects of all images in one launch.
-//   * ransac_select_refine: one workgroup per slot: deterministic arg-max over the
-//     hypothesis table, then wave 0 runs the local optimisation (27 normal-
-//     equation sums per Gauss-Newton step, butterfly-reduced), the instance
-//     acceptance tests on inlier bitsets (ballot + popcount) and the stable
-//     compaction of the still-unexplained correspondences.
+// Mapping to the hardware (one call = one launch sequence over all slots = (image, object)
+// pairs of a step; everything stays on the device, DESIGN.md (f) has the measurements):
+//   * ransac_init: per-call state, the sweeps' position-ordered candidate stream (static
+//     geometry) and the candidate window of every tile of 64 row-sorted points.
+//   Per proposal round (max_k rounds, + 2 retries in a multi-instance search):
+//   * ransac_hypotheses: ONE HYPOTHESIS SET PER WAVEFRONT. The 64 lanes compute the
+//     (wave-uniform) P3P solve redundantly, then stride over the slot's correspondences; the
+//     MSAC sums are reduced in a canonical order (64 strided partials, xor butterfly).
+//     Grid = (max_iters / 4, slots).
+//   * ransac_select_lo: FOUR workgroups per slot. Deterministic arg-max over the hypothesis
+//     table, then the Gauss-Newton refits on the inliers: one pass over the points per refit
+//     (score of the candidate + the 27 normal-equation sums of the step from it), 1024
+//     strided partials in the oracle's canonical tree -- a reduce-scatter butterfly per wave,
+//     a fence-free agent-scope hand-off between the workgroups, a pivot-free 6 x 6 solve by
+//     every thread; last, the fixed-point residual table the labelling starts from.
+//   * ransac_gc_scan (first sweep) / ransac_gc_delta (further sweeps): the spatial-coherence
+//     labelling on the 5-D neighbourhood graph. Scan: sixteen waves per tile walk the tile's
+//     window with the candidate in SCALAR registers (s_load), exact integer counters. Delta:
+//     only the candidates the previous sweep flipped are revisited. (ransac_gc_sweep: the
+//     LDS-staged predecessor, kept as EPOS_FIT_SCAN=0 and as ransac_nb_build, which writes
+//     the neighbour lists the joint refinement walks.)
+//   * ransac_refit_accept: refits on the labelled set (same machinery as select_lo), the
+//     instance acceptance tests on inlier bitsets (ballot + popcount), stable in-place
+//     compaction of the still-unexplained correspondences by the whole workgroup.
+//   * pearl_*: joint refinement of multi-instance slots (labels over all instances).
 // Arithmetic is fp64 (the reference hands f64 arrays to progressive-x) using only
 // + - * / sqrt, compiled with -ffp-contract=off: results are reproducible run to
 // run and identical to a scalar evaluation in the same canonical order.

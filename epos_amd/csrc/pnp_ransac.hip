@@ -453,6 +453,7 @@ struct Work {
   unsigned* lo_cnt;      // [S][lo_launches(max_k)] arrival counters, zeroed by ransac_init
   double* lo_data;       // [S][2][LO_G * 4][LO_NV] wave sums, double buffered
   int32_t* lo_timeout;   // [1] sticky: a workgroup gave up waiting for its siblings
+  unsigned lo_spin_max;  // polls before that happens (LO_SPIN_MAX; EPOS_FIT_SPIN_MAX: tests)
   // joint refinement
   double* pearl_pose;            // [S][8][12] candidate poses
   unsigned long long* pearl_acc; // [S][4][PEARL_BINS] data / smoothness sums before, after (exact)
@@ -724,6 +725,7 @@ struct LoSync {
   unsigned* cnt;        // this launch's counter of the slot (null: single workgroup)
   double* data;         // [2][LO_G * 4][LO_NV]
   int32_t* timeout;
+  unsigned spin_max;    // polls before a workgroup gives up on its siblings (Work::lo_spin_max)
   int g;                // workgroup index within the slot
   unsigned epoch;       // exchanges done so far in this launch
 };
@@ -791,7 +793,10 @@ __device__ void lo_combine(LoSync& sy, double val, int nv, int t, double* s_rows
     unsigned spins = 0;
     while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > LO_SPIN_MAX) { *sy.timeout = 1; break; }
+      if (++spins > sy.spin_max) {
+        __hip_atomic_store(sy.timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
@@ -1013,6 +1018,7 @@ __global__ __launch_bounds__(256) void ransac_select_lo(
   sy.cnt = w.lo_cnt + static_cast<int64_t>(s) * n_lo + lo_launch;
   sy.data = w.lo_data + static_cast<int64_t>(s) * (2 * LO_G * 4 * LO_NV);
   sy.timeout = w.lo_timeout;
+  sy.spin_max = w.lo_spin_max;
   sy.g = g;
   sy.epoch = 0;
 #ifdef EPOS_FIT_TRACE
@@ -1755,6 +1761,7 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
     sy.cnt = w.lo_cnt + static_cast<int64_t>(s) * n_lo + lo_launch;
     sy.data = w.lo_data + static_cast<int64_t>(s) * (2 * LO_G * 4 * LO_NV);
     sy.timeout = w.lo_timeout;
+    sy.spin_max = w.lo_spin_max;
     sy.g = g;
     sy.epoch = 0;
     // the first step on the labelled set starts from the accepted pose (its score is
@@ -1778,6 +1785,13 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
       fail = fail2;
       if (!(gain > LO_MIN_GAIN * sc)) break;
     }
+  }
+  // A hand-off that timed out (a sibling workgroup was not scheduled for ~0.5 s: never seen,
+  // but then the sums -- and everything derived from them -- are garbage) is reported, not
+  // hidden: the slot's instance count becomes -1 and the host entry points raise.
+  if (__hip_atomic_load(w.lo_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    if (g == 0 && t == 0) { num_models[s] = -1; w.done[s] = 1; }
+    return;
   }
   if (g != 0) return;          // the siblings only helped with the sums
   FIT_TRACE(2, s == 0 && t == 0);
@@ -2092,7 +2106,7 @@ __global__ __launch_bounds__(256) void pearl_refit(
   __shared__ LoLds s_lo;
   __shared__ int s_cnt[4];
   LoSync sy;                         // one workgroup: the sums stay in LDS
-  sy.cnt = nullptr; sy.data = nullptr; sy.timeout = nullptr; sy.g = 0; sy.epoch = 0;
+  sy.cnt = nullptr; sy.data = nullptr; sy.timeout = nullptr; sy.spin_max = 0; sy.g = 0; sy.epoch = 0;
   const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
   const double* xy = xy_all + 2 * base;
   const double* xyz = xyz_all + 3 * base;
@@ -2247,6 +2261,11 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   w.lo_cnt = reinterpret_cast<unsigned*>(wb + L.lo_cnt);
   w.lo_data = reinterpret_cast<double*>(wb + L.lo_data);
   w.lo_timeout = reinterpret_cast<int32_t*>(wb + L.lo_timeout);
+  static const unsigned spin_max = [] {      // EPOS_FIT_SPIN_MAX=0: every hand-off that has to
+    const char* e = getenv("EPOS_FIT_SPIN_MAX");   // wait at all gives up (tests of the error path)
+    return e ? static_cast<unsigned>(strtoul(e, nullptr, 10)) : LO_SPIN_MAX;
+  }();
+  w.lo_spin_max = spin_max;
   w.nb_cnt = reinterpret_cast<uint16_t*>(wb + L.nb_cnt);
   w.nb_pool = reinterpret_cast<int16_t*>(wb + L.nb_pool);
   w.nb_ok = reinterpret_cast<int32_t*>(wb + L.nb_ok);
@@ -2498,6 +2517,10 @@ extern "C" int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
           reinterpret_cast<int32_t*>(d[12]), nullptr);
     if (!rc) rc = check_hip(hipDeviceSynchronize(), "sync");
     if (!rc) rc = check_hip(hipMemcpy(&k, d[9], 4, hipMemcpyDeviceToHost), "copy k");
+    if (!rc && k < 0) {
+      set_error("epos_find6d_poses: a hand-off between cooperating workgroups timed out");
+      rc = EPOS_E_INTERNAL;
+    }
     if (!rc && k > 0) {
       rc = check_hip(hipMemcpy(poses_out, d[7], static_cast<size_t>(k) * 96, hipMemcpyDeviceToHost), "copy poses");
       if (!rc) rc = check_hip(hipMemcpy(scores_out, d[8], static_cast<size_t>(k) * 8, hipMemcpyDeviceToHost), "copy scores");

@@ -252,6 +252,11 @@ class EposPipeline(object):
         raise _lib.EposError(
             'correspondence capacity (%d rows) exceeded' % self.corr.capacity)
       nm = self._view(rh, rl, 'num_models')[:S].numpy()
+      if (nm < 0).any():
+        raise _lib.EposError(
+            'fitting stage: a hand-off between cooperating workgroups timed out for slot(s) '
+            '%s (num_models == -1, include/epos_hip.h); repeat the step' %
+            np.nonzero(nm < 0)[0].tolist())
       ph = self._view(rh, rl, 'poses')[:S * max_k * 12].numpy().reshape(
           S, max_k, 12)
       sh = self._view(rh, rl, 'scores')[:S * max_k].numpy().reshape(S, max_k)

@@ -31,6 +31,7 @@ extern "C" {
 #define EPOS_E_INVALID (-1)   /* bad argument (NULL, non-multiple-of-4 channels, ...) */
 #define EPOS_E_CAPACITY (-2)  /* caller-provided output capacity too small */
 #define EPOS_E_NODEVICE (-3)  /* no HIP device available */
+#define EPOS_E_INTERNAL (-4)  /* a device-side consistency check failed (see epos_last_error) */
 #define EPOS_E_HIP_BASE (-1000)
 
 #define EPOS_ABI_VERSION 5   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32; 4: epos_solve_pnp_ransac; 5: fp16-pair GEMM (Wh, a_amax, c_amax, epos_pack_pointwise_weights_h2, epos_absmax_f32) */
@@ -437,7 +438,10 @@ int epos_find6d_poses(const double* xy, const double* xyz, int64_t n,
  *   work: scratch of epos_fit_workspace_bytes(S, N_capacity, p) bytes
  * Outputs: poses f64[S,max_k,12] (per instance: R row-major [0..8], then t [9..11], as
  *          above), scores f64[S,max_k], num_models i32[S], labels i32[N] (instance index
- *          within the slot or -1).
+ *          within the slot or -1). num_models[s] == -1: a device-side consistency check
+ *          failed for that slot (a hand-off between the workgroups that fit it together
+ *          timed out); its outputs are not valid and the call should be repeated --
+ *          epos_find6d_poses returns EPOS_E_INTERNAL in that case.
  * PRECONDITION (not checked): the rows of every slot are in image-row order --
  * xy[.,1] non-decreasing within [slot_base[s], slot_base[s+1]) -- which is the raster order
  * epos_corr_fill writes. The spatial-coherence sweeps and the joint refinement find a

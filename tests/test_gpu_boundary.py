@@ -102,3 +102,39 @@ def test_pipeline_never_clamps_instance_counts_silently():
     warnings.simplefilter('always')
     poses, _ = pipe.process_batch(img, Ks, [{1: 2, 2: 1}])
   assert all(p['R'].shape == (3, 3) and p['t'].shape == (3, 1) for p in poses)
+
+
+def test_a_timed_out_hand_off_is_reported_not_hidden(tmp_path):
+  """The refits of a slot are summed by four workgroups that meet in global memory; a
+  workgroup that waits too long for its siblings gives up (bounded spin). With the bound
+  set to ZERO polls (EPOS_FIT_SPIN_MAX=0, read once per process: a subprocess) every
+  hand-off that has to wait at all fails -- the call must then raise (num_models == -1 /
+  EPOS_E_INTERNAL), never return poses computed from incomplete sums."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from helpers import fit_scenes as fs
+from epos_amd import fitting, _lib
+from oracle import pnp_ref
+rng = np.random.RandomState(7)
+R = fs.rand_rot(rng); t = np.array([10.0, -20.0, 750.0])
+xy, xyz, _, _ = fs.dense_scene(rng, [(R, t)], sigma3d=1.0, sym=0.3, outlier=0.3)
+raised = 0
+for seed in range(6):
+  try:
+    got = fitting.find6DPoses(xy, xyz, fs.K_YCBV, seed=seed)
+  except _lib.EposError as e:
+    assert 'timed out' in str(e), str(e)
+    raised += 1
+    continue
+  ref = pnp_ref.find6DPoses(xy, xyz, fs.K_YCBV, seed=seed)     # no time-out happened:
+  assert np.array_equal(got[1], ref[1])                          # then the result is right
+print('RAISED', raised)
+''' % (root, os.path.join(root, 'tests'))
+  r = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, EPOS_FIT_SPIN_MAX='0'),
+                     capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout + r.stderr
+  assert int(r.stdout.strip().split()[-1]) >= 1, r.stdout

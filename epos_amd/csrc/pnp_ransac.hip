@@ -1866,6 +1866,22 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
   //      start + what it kept (positions that have all been read).
   if (t < 12) poses[(static_cast<int64_t>(s) * max_k + k) * 12 + t] = pose[t];
   if (t == 0) scores[static_cast<int64_t>(s) * max_k + k] = best_score;
+  if (k + 1 >= want) {
+    // the slot's LAST instance: nobody reads its active list again, so the compaction (a
+    // dependent gather per entry) is skipped -- the unexplained inliers are labelled
+    // straight from the bitset, coalesced. (Every inlier that is still unlabelled IS
+    // active: the two sets are kept identical by the compaction below.)
+    for (int64_t i = t; i < n; i += 256)
+      if (((cur[i >> 6] >> (i & 63)) & 1ull) && labels[i] < 0) labels[i] = k;
+    if (t == 0) {
+      w.tries[s] = 0;
+      w.last_new[s] = n_new;
+      num_models[s] = k + 1;
+      w.done[s] = 1;
+    }
+    FIT_TRACE(2, s == 0 && t == 0);
+    return;
+  }
   int64_t wpos = 0;
   for (int64_t c0 = 0; c0 < n_active; c0 += 1024) {
     int32_t pv[4];

@@ -1,40 +1,44 @@
 #!/usr/bin/env python
-"""Do independent GEMM launches on different HIP streams fill each other's
-tile-quantisation gaps? N launches of one shape on 1, 2, 3 streams (round-robin)."""
+"""How does the fp16-pair GEMM scale with independent launches in flight? 1..6 streams
+round-robin at the middle-flow shape (228 workgroups per launch, two resident per CU): the
+aggregate algorithmic TFLOP/s the kernel reaches when the chip is kept full -- the ceiling
+of what the pipelined step can get out of it."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from epos_amd import _lib
 lib = _lib.load()
 def p(t): return ctypes.c_void_p(t.data_ptr())
-m, n, k = [int(x) for x in sys.argv[1:4]] if len(sys.argv) > 3 else (4800, 728, 728)
-nstream_max = 3
-bufs = []
-for s in range(nstream_max):
-  A = torch.randn(m, k, device='cuda'); C = torch.empty(m, n, device='cuda')
+NS = 6
+streams = [torch.cuda.Stream() for _ in range(NS)]
+for (m, n, k, res) in [(4800, 728, 728, 0), (4800, 728, 728, 1), (4800, 1024, 728, 0), (19200, 256, 304 + 16, 0)]:
+  As = [torch.relu(torch.randn(m, k, device='cuda')) for _ in range(NS)]
+  Cs = [torch.empty(m, n, device='cuda') for _ in range(NS)]
+  Rs = [torch.randn(m, n, device='cuda') for _ in range(NS)]
+  slot = torch.zeros(64, dtype=torch.int32, device='cuda')
+  slot[0] = int(np.float32(8.0).view(np.int32))
   w = (np.random.randn(k, n) / np.sqrt(k)).astype(np.float32)
-  total = lib.epos_pack_pointwise_weights(None, k, n, None); dst = np.empty(total, np.float32)
-  lib.epos_pack_pointwise_weights(w.ctypes.data_as(ctypes.c_void_p), k, n, dst.ctypes.data_as(ctypes.c_void_p))
-  Wp = torch.from_numpy(dst).cuda(); b = torch.zeros((n + 127) // 128 * 128, device='cuda')
-  a = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Wp), bias=p(b), R=None, ldr=n, C=p(C), ldc=n, M=m, N=n, K=k,
-                         relu=0, relu_in=0, sub=1)
-  bufs.append((A, C, Wp, b, a))
-streams = [torch.cuda.Stream() for _ in range(nstream_max)]
-clk = torch.zeros((8, 2), dtype=torch.int64, device='cuda'); cs = torch.cuda.Stream()
-N = 600
-for ns in (1, 2, 3):
-  for rep in range(2):
+  tot = lib.epos_pack_pointwise_weights_h2(w.ctypes.data_as(ctypes.c_void_p), k, n, None)
+  d8 = np.empty(tot, np.uint8)
+  lib.epos_pack_pointwise_weights_h2(w.ctypes.data_as(ctypes.c_void_p), k, n, d8.ctypes.data_as(ctypes.c_void_p))
+  Wh = torch.from_numpy(d8).cuda()
+  args = [_lib.PointwiseArgs(A=p(As[i]), lda=k, Wp=p(Wh), bias=None, R=p(Rs[i]) if res else None, ldr=n,
+                             C=p(Cs[i]), ldc=n, M=m, N=n, K=k, relu=0, relu_in=0, sub=1, Wh=p(Wh),
+                             a_amax=p(slot)) for i in range(NS)]
+  out = []
+  for nstream in range(1, NS + 1):
+    def call(i):
+      st = streams[i % nstream]
+      _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args[i % nstream]), ctypes.c_void_p(st.cuda_stream)))
+    for i in range(240): call(i)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    for st in streams: st.wait_stream(torch.cuda.current_stream())
     e0.record()
-    for s in streams[:ns]: s.wait_stream(torch.cuda.current_stream())
-    for i in range(N):
-      j = i % ns
-      lib.epos_pointwise_conv_f32(ctypes.byref(bufs[j][4]), ctypes.c_void_p(streams[j].cuda_stream))
-      if rep == 1 and i in (N // 2, N // 2 + 100):      # sample the core clock mid-run
-        lib.epos_clock_probe(ctypes.c_void_p(clk[i // 100 % 8].data_ptr()), 300, ctypes.c_void_p(cs.cuda_stream))
-    for s in streams[:ns]: torch.cuda.current_stream().wait_stream(s)
+    for st in streams[:nstream]: st.wait_event(e0)
+    for i in range(240): call(i)
+    for st in streams[:nstream]: torch.cuda.current_stream().wait_stream(st)
     e1.record(); torch.cuda.synchronize()
-  us = e0.elapsed_time(e1) / N * 1e3
-  ch = clk.cpu().numpy(); ch = ch[ch[:, 1] > 0]; mhz = float((ch[:, 0] / ch[:, 1]).mean() * 100) if len(ch) else 0; clk.zero_()
-  print('M=%d N=%d K=%d  %d stream(s): %.1f us per launch  %.1f TFLOP/s aggregate  core clock %.0f MHz (roof at that clock %.1f)' % (m, n, k, ns, us, 2 * m * n * k / us / 1e6, mhz, 65.536 * mhz / 1e3))
+    us = e0.elapsed_time(e1) / 240 * 1e3
+    out.append('%d: %5.1f' % (nstream, 2 * m * n * k / us / 1e6))
+  print('%dx%dx%d%s  TFLOP/s by streams in flight  %s' % (m, n, k, ' +res' if res else '', '  '.join(out)), flush=True)

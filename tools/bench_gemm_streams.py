@@ -11,7 +11,10 @@ lib = _lib.load()
 def p(t): return ctypes.c_void_p(t.data_ptr())
 NS = 6
 streams = [torch.cuda.Stream() for _ in range(NS)]
-for (m, n, k, res) in [(4800, 728, 728, 0), (4800, 728, 728, 1), (4800, 1024, 728, 0), (19200, 256, 304 + 16, 0)]:
+SHAPES = [(4800, 728, 728, 0), (4800, 728, 728, 1), (4800, 1024, 728, 0), (19200, 256, 304 + 16, 0)]
+if len(sys.argv) > 1:          # e.g. 29184x128x728 (one column tile: no A sharing between workgroups)
+  SHAPES = [tuple(int(v) for v in a.split('x')) + (0,) for a in sys.argv[1:]]
+for (m, n, k, res) in SHAPES:
   As = [torch.relu(torch.randn(m, k, device='cuda')) for _ in range(NS)]
   Cs = [torch.empty(m, n, device='cuda') for _ in range(NS)]
   Rs = [torch.randn(m, n, device='cuda') for _ in range(NS)]

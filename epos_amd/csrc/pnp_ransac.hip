@@ -661,11 +661,11 @@ __device__ void orthonormalize(double* R) {
   cross3(R, R + 3, R + 6);
 }
 
-// Gaussian elimination with partial pivoting, the arithmetic of the C definition's solve6
-// operation for operation, but with every index a compile-time constant (the pivot row is
-// swapped in by selects): the 6 x 7 system stays in registers. The indexed form went
-// through scratch memory -- a dependent chain of ~300 private loads and stores that every
-// thread of the workgroup repeated in every refit pass (~6 us of each ~17 us pass).
+// Gaussian elimination WITHOUT pivoting (see below), the arithmetic of the C definition's
+// solve6 operation for operation, with every index a compile-time constant so that the
+// 6 x 7 system stays in registers. The indexed form went through scratch memory -- a
+// dependent chain of ~300 private loads and stores that every thread of the workgroup
+// repeated in every refit pass (~6 us of each ~17 us pass).
 __device__ int solve6(const double* H /*[36]*/, const double* g, double* x) {
   // H = J^T J is symmetric positive (semi)definite: elimination WITHOUT pivoting is stable
   // for it, and one reciprocal per pivot serves the column and the back-substitution (round
@@ -793,6 +793,11 @@ __device__ void lo_combine(LoSync& sy, double val, int nv, int t, double* s_rows
     unsigned spins = 0;
     while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
+      // a hand-off of this launch has already timed out (the call will report
+      // num_models = -1): do not spin the full budget again at every later exchange
+      if ((spins & 255u) == 255u &&
+          __hip_atomic_load(sy.timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        break;
       if (++spins > sy.spin_max) {
         __hip_atomic_store(sy.timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;

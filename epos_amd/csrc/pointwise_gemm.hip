@@ -830,7 +830,13 @@ extern "C" int epos_pointwise_conv_grouped_ws_f32(const EposPointwiseArgs* args,
   // loses on the 48 middle-flow layers (47.9 -> 55 us) and end to end (213 -> 177
   // images/s: its fixed 512-workgroup grid leaves no slots for the other streams'
   // kernels). It therefore stays opt-in (EPOS_GEMM_SK=1).
-  const bool sk = workspace && use_sk == 1 && args[0].relu_in == 0;
+  // The stream-K kernel has its own inline epilogue: it neither publishes c_amax nor reads
+  // fp16-pair weights / a pre-split A, so a problem that carries any of those takes the
+  // data-parallel path (the consumers of an absmax slot would otherwise read zeros).
+  bool abi5 = false;
+  for (int i = 0; i < count; ++i)
+    abi5 = abi5 || args[i].c_amax || args[i].Wh || args[i].a_presplit;
+  const bool sk = workspace && use_sk == 1 && args[0].relu_in == 0 && !abi5;
   if (sk && units < (1LL << 31))
     return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
   return epos_pointwise_conv_grouped_f32(args, count, stream);
@@ -851,5 +857,8 @@ extern "C" int epos_pointwise_conv_grouped_sk_f32(const EposPointwiseArgs* args,
   }
   if (args[0].relu_in != 0)   // the LDS-DMA ring cannot apply the pre-activation
     return epos_pointwise_conv_grouped_f32(args, count, stream);
+  for (int i = 0; i < count; ++i)     // ABI-5 fields the stream-K epilogue does not serve
+    if (args[i].c_amax || args[i].Wh || args[i].a_presplit)
+      return epos_pointwise_conv_grouped_f32(args, count, stream);
   return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
 }

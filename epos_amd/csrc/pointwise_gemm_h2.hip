@@ -40,6 +40,8 @@
 // and the float4 epilogue are the split kernel's.
 #include <string.h>
 
+#include <mutex>
+
 #include "h2_scale.h"
 #include "pointwise_gemm.h"
 
@@ -474,6 +476,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   else k_loop(std::integral_constant<int, 4>{}, std::integral_constant<bool, PRESPLIT>{});
 
   // ---- epilogue --------------------------------------------------------------
+#ifdef EPOS_H2_ABL_NOEPI            // ablation (tools/power_components_h2.py): no epilogue
+  if (p.ldr != 0x7fffffff) return;  // (always taken; the compiler cannot know)
+#endif
   const float* cscale = reinterpret_cast<const float*>(
       static_cast<const char*>(p.Wh) + static_cast<int64_t>(tiles_n) * nks * H2_W_BYTES);
   float cn[4];
@@ -583,18 +588,26 @@ int launch_absmax(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsig
 // caller's stream. A slot is reused after 256 further such calls -- plans that overlap
 // streams or capture graphs pass their own slots.
 constexpr int RING_SLOTS = 256;
+constexpr int RING_DEVICES = 16;
 unsigned* ring_slot() {
-  static unsigned* base = nullptr;
-  static unsigned next = 0;
-  if (!base) {
-    if (hipMalloc(reinterpret_cast<void**>(&base),
+  // one ring per device, created under a lock (calls may come from several host threads
+  // and devices); the round-robin index is atomic
+  static std::mutex mu;
+  static unsigned* base[RING_DEVICES] = {};
+  static unsigned next[RING_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RING_DEVICES) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base[dev] &&
+        hipMalloc(reinterpret_cast<void**>(&base[dev]),
                   sizeof(unsigned) * EPOS_AMAX_WORDS * RING_SLOTS) != hipSuccess) {
-      base = nullptr;
+      base[dev] = nullptr;
       return nullptr;
     }
   }
-  const unsigned i = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % RING_SLOTS;
-  return base + static_cast<size_t>(i) * EPOS_AMAX_WORDS;
+  const unsigned i = __atomic_fetch_add(&next[dev], 1u, __ATOMIC_RELAXED) % RING_SLOTS;
+  return base[dev] + static_cast<size_t>(i) * EPOS_AMAX_WORDS;
 }
 
 }  // namespace

@@ -61,6 +61,7 @@ class EposPipeline(object):
     self.max_slots = max_slots or batch * num_objs
     self.max_k = max_instances
     self._warned_cap = False
+    self.cap_hits, self.last_cap_hits = [], []   # (scene, image, obj, instances) at the cap
     centers, sizes = _corresp.pack_model_store(model_store, num_objs, num_frags)
     self.obj_ids = list(model_store.dp_model['obj_ids'])
     self.corr = _corresp.CorrExtractor(
@@ -245,6 +246,7 @@ class EposPipeline(object):
     self._pending = None
     self._done.synchronize()                  # the one synchronisation
     S = len(slots)
+    self.last_cap_hits = []
     poses_out = []
     if S:
       rh, rl = self.res_host, self._res_layout
@@ -263,12 +265,20 @@ class EposPipeline(object):
       self.last_totals = self._view(rh, rl, 'totals')[:S * 2].numpy().reshape(
           S, 2).copy()
       for s, (im, obj_id) in enumerate(slots):
-        if wants[s] < 0 and int(nm[s]) >= max_k and not self._warned_cap:
-          # "all found" (detection) stopped at the plan's instance cap: say so, once
-          import warnings
-          warnings.warn('object %d: %d instances found = the cap this pipeline was built '
-                        'with (max_instances); more may exist' % (obj_id, int(nm[s])))
-          self._warned_cap = True
+        if wants[s] < 0 and int(nm[s]) >= max_k:
+          # "all found" (detection) stopped at the plan's instance cap: recorded for EVERY
+          # (frame, object) -- cap_hits accumulates over the run, last_cap_hits is this
+          # batch's -- and warned about once
+          hit = (scene_ids[im] if scene_ids is not None else 0,
+                 image_ids[im] if image_ids is not None else im, obj_id, int(nm[s]))
+          self.cap_hits.append(hit)
+          self.last_cap_hits.append(hit)
+          if not self._warned_cap:
+            import warnings
+            warnings.warn('object %d: %d instances found = the cap this pipeline was '
+                          'built with (max_instances); more may exist' %
+                          (obj_id, int(nm[s])))
+            self._warned_cap = True
         for i in range(int(nm[s])):
           poses_out.append({
               'scene_id': scene_ids[im] if scene_ids is not None else 0,

@@ -51,8 +51,12 @@ from epos_amd import synthetic, weights                                # noqa: E
 PARAMS_FILENAME = 'params.yml'   # common.py
 
 
-# "all found" (num_instances = -1, detection) needs a bound for the static buffers; a frame
-# that reaches it is reported (EposPipeline.collect warns once per run).
+# "all found" (num_instances = -1, detection) needs a bound for the static buffers
+# (--detection_instance_cap); every (frame, object) that reaches it is reported
+# (EposPipeline.cap_hits, printed per frame and summed up at the end of the run). This is a
+# DEVIATION from the reference, where -1 is unbounded (scripts/infer.py:463-468:
+# min(-1, max_instances_to_fit) == -1, so that flag never limits detection either -- nor
+# does it here).
 DETECTION_INSTANCE_CAP = 16
 
 
@@ -90,6 +94,7 @@ def build_parser():
   a('--max_tanimoto_similarity', type=float, default=0.9)
   a('--max_correspondences', type=int, default=None)
   a('--max_instances_to_fit', type=int, default=None)
+  a('--detection_instance_cap', type=int, default=DETECTION_INSTANCE_CAP)   # not in the reference
   a('--max_fitting_iterations', type=int, default=400)
   a('--vis', type=str2bool, default=False)
   a('--vis_gt_poses', type=str2bool, default=True)           # infer.py:126-146
@@ -531,14 +536,17 @@ def main(argv=None):
   B = args.batch
   # Instances per object (infer.py:456-468 of the reference): localization fits as many as
   # the frame's annotations hold -- the plan is sized for the largest count among the frames
-  # read, nothing is clamped; detection ("all found", -1) is bounded by a stated cap, and
-  # reaching it is reported. --max_instances_to_fit lowers both, as in the reference.
+  # read, nothing is clamped; --max_instances_to_fit lowers the counts as in the reference
+  # (scripts/infer.py:467-468). Detection ("all found", -1): the reference's
+  # min(-1, max_instances_to_fit) stays -1, i.e. the flag does not act there; this build
+  # bounds "all found" by --detection_instance_cap (static buffers) and reports every
+  # (frame, object) that reaches the cap.
   if args.task_type == pipeline.LOCALIZATION:
     max_inst = max([1] + [int(c) for f in frames for c in f[4].values()])
+    if args.max_instances_to_fit is not None:
+      max_inst = max(1, min(max_inst, args.max_instances_to_fit))
   else:
-    max_inst = DETECTION_INSTANCE_CAP
-  if args.max_instances_to_fit is not None:
-    max_inst = max(1, min(max_inst, args.max_instances_to_fit))
+    max_inst = max(1, int(args.detection_instance_cap))
   depth = max(1, args.pipeline_depth)
   if operator_path or args.save_corresp or args.vis:
     depth = 1                      # those paths read the plan's buffers after the step
@@ -615,6 +623,12 @@ def main(argv=None):
   while inflight:
     q, j0, ch = inflight.pop(0)
     finish(j0, ch, *q.collect())
+  hits = sorted(set(h for q in pipes for h in q.cap_hits))
+  if hits:
+    print('Instance cap (--detection_instance_cap={}) reached for {} (scene, image, object) '
+          'triples; more instances may exist there:'.format(max_inst, len(hits)))
+    for sc_, im_, ob_, n_ in hits:
+      print('  scene {} image {} object {}: {} instances'.format(sc_, im_, ob_, n_))
   # First-image time := mean time of the others (infer.py:741-749).
   if len(poses_all) > 1 and frames:
     first = (frames[0][0], frames[0][1])

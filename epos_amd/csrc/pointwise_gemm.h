@@ -35,6 +35,11 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                       const int* conv_cin = nullptr, const int* conv_rate = nullptr);
 bool h2_eligible(const EposPointwiseArgs* args, int count);
 int64_t sepconv_sync_words(int M);
+// pointwise_gemm_h2.hip: the fused separable conv on the fp16-pair kernel (LDS-staged
+// depthwise producer phase writing fp16 pairs, pre-split K loop); taken when the caller
+// opted into fp16-pair intermediates (dw.y_h2 and pw.a_presplit).
+bool sepconv_h2_eligible(const EposSepConvArgs* a);
+int launch_sepconv_h2(const EposSepConvArgs* a, hipStream_t s);
 
 namespace {
 

@@ -787,11 +787,15 @@ extern "C" int epos_separable_conv_f32(const EposSepConvArgs* a, void* stream) {
     const char* e = getenv("EPOS_SEPCONV_FUSED");
     return e ? atoi(e) : 1;
   }();
-  const bool ok = fused != 0 && a->sync && d.stride == 1 && d.Hi == d.Ho && d.Wi == d.Wo &&
-                  d.C % 4 == 0 && d.ldx % 4 == 0 && d.ldy % 4 == 0 && p.sub == 1 &&
-                  p.M > 8 && split_eligible(&p, 1) &&
-                  (reinterpret_cast<uintptr_t>(d.X) & 15) == 0 &&
-                  (reinterpret_cast<uintptr_t>(d.Y) & 127) == 0 &&
+  const bool shape_ok = fused != 0 && a->sync && d.stride == 1 && d.Hi == d.Ho &&
+                        d.Wi == d.Wo && d.C % 4 == 0 && d.ldx % 4 == 0 && d.ldy % 4 == 0 &&
+                        p.sub == 1 && p.M > 8 &&
+                        (reinterpret_cast<uintptr_t>(d.X) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(d.Y) & 127) == 0;
+  // fp16-pair intermediates (dw.y_h2 + pw.a_presplit): the fused fp16-pair kernel
+  if (shape_ok && sepconv_h2_eligible(a))
+    return launch_sepconv_h2(a, static_cast<hipStream_t>(stream));
+  const bool ok = shape_ok && !d.y_h2 && !p.a_presplit && split_eligible(&p, 1) &&
                   static_cast<int64_t>(d.Hi) * d.Wi * d.ldx < (1LL << 29);
   if (ok) return launch_sepconv_split(a, static_cast<hipStream_t>(stream));
   const int rd = epos_depthwise3x3_f32(&d, stream);

@@ -52,7 +52,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __attribute__((aligned(16))) float g_zero_chunk_h2[4] = {0.f, 0.f, 0.f, 0.f};
+// where the always-issued output stores of the fused depthwise producer go for lanes that
+// have no output (rows past M, channel groups past the slice)
+__device__ __attribute__((aligned(16))) float g_dw_dump_h2[4 * THREADS];
 
+constexpr int RING_DEVICES = 16;
 constexpr int H2_BM = 128, H2_BN = 128, H2_BK = 16;
 constexpr int H2_W_BYTES = H2_BK * H2_BN * 4;       // 8192: 4 col blocks x 2 pieces x 1 KB
 constexpr int H2_A_BYTES = H2_BM * H2_BK * 4;       // 8192
@@ -74,6 +78,283 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float s, unsigned
 __device__ __forceinline__ void a_scale(const EposPointwiseArgs& p, int lane, float& s,
                                         float& inv) {
   h2_scale(p.a_amax, p.a_amax2, p.a_gain, p.a_bias, lane, s, inv);
+}
+
+// ---------------------------------------------------------------------------------
+// Fused separable conv on the fp16-pair kernel (round 4; epos_separable_conv_f32 when the
+// caller opted into fp16-pair intermediates: dw.y_h2 and pw.a_presplit): the depthwise 3x3
+// runs as a PRODUCER PHASE of the pointwise GEMM's own workgroups, as in round 2's
+// bf16 x 6 version (pointwise_gemm_split.hip) -- the tiles_n workgroups that share a row
+// tile each compute 1 / tiles_n of the channels of the tile's 128 rows, hand them over
+// through global memory (write-through stores, one arrival counter, one agent-scope
+// acquire per workgroup), and the K loop reads the intermediate as its A operand -- but
+//   * the producer stages its input through LDS by LDS-DMA: per chunk of 16 channels the
+//     three dilated input rows of the tile (128 + 2 * 4 raster-contiguous pixels each,
+//     64 B per pixel: 26 KB) land in one of three ring buffers that the GEMM's 80 KB ring
+//     leaves unused at that point; a thread computes 2 pixels x 4 channels per chunk from
+//     18 conflict-free ds_read_b128 (the register-direct version of round 2 issued 9
+//     global loads per output from 4 waves: 14.6 us per workgroup, TA-issue bound);
+//   * it writes fp16 PAIRS (the y_h2 arithmetic of layers.hip, same scale as the GEMM's
+//     a_scale), so every activation is split once instead of once per column tile and the
+//     K loop is the PRESPLIT instantiation -- no conversion in the loop (the split costs
+//     11-18 % of the loop, profiles/r04/power_by_component_h2.txt);
+//   * same fmaf chain per output as depthwise3x3_s1_kernel: intermediate and result are
+//     bit-identical to the two launches (tests/test_gpu_layers.py).
+// Progress never depends on co-scheduling: a workgroup that has waited `timeout` for its
+// siblings computes their slices itself (identical values; duplicate stores are benign).
+// ---------------------------------------------------------------------------------
+struct H2Div { unsigned mul, sh1, sh2; };          // n / d by multiply-shift (32-bit n)
+struct DwPhaseH2 {
+  const float* X; int64_t ldx;                     // depthwise input, NHWC
+  const float* w9c; const float* bias;             // [9][C] (BN folded), [C]
+  float* T; int64_t ldt;                           // depthwise output (fp16 pairs) = A
+  unsigned* sync;                                  // [tiles_m][2] arrivals, departures
+  unsigned* stats;                                 // [2] time-outs (diagnostics) or null
+  int Hi, Wi, rate, relu_in, relu_out, C;
+  unsigned timeout;                                // 100 MHz ticks
+  H2Div dw, dh;                                    // / Wi, / Hi
+};
+typedef __attribute__((address_space(1))) unsigned h2_gu32;
+typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DWP_RUN = 136;                       // staged pixels per input row of a chunk
+constexpr int DWP_PADL = 4;                        // = the largest dilation served
+constexpr int DWP_RUN_BYTES = DWP_RUN * 64;        // 16 channels fp32 per pixel
+constexpr int DWP_DATA = 3 * DWP_RUN_BYTES;        // 26112: one ring buffer
+constexpr int DWP_NBUF = 3;
+constexpr int DWP_WOFF = DWP_NBUF * DWP_DATA;      // 78336: three 1 KB weight areas
+constexpr int DWP_FLAG = DWP_WOFF + DWP_NBUF * 1024;   // 81408: the time-out flag
+constexpr int DWP_NI = 7;                          // LDS-DMA instructions per wave and chunk
+static_assert(DWP_FLAG + 16 <= H2_LDS, "producer buffers must fit the GEMM's ring");
+
+__device__ __forceinline__ unsigned h2_div(unsigned n, const H2Div& f) {
+  const unsigned t = __umulhi(f.mul, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+__device__ __forceinline__ float relu_1op_h2(float x) {          // as layers.hip
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+// Plain 16-byte store (lands in L2). A C++ store, NOT inline asm: a store of more than 64
+// bits reads its data VGPRs a cycle or two after issue, and the compiler only keeps the next
+// VALU write away from them (s_nop) for stores it knows about -- an asm store had its first
+// two data registers overwritten by the address computation of the next one.
+__device__ __forceinline__ void st4_l2_h2(float* p, u32x4 v) {
+  *reinterpret_cast<u32x4*>(p) = v;
+}
+
+// Depthwise 3x3 (stride 1, dilation d.rate <= 4, TF 'SAME') of rows [m0, m0 + 128) for the
+// channel groups (float4) [g_lo, g_lo + wc), written as fp16 pairs under the scale `sa`.
+__device__ __forceinline__ void dw_produce_h2(const DwPhaseH2& d, float* smem, unsigned lds0,
+                                              int M, int m0, int g_lo, int wc, float sa,
+                                              int t) {
+  const int lane = t & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int g = t & 3;
+  const int c4n = d.C >> 2;
+  const int Wi = d.Wi, Hi = d.Hi, r = d.rate;
+  const int nq = (wc + 3) >> 2;                    // chunks of 4 groups (16 channels)
+  if (nq <= 0) return;                             // uniform
+  const float* xb = uniform_ptr(d.X);
+  // ---- L2 prefetch: the tile's input (3 rows x 136 pixels x this slice's channels) was
+  //      written by the previous launch and sits in the Infinity Cache / HBM; with ~52 KB of
+  //      LDS-DMA in flight per workgroup a chunk loop that pays that latency per chunk is
+  //      latency bound (16 us measured). One dword per 128-byte line, all issued at once,
+  //      pulls everything into this XCD's L2; they retire (in order) with the first chunk.
+  //      The loads are LDS-DMA dwords into a dump area (the third weight area, unused
+  //      until chunk 2 is issued): no destination VGPRs, so nothing the compiler allocates
+  //      can be overwritten by a load that returns late.
+  {
+    const int nl = ((wc * 16 + 127) >> 7) + 1;           // lines per pixel (unaligned rows)
+    const int fmax = (g_lo + wc) * 4 - 1;
+    const unsigned dump = __builtin_amdgcn_readfirstlane(lds0 + DWP_WOFF + 2 * 1024 + (wave_u & 1) * 256);
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      int px = t + i2 * 256;
+      px = px < 3 * DWP_RUN ? px : 3 * DWP_RUN - 1;
+      const int run = px / DWP_RUN, pr = px - run * DWP_RUN;
+      int mm = m0 + pr - DWP_PADL + (run - 1) * r * Wi;
+      mm = mm < 0 ? 0 : (mm >= M ? M - 1 : mm);
+      const float* row = d.X + static_cast<int64_t>(mm) * d.ldx;
+#pragma unroll
+      for (int l = 0; l < 5; ++l) {
+        int fo = g_lo * 4 + (l < nl ? l : nl - 1) * 32;
+        fo = fo < fmax ? fo : fmax;
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                     : : "v"(row + fo), "s"(dump) : "memory", "m0");
+      }
+    }
+  }
+  // ---- my 7 LDS-DMA instructions of a chunk: 27 = 3 input rows x 9 pieces of 16 pixels
+  //      (the ninth overlaps the eighth: 136 = 8 * 16 + 8) + 1 = the nine weight vectors
+  //      and the bias of the chunk's 16 channels
+  unsigned pixoff[DWP_NI], dsto[DWP_NI];
+  const float* wsrc = d.bias;
+#pragma unroll
+  for (int u = 0; u < DWP_NI; ++u) {
+    const int j = wave_u * DWP_NI + u;             // uniform
+    pixoff[u] = 0; dsto[u] = 0;
+    if (j < 27) {
+      const int run = j / 9, i = j - run * 9;
+      const int ps = i < 8 ? 16 * i : DWP_RUN - 16;
+      int mm = m0 + ps + (lane >> 2) - DWP_PADL + (run - 1) * r * Wi;
+      mm = mm < 0 ? 0 : (mm >= M ? M - 1 : mm);    // masked at compute time
+      pixoff[u] = static_cast<unsigned>(mm) * static_cast<unsigned>(d.ldx * 4);
+      dsto[u] = static_cast<unsigned>(run * DWP_RUN_BYTES + ps * 64);
+    } else {
+      const int tap = lane >> 2;
+      if (tap < 9) wsrc = d.w9c + static_cast<int64_t>(tap) * d.C;
+    }
+  }
+  auto issue = [&](int q, int b) {
+    const int gq = g_lo + 4 * q + (lane & 3);
+    const int gcl = gq < c4n ? gq : c4n - 1;       // a lane past the tensor's channels
+#pragma unroll
+    for (int u = 0; u < DWP_NI; ++u) {
+      const int j = wave_u * DWP_NI + u;
+      if (j < 27) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            lds0 + static_cast<unsigned>(b) * DWP_DATA + dsto[u]);
+        glds16_s_m0(pixoff[u] + static_cast<unsigned>(gcl) * 16u, xb, dst);
+      } else {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            lds0 + DWP_WOFF + static_cast<unsigned>(b) * 1024u);
+        glds16_v_m0(wsrc + gcl * 4, dst);
+      }
+    }
+  };
+  // ---- my two pixels: validity of the nine taps, output row
+  unsigned okm[2];
+  bool valid[2];
+  unsigned toff[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int pl = (t >> 2) + 64 * pp;
+    int m = m0 + pl;
+    valid[pp] = m < M;
+    m = m < M ? m : M - 1;
+    const unsigned row = h2_div(static_cast<unsigned>(m), d.dw);
+    const int x = m - static_cast<int>(row) * Wi;
+    const int y = static_cast<int>(row - h2_div(row, d.dh) * Hi);
+    unsigned ok = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yi = y + (ky - 1) * r, xi = x + (kx - 1) * r;
+        const bool in = static_cast<unsigned>(yi) < static_cast<unsigned>(Hi) &&
+                        static_cast<unsigned>(xi) < static_cast<unsigned>(Wi);
+        ok |= in ? 1u << (ky * 3 + kx) : 0u;
+      }
+    okm[pp] = ok;
+    toff[pp] = static_cast<unsigned>(m) * static_cast<unsigned>(d.ldt);
+  }
+  const bool relu_in = d.relu_in != 0, relu_out = d.relu_out != 0;
+  const int ro = r * 16;                           // floats between taps kx, kx + 1
+  // every tap of both pixels of every lane of this wave inside the image: no selects
+  const bool interior = __builtin_amdgcn_ballot_w64(okm[0] != 0x1ffu || okm[1] != 0x1ffu) == 0;
+  // One chunk for both pixels of the thread: ALL LDS reads first (28 ds_read_b128, nothing
+  // between them -- a run-time flag tested per tap made the compiler wait for every read on
+  // the spot, ~2 us per chunk), then the select / ReLU / fmaf chain.
+  auto compute = [&](int b, auto masked_tag, auto relu_tag, u32x4& o0, u32x4& o1) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr bool RELU_IN = decltype(relu_tag)::value;
+    const float* sb = smem + b * (DWP_DATA / 4);
+    const float* wsm = smem + (DWP_WOFF + b * 1024) / 4;
+    h2_f32x4 w[9], xv[2][9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      w[i] = *reinterpret_cast<const h2_f32x4*>(wsm + (i * 4 + g) * 4);
+    const h2_f32x4 bias = *reinterpret_cast<const h2_f32x4*>(wsm + (36 + g) * 4);
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const float* px = sb + ((t >> 2) + 64 * pp + DWP_PADL) * 16 + g * 4;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          xv[pp][ky * 3 + kx] =
+              *reinterpret_cast<const h2_f32x4*>(px + ky * (DWP_RUN * 16) + (kx - 1) * ro);
+    }
+    u32x4 o[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      h2_f32x4 acc = bias;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        h2_f32x4 x = xv[pp][i];
+        if constexpr (MASKED) {
+          const bool in = (okm[pp] >> i) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = in ? x[e] : 0.f;
+        }
+        if constexpr (RELU_IN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = relu_1op_h2(x[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(x[e], w[i][e], acc[e]);
+      }
+      if (relu_out) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = relu_1op_h2(acc[e]);
+      }
+      unsigned h0, h1, mm0, mm1;
+      h2_split_pair(acc[0], acc[1], sa, h0, mm0);
+      h2_split_pair(acc[2], acc[3], sa, h1, mm1);
+      o[pp][0] = h0; o[pp][1] = h1; o[pp][2] = mm0; o[pp][3] = mm1;
+    }
+    o0 = o[0]; o1 = o[1];
+  };
+  // ---- the chunk loop: COMPACT code (a first version, unrolled over eight chunks with the
+  //      outputs held in registers, was ~50 KB of straight-line code executed once per
+  //      workgroup -- 17 us per tile, instruction-fetch bound). Chunk q + 2 is issued while
+  //      chunk q is computed; the two output stores of a chunk are ALWAYS issued (lanes
+  //      without an output store to a dump word), so the counted waits know exactly what is
+  //      in flight: vector memory operations retire in order on gfx9-family parts.
+#ifdef EPOS_SEPCONV_TRACE
+  if (t == 0 && d.stats) (reinterpret_cast<uint64_t*>(d.stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x))[6] = wall_clock64();
+#endif
+  issue(0, 0);
+  if (nq > 1) issue(1, 1);
+  int b = 0;
+#pragma unroll 1
+  for (int q = 0; q < nq; ++q) {
+    // younger than chunk q's pieces: the stores of up to two earlier chunks (2 each) and
+    // chunk q + 1's seven pieces
+    const int younger = (q + 1 < nq ? DWP_NI : 0) + 2 * (q < 2 ? q : 2);
+    switch (younger) {
+      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();       // chunk q visible; everyone is past chunk q - 1
+    asm volatile("" ::: "memory");
+#ifdef EPOS_SEPCONV_TRACE
+    if (t == 0 && d.stats && q == 0) (reinterpret_cast<uint64_t*>(d.stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x))[7] = wall_clock64();
+#endif
+    const int b2 = b >= 1 ? b - 1 : b + 2;        // (q + 2) % 3
+    if (q + 2 < nq) issue(q + 2, b2);
+    u32x4 o0, o1;
+    if (relu_in) {
+      if (interior) compute(b, std::false_type{}, std::true_type{}, o0, o1);
+      else compute(b, std::true_type{}, std::true_type{}, o0, o1);
+    } else {
+      if (interior) compute(b, std::false_type{}, std::false_type{}, o0, o1);
+      else compute(b, std::true_type{}, std::false_type{}, o0, o1);
+    }
+    const int gq = g_lo + 4 * q + g;
+    const bool gok = gq < g_lo + wc;
+    float* dump = g_dw_dump_h2 + t * 4;
+    st4_l2_h2(valid[0] && gok ? d.T + (static_cast<size_t>(toff[0]) + gq * 4) : dump, o0);
+    st4_l2_h2(valid[1] && gok ? d.T + (static_cast<size_t>(toff[1]) + gq * 4) : dump, o1);
+    b = b == DWP_NBUF - 1 ? 0 : b + 1;
+  }
+  static_assert(DWP_NI == 7, "the counted waits assume 7 pieces per wave and chunk");
 }
 
 // Epilogue of the h2 kernel: value = (acc + corr * 2^-11) * 2^-e_n * 2^-e_a + bias
@@ -135,8 +416,10 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
 
 // PRESPLIT: every problem of the launch has its A operand already as fp16 pairs
 // (EposPointwiseArgs.a_presplit; the plan does not mix the two kinds in one group).
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT>
-__global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs ga_) {
+// DW: fused separable conv (the producer phase above; SINGLE, PRESPLIT, not CONV).
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, bool DW = false>
+__global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs ga_,
+                                                                    DwPhaseH2 dw_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -145,9 +428,23 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   const int l31 = lane & 31, h = lane >> 5;
 
   (void)ga_;
+  (void)dw_;
   const GroupedArgs* __restrict__ gp =
       (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   int bid;
+  if constexpr (DW) {
+    // Fused separable conv: an XCD (blockIdx % 8) owns WHOLE row tiles, so that the
+    // workgroups that share a row tile -- and hand the depthwise slices to each other --
+    // sit behind the same L2: the hand-off then needs neither write-through stores nor an
+    // L2 invalidate (plain stores are in L2 once vmcnt says so, the siblings' LDS-DMA reads
+    // hit them there). Surplus workgroups of XCDs with one row tile less leave at once.
+    const int tn = gp->tiles_n[0];
+    const int tiles_m = (gp->p[0].M + H2_BM - 1) / H2_BM;
+    const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int rt_lo = x * tiles_m / 8, rt_n = (x + 1) * tiles_m / 8 - rt_lo;
+    if (idx >= rt_n * tn) return;
+    bid = rt_lo * tn + idx;
+  } else
   {   // workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles
     const int total = gp->tile_start[MAX_GROUP];
     const int raw = blockIdx.x, x = raw & 7, idx = raw >> 3;
@@ -167,7 +464,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   // tile order inside an XCD's range: column fastest; wide problems in bands of 8 column
   // tiles (all row tiles of a band before the next band), as in the split kernel
   int tile_m, tile_n;
-  if (tiles_n <= 8) {
+  if (DW || tiles_n <= 8) {       // DW: the siblings of a row tile must be neighbours
     tile_n = bid % tiles_n;
     tile_m = bid / tiles_n;
   } else {
@@ -191,6 +488,72 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
 
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
+
+  if constexpr (DW) {
+    // ---- producer phase: my channel slice of this row tile's depthwise output ----
+    const DwPhaseH2* __restrict__ dp = reinterpret_cast<const DwPhaseH2*>(
+        reinterpret_cast<const char*>(gp) + ((sizeof(GroupedArgs) + 7) & ~size_t(7)));
+    const DwPhaseH2 d = *dp;
+    const int c4n = K >> 2;
+    int* flag = reinterpret_cast<int*>(smem + DWP_FLAG / 4);
+    h2_gu32* cnt = (h2_gu32*)(d.sync + 2 * tile_m);
+    int late = 0;
+#ifdef EPOS_SEPCONV_TRACE      // tools/sepconv_h2_trace.py: 100 MHz stamps per workgroup
+    uint64_t* trc = reinterpret_cast<uint64_t*>(d.stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x);
+    if (t == 0) trc[0] = wall_clock64();
+#endif
+#pragma unroll 1
+    for (int pass = 0; pass < tiles_n; ++pass) {
+      // pass 0: my slice; further passes (only after a time-out): the siblings' slices
+      const int sl = pass == 0 ? tile_n : (pass <= tile_n ? pass - 1 : pass);
+      const int g_lo = sl * c4n / tiles_n;
+      const int wc = (sl + 1) * c4n / tiles_n - g_lo;
+      dw_produce_h2(d, smem, lds0, M, m0, g_lo, wc, sa, t);
+#ifdef EPOS_SEPCONV_TRACE
+      if (t == 0 && pass == 0) trc[1] = wall_clock64();
+#endif
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every storing wave drains
+      __syncthreads();
+#ifdef EPOS_SEPCONV_TRACE
+      if (t == 0 && pass == 0) trc[2] = wall_clock64();
+#endif
+      if (pass == 0) {
+        if (t == 0) {
+          __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t t0 = wall_clock64();
+          int lt = 0;
+          while (__hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+                 static_cast<unsigned>(tiles_n)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > d.timeout) { lt = 1; break; }
+          }
+          *flag = lt;
+#ifdef EPOS_SEPCONV_TRACE
+          trc[3] = wall_clock64();
+#endif
+        }
+        __syncthreads();
+        late = *flag;
+        if (!late) break;          // uniform: every slice of the row tile is in memory
+      }
+    }
+    if (t == 0) {
+      if (late && d.stats)
+        __hip_atomic_fetch_add((h2_gu32*)d.stats, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      // no acquire: the siblings are behind this XCD's L2 (see the tile mapping above)
+      // departures: the last sibling re-arms the pair for the next launch of this layer
+      if (__hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+          static_cast<unsigned>(tiles_n - 1)) {
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#ifdef EPOS_SEPCONV_TRACE
+      trc[4] = wall_clock64();
+#endif
+    }
+    __syncthreads();
+  }
 
   // ---- A pieces (1 KB = 16 rows x 64 B): piece = wave*2 + i, lane -> (row, slot);
   //      slot s of row r holds chunk s ^ ((r >> 2) & 3)
@@ -475,6 +838,13 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{}, std::integral_constant<bool, PRESPLIT>{});
   else k_loop(std::integral_constant<int, 4>{}, std::integral_constant<bool, PRESPLIT>{});
 
+#ifdef EPOS_SEPCONV_TRACE
+  if constexpr (DW) {
+    const DwPhaseH2* dq = reinterpret_cast<const DwPhaseH2*>(
+        reinterpret_cast<const char*>(gp) + ((sizeof(GroupedArgs) + 7) & ~size_t(7)));
+    if (t == 0) (reinterpret_cast<uint64_t*>(dq->stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x))[5] = wall_clock64();
+  }
+#endif
   // ---- epilogue --------------------------------------------------------------
 #ifdef EPOS_H2_ABL_NOEPI            // ablation (tools/power_components_h2.py): no epilogue
   if (p.ldr != 0x7fffffff) return;  // (always taken; the compiler cannot know)
@@ -518,9 +888,10 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   }
 }
 
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false>
-int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT>;
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, bool DW = false>
+int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s,
+                 const DwPhaseH2* dw = nullptr) {
+  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, DW>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -528,7 +899,8 @@ int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
     attr_set = true;
   }
   // 80 KB per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), H2_LDS, s, g);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), H2_LDS, s, g,
+                     dw ? *dw : DwPhaseH2{});
   return launch_status("pointwise_gemm_h2_f32");
 }
 
@@ -588,7 +960,6 @@ int launch_absmax(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsig
 // caller's stream. A slot is reused after 256 further such calls -- plans that overlap
 // streams or capture graphs pass their own slots.
 constexpr int RING_SLOTS = 256;
-constexpr int RING_DEVICES = 16;
 unsigned* ring_slot() {
   // one ring per device, created under a lock (calls may come from several host threads
   // and devices); the round-robin index is atomic
@@ -699,7 +1070,119 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                 : launch_h2_tt<false, false, false>(g, total, s);
 }
 
+// The fused kernel's hand-off assumes that workgroups whose block indices agree modulo 8
+// run on the same XCD (the dispatcher deals workgroups round robin over the XCDs). That is
+// probed ONCE per device (64 workgroups report HW_REG_XCC_ID; blocking, so never during a
+// stream capture): if it does not hold -- or cannot be probed yet -- the fused path is not
+// taken and epos_separable_conv_f32 issues the two launches.
+__global__ void xcc_probe_kernel(unsigned* out) {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (threadIdx.x == 0) out[blockIdx.x] = x & 15u;
+}
+int xcd_mapping_state(hipStream_t s) {      // 1 ok, 0 not ok, -1 unknown (capturing)
+  static std::mutex mu;
+  static int state[RING_DEVICES];
+  static bool init = false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!init) {
+    for (int i = 0; i < RING_DEVICES; ++i) state[i] = -1;
+    init = true;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RING_DEVICES) return 0;
+  if (state[dev] >= 0) return state[dev];
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+    return -1;
+  constexpr int NB = 256;
+  unsigned* dbuf = nullptr;
+  unsigned host[NB];
+  int ok = 0;
+  if (hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(host)) == hipSuccess) {
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(NB), dim3(64), 0, s, dbuf);
+    if (hipMemcpyAsync(host, dbuf, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess &&
+        hipStreamSynchronize(s) == hipSuccess) {
+      ok = 1;
+      for (int b = 8; b < NB; ++b) ok = ok && host[b] == host[b & 7];
+    }
+    (void)hipFree(dbuf);
+  }
+  state[dev] = ok;
+  return ok;
+}
+
+// Fused separable conv on the fp16-pair kernel (epos_separable_conv_f32). The caller has
+// checked eligibility (sepconv_h2_eligible).
+bool sepconv_h2_eligible(const EposSepConvArgs* a) {
+  const EposDepthwiseArgs& d = a->dw;
+  const EposPointwiseArgs& p = a->pw;
+  if (!(p.Wh && p.a_amax && p.a_presplit && d.y_h2)) return false;
+  if (!h2_eligible(&p, 1)) return false;
+  // the GEMM derives the scale of its A operand from its own fields: they must be the
+  // ones the depthwise output was described with
+  if (d.x_amax != p.a_amax || d.x_amax2 != p.a_amax2 || d.gain != p.a_gain ||
+      d.bias0 != p.a_bias)
+    return false;
+  if (d.rate < 1 || d.rate > DWP_PADL) return false;
+  const int64_t xbytes = static_cast<int64_t>(d.B) * d.Hi * d.Wi * d.ldx * 4;
+  return xbytes < (1LL << 32) && (reinterpret_cast<uintptr_t>(d.w9c) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0;
+}
+
+int launch_sepconv_h2(const EposSepConvArgs* a, hipStream_t s) {
+  if (xcd_mapping_state(s) != 1) {          // not proven: the two launches (same bits)
+    const int rd = epos_depthwise3x3_f32(&a->dw, s);
+    if (rd) return rd;
+    return epos_pointwise_conv_f32(&a->pw, s);
+  }
+  const EposPointwiseArgs& pw = a->pw;
+  const EposDepthwiseArgs& dwa = a->dw;
+  GroupedArgs g = {};
+  g.count = 1;
+  g.p[0] = pw;
+  g.tile_start[0] = 0;
+  g.tiles_n[0] = static_cast<int>(ceil_div(pw.N, H2_BN));
+  g.npad[0] = g.tiles_n[0] * H2_BN;
+  g.conv_rate[0] = 1;
+  const int total = static_cast<int>(ceil_div(pw.M, H2_BM)) * g.tiles_n[0];
+  for (int i = 1; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  auto sp = [](unsigned d) {
+    H2Div f;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = static_cast<unsigned>(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l > 0 ? 1 : 0;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+  };
+  static const unsigned timeout = [] {      // EPOS_SEPCONV_TIMEOUT_US (default 200)
+    const char* e = getenv("EPOS_SEPCONV_TIMEOUT_US");
+    return static_cast<unsigned>((e ? atoi(e) : 200) * 100);
+  }();
+  DwPhaseH2 d = {};
+  d.X = dwa.X; d.ldx = dwa.ldx;
+  d.w9c = dwa.w9c; d.bias = dwa.bias;
+  d.T = dwa.Y; d.ldt = dwa.ldy;
+  d.sync = a->sync;
+  d.stats = a->stats;
+  d.Hi = dwa.Hi; d.Wi = dwa.Wi; d.rate = dwa.rate; d.C = dwa.C;
+  d.relu_in = dwa.relu_in; d.relu_out = dwa.relu_out;
+  d.timeout = timeout;
+  d.dw = sp(static_cast<unsigned>(dwa.Wi));
+  d.dh = sp(static_cast<unsigned>(dwa.Hi));
+  // XCD-aligned grid: 8 x (row tiles of the fullest XCD) x column tiles (surplus exits)
+  const int tiles_m = static_cast<int>(ceil_div(pw.M, H2_BM));
+  const int grid = 8 * static_cast<int>(ceil_div(tiles_m, 8)) * g.tiles_n[0];
+  return pw.R != nullptr ? launch_h2_tt<true, true, false, true, true>(g, grid, s, &d)
+                         : launch_h2_tt<false, true, false, true, true>(g, grid, s, &d);
+}
+
 }  // namespace epos
+
+extern "C" int epos_separable_conv_fused_state(void* stream) {
+  return epos::xcd_mapping_state(static_cast<hipStream_t>(stream));
+}
 
 extern "C" int epos_amax_clear(uint32_t* slots, int64_t n_slots, void* stream) {
   using namespace epos;

@@ -119,7 +119,9 @@ __device__ __forceinline__ unsigned sp_div(unsigned n, const SpDiv& f) {
   return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 __device__ __forceinline__ void st4_wt(float* p, f32x4 v) {      // write-through store
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  // s_nop: a store of more than 64 bits reads its data VGPRs after issue; the compiler does
+  // not know this asm is one and would not keep the next VALU write away from them
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ float relu_1op_sp(float x) {          // as layers.hip
   float r;

@@ -94,11 +94,12 @@ class EposNet(object):
         dtype=torch.uint8, device=self.dev)
     # Fused separable convs (depthwise as a producer phase of the pointwise GEMM's
     # workgroups, epos_separable_conv_f32) for every stride-1 sep-conv whose GEMM is a
-    # launch of its own: OPT-IN (EPOS_SEPCONV_FUSED=1). Same bits either way, but
-    # measured slower (round 2, DESIGN.md: 294 vs 331 images/s): the producer phase costs
-    # a workgroup 14 us of latency-bound loads + 5 us of hand-off where the stand-alone
-    # depthwise launch costs 8.8 us, and a CU with one GEMM workgroup in its K loop
-    # only reaches ~70 % of the two-workgroup rate, so little of it hides.
+    # launch of its own (EPOS_SEPCONV_FUSED=0|1). Round 2's version (register-direct loads
+    # in front of the bf16 x 6 loop) measured slower (294 vs 331 images/s: 14 us of
+    # latency-bound loads per workgroup); round 4's runs in the fp16-pair kernel with an
+    # LDS-staged producer that writes fp16 pairs, so the K loop carries no operand split
+    # (csrc/pointwise_gemm_h2.hip). Same bits as the two launches with fp16-pair
+    # intermediates either way.
     import os
     self.fuse_sepconv = os.environ.get('EPOS_SEPCONV_FUSED', '0') == '1'
     self.fused_sepconvs = []
@@ -443,7 +444,7 @@ class EposNet(object):
         B=self.B, Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c, stride=stride, rate=rate,
         relu_in=int(relu_in), relu_out=int(relu_out))
     yb = self._bound_of(y)
-    if yb is not None and self.use_presplit and not defer:
+    if yb is not None and (self.use_presplit or (defer and self.use_h2)):
       # fp16-pair output, pending the consumer's decision (_pointwise): scale from the
       # bound of |Y| = gain * max|X| + max|bias| (the same numbers the GEMM gets)
       args.y_h2 = 1

@@ -246,6 +246,18 @@ int epos_depthwise3x3_f32(const EposDepthwiseArgs* args, void* stream);
  * ONCE by the caller, private to this layer and stream (the kernel re-arms them);
  * stats [device, optional]: one uint32 counting workgroups that stopped waiting for
  * their siblings and computed the siblings' slices themselves (diagnostics). */
+/* Round 4: with fp16-pair intermediates (dw.y_h2 != 0 and pw.a_presplit != 0, pw.Wh and
+ * pw.a_amax given, dw.x_amax / x_amax2 / gain / bias0 equal to pw.a_amax / a_amax2 / a_gain /
+ * a_bias, dw.rate <= 4) the fused launch runs on the fp16-pair kernel: the producer phase
+ * stages its input through LDS by LDS-DMA and writes fp16 pairs, the K loop carries no
+ * operand split. dw.Y then holds the fp16 pairs (the y_h2 format). Bit-identical to
+ * epos_depthwise3x3_f32 (y_h2) + epos_pointwise_conv_f32 (a_presplit). Its hand-off between
+ * the workgroups of a row tile goes through ONE XCD's L2 and relies on workgroups with equal
+ * block index modulo 8 sharing an XCD; epos_separable_conv_fused_state() reports whether
+ * that was verified on the current device (1), refuted (0) or not probed yet because the
+ * first call came during a stream capture (-1) -- unless it is 1 the two launches are
+ * issued instead. */
+int epos_separable_conv_fused_state(void* stream);
 typedef struct EposSepConvArgs {
   EposDepthwiseArgs dw;
   EposPointwiseArgs pw;

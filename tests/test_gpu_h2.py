@@ -450,3 +450,164 @@ def test_presplit_needs_the_fp16_pair_kernel(lib):
                          M=64, N=32, K=32, relu=0, relu_in=0, sub=1, a_presplit=1)
   with pytest.raises(_lib.EposError):
     _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+
+
+# ------------------------------- fused separable conv on the fp16-pair kernel (round 4) ---
+def _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res, seed=0):
+  """A separable conv with fp16-pair intermediates: (dw args, pw args, SepConvArgs) for given
+  intermediate / output / sync buffers; the depthwise input's absmax slot is measured."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(seed + h * 7 + cin)
+  x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+  w9c = (rng.standard_normal((9, cin)) / 3).astype(np.float32)
+  dbias = rng.standard_normal(cin).astype(np.float32)
+  wkn = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+  bias = rng.standard_normal(cout).astype(np.float32)
+  npad = (cout + 127) // 128 * 128
+  bpad = np.zeros(npad, np.float32); bpad[:cout] = bias
+  m = b * h * w
+  t = dict(x=x, w9c_h=w9c, dbias_h=dbias,
+           X=torch.from_numpy(x).cuda(), w9c=torch.from_numpy(w9c).cuda(),
+           dbias=torch.from_numpy(dbias).cuda(), Wp=_pack(lib, wkn), Wh=_pack(lib, wkn, 'h2'),
+           bias=torch.from_numpy(bpad).cuda(),
+           R=torch.from_numpy(rng.standard_normal((m, cout)).astype(np.float32)).cuda(),
+           xs=_slot())
+  _lib.check(lib.epos_absmax_f32(_p(t['X']), cin, m, cin, _p(t['xs']), None))
+  gain = float(np.abs(w9c.astype(np.float64)).sum(0).max())
+  bias0 = float(np.abs(dbias).max())
+
+  def make(T, C, sync, stats=None):
+    dw = _lib.DepthwiseArgs(X=_p(t['X']), ldx=cin, w9c=_p(t['w9c']), bias=_p(t['dbias']),
+                            Y=_p(T), ldy=cin, B=b, Hi=h, Wi=w, Ho=h, Wo=w, C=cin,
+                            stride=1, rate=rate, relu_in=relu_in, relu_out=relu_out,
+                            y_h2=1, x_amax=_p(t['xs']), gain=gain, bias0=bias0)
+    pw = _lib.PointwiseArgs(A=_p(T), lda=cin, Wp=_p(t['Wp']), bias=_p(t['bias']),
+                            R=_p(t['R']) if res else None, ldr=cout, C=_p(C), ldc=cout,
+                            M=m, N=cout, K=cin, relu=1, relu_in=0, sub=1, Wh=_p(t['Wh']),
+                            a_amax=_p(t['xs']), a_gain=gain, a_bias=bias0, a_presplit=1)
+    return dw, pw, _lib.SepConvArgs(dw=dw, pw=pw, sync=_p(sync) if sync is not None else None,
+                                    stats=_p(stats) if stats is not None else None)
+  return t, m, make
+
+
+@pytest.mark.parametrize('b,h,w,cin,cout,rate', [
+    (1, 60, 80, 728, 728, 2),       # middle flow: 6 siblings, ragged slices (30 / 31 groups)
+    (1, 60, 80, 1024, 1536, 4),     # exit flow: 12 column tiles, rate 4 = the staging pad
+    (1, 30, 40, 304, 256, 1),       # decoder shape: slices of 38 groups = two super-blocks
+    (2, 13, 17, 64, 128, 1),        # one column tile, tiles straddle the two images
+    (1, 9, 11, 36, 200, 3),         # rate > a third of the image: every tap class at the border
+    (1, 120, 160, 256, 256, 1),     # 19200 rows
+    (1, 8, 8, 8, 384, 2)])          # fewer channel groups than column tiles: empty slices
+@pytest.mark.parametrize('relu_in,relu_out,res', [(0, 1, 0), (1, 0, 1)])
+def test_fused_separable_conv_h2_equals_two_launches(lib, b, h, w, cin, cout, rate, relu_in,
+                                                     relu_out, res):
+  """epos_separable_conv_f32 with fp16-pair intermediates (dw.y_h2 + pw.a_presplit: the
+  LDS-staged depthwise producer phase inside pointwise_gemm_h2_f32) against
+  epos_depthwise3x3_f32 (y_h2) + epos_pointwise_conv_f32 (a_presplit): intermediate (the
+  fp16 pairs) and output bit for bit, over repeated launches (the counters re-arm)."""
+  from epos_amd import _lib
+  # the fused kernel really runs here (otherwise the entry point issues the two launches and
+  # this test would compare them with themselves): the XCD mapping its hand-off relies on
+  # has been verified on this device
+  assert lib.epos_separable_conv_fused_state(None) == 1
+  t, m, make = _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res)
+  assert t['Wh'] is not None
+  T0 = torch.full((m, cin), 3.0, device='cuda'); C0 = torch.zeros(m, cout, device='cuda')
+  dw, pw, _ = make(T0, C0, None)
+  _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))
+  torch.cuda.synchronize()
+  sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32,
+                     device='cuda')
+  stats = torch.zeros(2, dtype=torch.int32, device='cuda')
+  T1 = torch.empty(m, cin, device='cuda'); C1 = torch.empty(m, cout, device='cuda')
+  _, _, sa = make(T1, C1, sync, stats)
+  for it in range(4):
+    T1.fill_(float(it)); C1.fill_(-1.0)       # stale lines from the previous round
+    _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sa), None))
+    torch.cuda.synchronize()
+    assert torch.equal(T1.view(torch.int32), T0.view(torch.int32)), 'intermediate, launch %d' % it
+    assert torch.equal(C1, C0), 'output, launch %d' % it
+    assert int(sync.abs().sum()) == 0         # re-armed
+  # the reference itself against fp64 (so that "equal" means "right")
+  x = torch.from_numpy(t['x']).double().permute(0, 3, 1, 2)
+  if relu_in:
+    x = x.clamp(min=0)
+  wd = torch.from_numpy(t['w9c_h']).double().t().reshape(cin, 1, 3, 3)
+  y = torch.nn.functional.conv2d(x, wd, padding=rate, dilation=rate, groups=cin) + \
+      torch.from_numpy(t['dbias_h']).double().view(1, -1, 1, 1)
+  if relu_out:
+    y = y.clamp(min=0)
+  y = y.permute(0, 2, 3, 1).reshape(m, cin).numpy()
+  raw = T0.cpu().numpy().view(np.float16).reshape(m, cin // 4, 2, 4).astype(np.float64)
+  bound = float(np.abs(t['w9c_h'].astype(np.float64)).sum(0).max()) * np.abs(t['x']).max() + \
+      float(np.abs(t['dbias_h']).max())
+  s = 2.0 ** (14 - np.floor(np.log2(bound)))
+  dec = ((raw[:, :, 0, :] + raw[:, :, 1, :] / 2048.0) / s).reshape(m, cin)
+  np.testing.assert_allclose(dec, y, rtol=1e-5, atol=1e-5 * bound)
+
+
+def test_fused_separable_conv_h2_concurrent_streams_and_timeout(lib):
+  """Four fused layers in flight on four streams with other kernels competing for the
+  workgroup slots, many rounds, every word checked; then a zero time-out in a fresh process:
+  every workgroup gives up waiting at once and computes its siblings' slices itself --
+  same bits (the progress guarantee of the hand-off)."""
+  import os
+  import subprocess
+  import sys
+  from epos_amd import _lib
+  b, h, w, cin, cout, rate = 1, 60, 80, 728, 728, 2
+  t, m, make = _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, 1, 0, 1, seed=5)
+  T0 = torch.empty(m, cin, device='cuda'); C0 = torch.empty(m, cout, device='cuda')
+  dw, pw, _ = make(T0, C0, None)
+  _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))
+  torch.cuda.synchronize()
+  streams = [torch.cuda.Stream() for _ in range(4)]
+  bufs = []
+  for s in streams:
+    sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32,
+                       device='cuda')
+    T = torch.zeros(m, cin, device='cuda'); C = torch.zeros(m, cout, device='cuda')
+    bufs.append((T, C, sync, make(T, C, sync)[2]))
+  noise = torch.randn(1 << 22, device='cuda')
+  for rnd in range(25):
+    for i, s in enumerate(streams):
+      T, C, sync, sa = bufs[i]
+      with torch.cuda.stream(s):
+        if (rnd + i) % 3 == 0:
+          noise.mul_(1.0001)                      # uneven load between the launches
+        T.fill_(float(rnd)); C.fill_(-2.0)
+        _lib.check(lib.epos_separable_conv_f32(
+            ctypes.byref(sa), ctypes.c_void_p(s.cuda_stream)))
+    torch.cuda.synchronize()
+    for T, C, sync, _ in bufs:
+      assert torch.equal(T.view(torch.int32), T0.view(torch.int32)) and torch.equal(C, C0), \
+          'round %d' % rnd
+      assert int(sync.abs().sum()) == 0
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = (
+      "import sys, ctypes, numpy as np, torch\n"
+      "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+      "from epos_amd import _lib\n"
+      "import test_gpu_h2 as th\n"
+      "lib = _lib.load()\n"
+      "t, m, make = th._sepconv_h2_problem(lib, 1, 60, 80, 728, 728, 2, 1, 0, 1, seed=5)\n"
+      "T0 = torch.empty(m, 728, device='cuda'); C0 = torch.empty(m, 728, device='cuda')\n"
+      "dw, pw, _ = make(T0, C0, None)\n"
+      "_lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))\n"
+      "_lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))\n"
+      "sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32, device='cuda')\n"
+      "stats = torch.zeros(2, dtype=torch.int32, device='cuda')\n"
+      "T = torch.zeros(m, 728, device='cuda'); C = torch.zeros(m, 728, device='cuda')\n"
+      "sa = make(T, C, sync, stats)[2]\n"
+      "for it in range(3):\n"
+      "  _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sa), None)); torch.cuda.synchronize()\n"
+      "  assert torch.equal(T.view(torch.int32), T0.view(torch.int32)) and torch.equal(C, C0), it\n"
+      "  assert int(sync.abs().sum()) == 0\n"
+      "print('TIMEOUTS', int(stats[0]))\n" % (root, os.path.join(root, 'tests')))
+  r = subprocess.run([sys.executable, '-c', script],
+                     env=dict(os.environ, EPOS_SEPCONV_TIMEOUT_US='0'),
+                     capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout + r.stderr
+  assert int(r.stdout.split('TIMEOUTS')[1]) > 0, r.stdout     # the path was taken

@@ -170,3 +170,32 @@ def test_split_gemm_network_is_not_less_accurate_than_fp32_mfma(tmp_path):
   assert not np.array_equal(outs['1']['decoder'], outs['0']['decoder'])   # two kernels ran
   for k in exact:
     assert rms['1'][k] <= rms['0'][k] * 1.15, k
+
+
+def test_fused_separable_convs_give_the_same_network_bits(monkeypatch):
+  """EPOS_SEPCONV_FUSED=1 (every stride-1 separable conv with a GEMM launch of its own runs
+  as ONE launch: LDS-staged depthwise producer phase writing fp16 pairs + pre-split K loop,
+  csrc/pointwise_gemm_h2.hip) against the default plan (depthwise launch + GEMM launch with
+  the in-kernel operand split): every head tensor and the encoder / decoder check points
+  bit for bit, eagerly and as a replayed graph, and no hand-off timed out."""
+  from epos_amd import model, weights
+  num_objs, h, w = 2, 96, 128
+  ckpt = weights.random_init(num_objs=num_objs, seed=3, randomize_bn=True, logits_std=0.2)
+  img = torch.from_numpy(
+      np.random.RandomState(0).randint(0, 256, (1, h, w, 3)).astype('f')).cuda()
+  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
+  monkeypatch.setenv('EPOS_SEPCONV_FUSED', '0')
+  net0 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=10)
+  out0 = {k: v.clone() for k, v in net0.forward(img).items()}
+  monkeypatch.setenv('EPOS_SEPCONV_FUSED', '1')
+  net1 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=11)
+  assert len(net1.fused_sepconvs) >= 50 and not net0.fused_sepconvs
+  assert len(net1.presplit_layers) >= len(net1.fused_sepconvs)
+  for rep in range(3):
+    out1 = net1.forward(img, use_graph=rep > 0)
+    torch.cuda.synchronize()
+    for k in out0:
+      assert torch.equal(out0[k], out1[k]), (k, rep)
+    assert torch.equal(net0.encoder, net1.encoder)
+    assert torch.equal(net0.decoder_out, net1.decoder_out)
+  assert int(net1.sepconv_stats[0]) == 0

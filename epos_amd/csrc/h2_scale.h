@@ -15,14 +15,29 @@ typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
 // gain * max(slot, slot2) + bias (gain == 0 reads as 1, 0). A non-finite bound (an Inf / NaN
 // upstream) gives s = 1: such rows come out non-finite, the others right. Wave-wide; every
 // lane returns the same values.
+// The two halves of h2_scale: the lane's word(s) of the slot(s) -- a global load whose
+// latency a caller may want to overlap with other work -- and the wave-wide rest.
+// (the two raw words are only combined in h2_scale_finish: nothing waits for them here)
+__device__ __forceinline__ void h2_scale_load(const unsigned* amax, const unsigned* amax2,
+                                              int lane, unsigned& v, unsigned& v2) {
+  v = amax[lane];
+  // unconditional (a load under a branch is waited for on the spot): without a second slot
+  // the first one is read twice
+  const unsigned* a2 = amax2 ? amax2 : amax;
+  v2 = a2[lane];
+}
+__device__ __forceinline__ void h2_scale_finish(unsigned v, unsigned v2, float gain,
+                                                float bias, float& s, float& inv);
 __device__ __forceinline__ void h2_scale(const unsigned* amax, const unsigned* amax2,
                                          float gain, float bias, int lane, float& s,
                                          float& inv) {
-  unsigned v = amax[lane];
-  if (amax2) {
-    const unsigned v2 = amax2[lane];
-    v = v2 > v ? v2 : v;
-  }
+  unsigned v, v2;
+  h2_scale_load(amax, amax2, lane, v, v2);
+  h2_scale_finish(v, v2, gain, bias, s, inv);
+}
+__device__ __forceinline__ void h2_scale_finish(unsigned v, unsigned v2, float gain,
+                                                float bias, float& s, float& inv) {
+  v = v2 > v ? v2 : v;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned w = __shfl_xor(v, o, 64);

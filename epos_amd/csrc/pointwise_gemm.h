@@ -60,6 +60,9 @@ struct GroupedArgs {
   int conv_cin[MAX_GROUP];         // LDS-DMA kernel, implicit 3x3 conv: input channels
   int conv_rate[MAX_GROUP];        //   and dilation
   int count;
+  // fp16-pair kernel: n / tiles_n[i] by multiply-shift (set by launch_grouped_h2; a run-time
+  // division costs ~25 instructions of every workgroup's set-up)
+  unsigned tn_mul[MAX_GROUP], tn_sh1[MAX_GROUP], tn_sh2[MAX_GROUP];
 };
 
 // ---- LDS-DMA (global_load_lds_dwordx4) helpers, inline asm: hipcc neither waits for

@@ -56,6 +56,12 @@ __device__ __attribute__((aligned(16))) float g_zero_chunk_h2[4] = {0.f, 0.f, 0.
 // have no output (rows past M, channel groups past the slice)
 __device__ __attribute__((aligned(16))) float g_dw_dump_h2[4 * THREADS];
 
+#ifdef EPOS_GEMM_TRACE      // tools/gemm_h2_trace.py: 100 MHz stamps per workgroup
+__device__ uint64_t* g_h2_trace = nullptr;
+#define H2_STAMP(i) do { if (g_h2_trace && t == 0) g_h2_trace[8 * static_cast<uint64_t>(blockIdx.x) + (i)] = wall_clock64(); } while (0)
+#else
+#define H2_STAMP(i) do { } while (0)
+#endif
 constexpr int RING_DEVICES = 16;
 constexpr int H2_BM = 128, H2_BN = 128, H2_BK = 16;
 constexpr int H2_W_BYTES = H2_BK * H2_BN * 4;       // 8192: 4 col blocks x 2 pieces x 1 KB
@@ -363,8 +369,9 @@ __device__ __forceinline__ void dw_produce_h2(const DwPhaseH2& d, float* smem, u
 template <bool HAS_RES>
 __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
                                                 const f32x16* corr, const float* cn,
-                                                float inv_a, const EposPointwiseArgs& p,
-                                                int m0w, int n0w, int lane, int salt) {
+                                                const float* bias4, float inv_a,
+                                                const EposPointwiseArgs& p, int m0w, int n0w,
+                                                int lane, int salt) {
   const int l31 = lane & 31, h = lane >> 5;
   const int M = p.M, N = p.N;
   constexpr int EPR = H2_EP_ROW;
@@ -385,8 +392,13 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int nb = n0w + j * 32 + l31;
-    const float bias = p.bias ? p.bias[nb < N ? nb : N - 1] : 0.f;
+    float bias;
+    if (bias4) {
+      bias = bias4[j];
+    } else {             // residual variants: loaded here, behind the residual rows (VGPRs)
+      const int nb = n0w + j * 32 + l31;
+      bias = p.bias ? p.bias[nb < N ? nb : N - 1] : 0.f;
+    }
     const float c = cn[j];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -429,6 +441,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
 
   (void)ga_;
   (void)dw_;
+  H2_STAMP(0);
   const GroupedArgs* __restrict__ gp =
       (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   int bid;
@@ -465,8 +478,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   // tiles (all row tiles of a band before the next band), as in the split kernel
   int tile_m, tile_n;
   if (DW || tiles_n <= 8) {       // DW: the siblings of a row tile must be neighbours
-    tile_n = bid % tiles_n;
-    tile_m = bid / tiles_n;
+    const H2Div dv = {gp->tn_mul[pi], gp->tn_sh1[pi], gp->tn_sh2[pi]};
+    tile_m = static_cast<int>(h2_div(static_cast<unsigned>(bid), dv));
+    tile_n = bid - tile_m * tiles_n;
   } else {
     const int tiles_m = (M + H2_BM - 1) / H2_BM;
     const int per_band = tiles_m * 8;
@@ -482,9 +496,37 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   const int cblocks = CONV ? gp->conv_cin[pi] / H2_BK : 1;   // channel blocks per tap
   const int crate = CONV ? gp->conv_rate[pi] : 1;
 
-  float sa_v, inv_a;
-  a_scale(p, lane, sa_v, inv_a);
-  const float sa = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sa_v)));
+  // The scale of A comes from a global load (the absmax slot) + a wave reduction: ~2 us of
+  // latency that the first LDS-DMA stages can hide -- so it is computed AFTER the prologue's
+  // DMA issue (below), except in the fused form, whose producer phase needs it first.
+  // (Only in the variants with registers to spare: the residual ones sit at 256 VGPRs.)
+  constexpr bool LATE_SCALE = !DW && !HAS_RES;
+  constexpr bool EARLY_EPI = !HAS_RES;
+  float sa_v = 0.f, inv_a = 0.f, sa = 0.f;
+  unsigned am_raw = 0, am_raw2 = 0;
+  if constexpr (LATE_SCALE) {
+    h2_scale_load(p.a_amax, p.a_amax2, lane, am_raw, am_raw2);
+  } else {
+    a_scale(p, lane, sa_v, inv_a);
+    sa = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sa_v)));
+  }
+  // The epilogue's per-column operands (inverse weight scales, bias) are requested here
+  // too -- ahead of the LDS-DMA pieces, so that they retire first and their latency does
+  // not stand between the K loop and the stores (8 VGPRs).
+  float cn[4], bias4[4];
+  if constexpr (EARLY_EPI) {
+    const float* cscale = reinterpret_cast<const float*>(
+        static_cast<const char*>(p.Wh) + static_cast<int64_t>(gp->tiles_n[pi]) *
+                                             ((K + H2_BK - 1) / H2_BK) * H2_W_BYTES);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + j * 32 + l31;
+      cn[j] = cscale[nb];                                 // padded to tiles_n * 128
+      // unconditional load (no bias: a zero word), so that nothing waits for it here
+      const float* bsrc = p.bias ? p.bias + (nb < N ? nb : N - 1) : g_zero_chunk_h2;
+      bias4[j] = *bsrc;
+    }
+  }
 
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
@@ -583,8 +625,10 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
       const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
       row = (static_cast<int64_t>(b) * p.Hi + yo * p.sub) * p.Wi + xo * p.sub;
     }
-    asrc[i] = p.A + row * p.lda + c * 4;
-    avoff[i] = static_cast<unsigned>((row * p.lda + c * 4) * 4);   // bytes from p.A
+    // 32-bit element offset (h2_eligible: every row read lies within 4 GB of p.A)
+    const unsigned eoff = static_cast<unsigned>(row) * static_cast<unsigned>(p.lda) + c * 4;
+    asrc[i] = p.A + eoff;
+    avoff[i] = eoff * 4u;                                            // bytes from p.A
     achunk[i] = c * 4;
     a_dst[i] = lds0 + H2_W_BYTES + (wave_u * 2 + i) * 1024;
   }
@@ -683,11 +727,17 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   if (nks > 1) issue(1, 1);
   if (nks > 2) issue(2, 2);
   if (nks > 3) issue(3, 3);
+  H2_STAMP(1);
+  if constexpr (LATE_SCALE) {
+    h2_scale_finish(am_raw, am_raw2, p.a_gain, p.a_bias, sa_v, inv_a);
+    sa = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sa_v)));
+  }
   if (nks > 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if (nks > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (nks > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  H2_STAMP(2);
   u32x4 ah, am;
   if constexpr (PRESPLIT) {
     read_a_ps(0, ah, am);
@@ -838,6 +888,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{}, std::integral_constant<bool, PRESPLIT>{});
   else k_loop(std::integral_constant<int, 4>{}, std::integral_constant<bool, PRESPLIT>{});
 
+  H2_STAMP(3);
 #ifdef EPOS_SEPCONV_TRACE
   if constexpr (DW) {
     const DwPhaseH2* dq = reinterpret_cast<const DwPhaseH2*>(
@@ -849,24 +900,36 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
 #ifdef EPOS_H2_ABL_NOEPI            // ablation (tools/power_components_h2.py): no epilogue
   if (p.ldr != 0x7fffffff) return;  // (always taken; the compiler cannot know)
 #endif
-  const float* cscale = reinterpret_cast<const float*>(
-      static_cast<const char*>(p.Wh) + static_cast<int64_t>(tiles_n) * nks * H2_W_BYTES);
-  float cn[4];
+  if constexpr (!EARLY_EPI) {
+    const float* cscale = reinterpret_cast<const float*>(
+        static_cast<const char*>(p.Wh) + static_cast<int64_t>(tiles_n) * nks * H2_W_BYTES);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) cn[j] = cscale[n0 + j * 32 + l31];   // padded to tiles_n*128
+    for (int j = 0; j < 4; ++j) cn[j] = cscale[n0 + j * 32 + l31];   // padded to tiles_n*128
+  }
   if (vec_epilogue_ok(p, HAS_RES)) {
     __syncthreads();
     float* ws = smem + wave * 32 * H2_EP_ROW;
-    vec_epilogue_h2<HAS_RES>(ws, acc, corr, cn, inv_a, p, m0 + wave * 32, n0, lane,
-                             blockIdx.x * 4 + wave);
+    vec_epilogue_h2<HAS_RES>(ws, acc, corr, cn, EARLY_EPI ? bias4 : nullptr, inv_a, p,
+                             m0 + wave * 32, n0, lane, blockIdx.x * 4 + wave);
+#ifdef EPOS_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores acknowledged
+    H2_STAMP(4);
+#endif
     return;
+  }
+  if constexpr (!EARLY_EPI) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + j * 32 + l31;
+      bias4[j] = p.bias ? p.bias[nb < N ? nb : N - 1] : 0.f;
+    }
   }
   const bool relu = p.relu != 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + j * 32 + l31;
     const int nc = n < N ? n : N - 1;
-    const float bias = p.bias ? p.bias[nc] : 0.f;
+    const float bias = bias4[j];
     const int mb = m0 + wave * 32 + 4 * h;
     float rv[16];
     if (HAS_RES) {
@@ -959,6 +1022,17 @@ int launch_absmax(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsig
 // a ring of 256 slots, taken round robin; memset + reduction + GEMM are ordered on the
 // caller's stream. A slot is reused after 256 further such calls -- plans that overlap
 // streams or capture graphs pass their own slots.
+// n / tiles_n[i] by multiply-shift for the kernels' tile mapping (Granlund-Montgomery, any
+// 32-bit n)
+void set_tn_div(GroupedArgs& g, int i) {
+  const unsigned d = static_cast<unsigned>(g.tiles_n[i] > 0 ? g.tiles_n[i] : 1);
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  g.tn_mul[i] = static_cast<unsigned>(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  g.tn_sh1[i] = l > 0 ? 1 : 0;
+  g.tn_sh2[i] = l > 0 ? l - 1 : 0;
+}
+
 constexpr int RING_SLOTS = 256;
 unsigned* ring_slot() {
   // one ring per device, created under a lock (calls may come from several host threads
@@ -1043,6 +1117,7 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
     }
     g.tile_start[i] = total;
     g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, H2_BN));
+    set_tn_div(g, i);
     g.npad[i] = g.tiles_n[i] * H2_BN;
     g.conv_cin[i] = conv_cin ? conv_cin[i] : 0;
     g.conv_rate[i] = conv_rate ? conv_rate[i] : 1;
@@ -1143,6 +1218,7 @@ int launch_sepconv_h2(const EposSepConvArgs* a, hipStream_t s) {
   g.p[0] = pw;
   g.tile_start[0] = 0;
   g.tiles_n[0] = static_cast<int>(ceil_div(pw.N, H2_BN));
+  set_tn_div(g, 0);
   g.npad[0] = g.tiles_n[0] * H2_BN;
   g.conv_rate[0] = 1;
   const int total = static_cast<int>(ceil_div(pw.M, H2_BM)) * g.tiles_n[0];
@@ -1179,6 +1255,13 @@ int launch_sepconv_h2(const EposSepConvArgs* a, hipStream_t s) {
 }
 
 }  // namespace epos
+
+#ifdef EPOS_GEMM_TRACE
+extern "C" int epos_debug_set_gemm_trace(uint64_t* buf) {
+  return epos::check_hip(hipMemcpyToSymbol(HIP_SYMBOL(epos::g_h2_trace), &buf, sizeof(buf)),
+                         "epos_debug_set_gemm_trace");
+}
+#endif
 
 extern "C" int epos_separable_conv_fused_state(void* stream) {
   return epos::xcd_mapping_state(static_cast<hipStream_t>(stream));

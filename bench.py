@@ -25,6 +25,7 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                   on this host on a bounded sample (N=1, rank 0 only).
 """
 import argparse
+import math
 import ctypes
 import json
 import os
@@ -414,7 +415,11 @@ def main():
            for j in range(depth)]
   pipe = pipes[0]
   # Synthetic frames, resident in HBM before the timed region.
-  n_pool = 4
+  # a pool size co-prime with the pipeline depth, so that a plan does not see the same frame
+  # at every step (plan j takes step i = j, j + depth, ...: frames i % n_pool)
+  n_pool = 5
+  while math.gcd(n_pool, depth) != 1:
+    n_pool += 1
   pool = []
   for j in range(n_pool):
     idx = [rank * 100000 + j * B + b for b in range(B)]
@@ -607,18 +612,17 @@ def main():
       else:
         roof['traffic_source'] = 'live measurement unavailable (%s); %s' % (
             how, roof['traffic_source'])
-    # The HBM view north_star names: images/s x algorithmic bytes per image against
-    # the 8 TB/s spec (3.30 GB per 640x480 image at 21 objects with
-    # fused separable convs, dense heads written once; 3.15 GB/image at batch 8).
-    if (args.model_variant == 'xception_65' and (args.height, args.width) == (480, 640)
-        and args.num_objs == 21 and args.num_frags == 64 and not args.sparse_heads):
-      gb = 3.30 if B == 1 else 3.15 if B >= 8 else 3.30 - 0.15 * (B - 1) / 7.0
-      roof['hbm_view'] = {
-          'bound': 'hbm', 'algorithmic_gb_per_image': round(gb, 3),
-          'achieved': round(value / world * gb, 1), 'peak': 8000.0, 'unit': 'GB/s',
-          'frac': round(value / world * gb / 8000.0, 4),
-          'note': 'whole network, per GPU: the step is bound by the matrix pipe (the '
-                  'GEMMs are 99 % of the flops at ~150 flop/B), not by HBM'}
+    # The HBM view north_star names: images/s x algorithmic bytes per image against the
+    # 8 TB/s spec. Bytes per image from the plan itself under the fusion-group rule of
+    # SURVEY.md App. A (EposNet.algorithmic_bytes: C2 3.32 GB -- the survey's hand count is
+    # 3.30 --, 3.17 at batch 8, C4 4.40, C5 3.64 at batch 8), for every configuration.
+    gb = pipe.net.algorithmic_bytes(dense_heads=not args.sparse_heads) / B / 1e9
+    roof['hbm_view'] = {
+        'bound': 'hbm', 'algorithmic_gb_per_image': round(gb, 3),
+        'achieved': round(value / world * gb, 1), 'peak': 8000.0, 'unit': 'GB/s',
+        'frac': round(value / world * gb / 8000.0, 4),
+        'note': 'whole network, per GPU: the step is bound by the matrix pipe (the '
+                'GEMMs are 99 % of the flops at ~150 flop/B), not by HBM'}
     if core_mhz:
       # sampled in extra steps after the timed region; peak stays the 2.4 GHz figure
       roof['core_clock_mhz_under_load'] = round(core_mhz, 0)

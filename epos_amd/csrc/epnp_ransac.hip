@@ -601,6 +601,22 @@ __device__ __forceinline__ bool ep_is_inlier(const double* P, const EpCam& cam,
   return err <= t2;
 }
 
+__device__ __forceinline__ double ep_pow5_rn(double w) {        // = pow5_rn of the C definition
+  const double h2 = w * w, l2 = fma(w, w, -h2);
+  const double h4 = h2 * h2;
+  const double l4 = fma(h2, h2, -h4) + 2.0 * (h2 * l2);
+  const double h5 = h4 * w;
+  const double l5 = fma(h4, w, -h5) + l4 * w;
+  return h5 + l5;
+}
+// The image point as the EPnP SOLVER sees it (us_of of the C definition): solvePnP's
+// undistortPoints writes (float)((u - cx) * (1 / fx)), epnp::init_points maps it back.
+__device__ __forceinline__ double ep_us_of(double u_f32, double c, double f) {
+  const double inv = 1.0 / f;
+  const float xn = static_cast<float>((u_f32 - c) * inv);
+  return static_cast<double>(xn) * f + c;
+}
+
 __device__ __forceinline__ int ep_update_niters(double p, double ep, int max_iters) {
   if (p < 0.0) p = 0.0;
   if (p > 1.0) p = 1.0;
@@ -609,13 +625,11 @@ __device__ __forceinline__ int ep_update_niters(double p, double ep, int max_ite
   double num = 1.0 - p;
   if (num < DBL_MIN) num = DBL_MIN;
   const double w = 1.0 - ep;
-  // OpenCV's RANSACUpdateNumIters takes pow(1 - ep, modelPoints) from libm; the fifth power
-  // is written out here (and in the C oracle) because a device pow() and a host pow() need not
-  // agree in the last bit, which would break the kernel == oracle identity the tests hold.
-  // The two forms can differ by an ulp of w^5; through log / cvRound that changes the
-  // iteration cap only when num / denom falls within ~1e-15 of a half-integer -- a known,
-  // documented deviation from cv2 (not checkable here: cv2 is not installable).
-  double denom = 1.0 - (w * w) * (w * w) * w;
+  // OpenCV's RANSACUpdateNumIters takes pow(1 - ep, modelPoints) from libm. A device pow()
+  // and a host pow() need not agree in the last bit, so the fifth power is formed here (and
+  // in the C oracle) as what a CORRECTLY ROUNDED pow returns: double-double products by fma,
+  // one final addition (round 4; the four-rounding product used before could be an ulp off).
+  double denom = 1.0 - ep_pow5_rn(w);
   if (denom < DBL_MIN) return 0;
   num = log(num);
   denom = log(denom);
@@ -697,7 +711,8 @@ __global__ __launch_bounds__(256) void cvr_hypotheses(
   for (int i = 0; i < EP_SET; ++i) {
     const int64_t p = set[i];
     X[i][0] = f32r(xyz[3 * p]); X[i][1] = f32r(xyz[3 * p + 1]); X[i][2] = f32r(xyz[3 * p + 2]);
-    x[i][0] = f32r(xy[2 * p]); x[i][1] = f32r(xy[2 * p + 1]);
+    x[i][0] = ep_us_of(f32r(xy[2 * p]), cam.uc, cam.fu);
+    x[i][1] = ep_us_of(f32r(xy[2 * p + 1]), cam.vc, cam.fv);
   }
   // sums over the 5 correspondences: plain left to right
   EpFrame f;
@@ -869,7 +884,8 @@ __global__ __launch_bounds__(256) void cvr_select_fit(
   auto load = [&](int64_t i, double* X, double* x2) {
     const int64_t p = idx[i];
     X[0] = f32r(xyz[3 * p]); X[1] = f32r(xyz[3 * p + 1]); X[2] = f32r(xyz[3 * p + 2]);
-    x2[0] = f32r(xy[2 * p]); x2[1] = f32r(xy[2 * p + 1]);
+    x2[0] = ep_us_of(f32r(xy[2 * p]), cam.uc, cam.fu);
+    x2[1] = ep_us_of(f32r(xy[2 * p + 1]), cam.vc, cam.fv);
   };
   block_sums<3>([&](int64_t i, double* o) { double x2[2]; load(i, o, x2); }, m, t, s_red, s3);
 #pragma unroll

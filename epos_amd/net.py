@@ -84,6 +84,10 @@ class EposNet(object):
     self.op_flops = {}
     self.op_kind = {}        # 'gemm' | 'dw' | 'im2col' | 'other'
     self.op_bytes = {}       # GEMM launches: algorithmic bytes (A + W + out + residual)
+    # fusion-group byte model (algorithmic_bytes): per GEMM (A bytes, the rest, id of the A
+    # buffer); per depthwise output buffer the bytes its launch READS (input + weights)
+    self.op_io = {}
+    self._dw_reads = {}
     self._graph = None
     self._graph_sparse = None
     self._graph_alt, self.alt_skip = None, None   # measurement aid: see capture_alt()
@@ -360,6 +364,7 @@ class EposNet(object):
     # fp32 activations in and out, weights once (4 B each: what the layer IS; the
     # split kernel streams 6 B per weight), residual once
     nbytes = 4 * (m * k + k * n + m * n + (m * n if res is not None else 0))
+    self.op_io[name] = (4 * m * k, nbytes - 4 * m * k, id(a))
     if group is not None:
       group.append((name, args, 2 * m * n * k, nbytes))
       return
@@ -452,6 +457,7 @@ class EposNet(object):
       args.gain, args.bias0 = yb[2], yb[3]
       self._dw_h2[id(y)] = args
     lib = self.lib
+    self._dw_reads[id(y)] = 4 * (self.B * hi * wi * c + 10 * c)
     if defer:
       return y, ho, wo, (name, args, 2 * 9 * self.B * ho * wo * c)
 
@@ -504,6 +510,8 @@ class EposNet(object):
         _lib.check(lib.epos_conv3x3_f32(ctypes.byref(cargs), stream), name)
       self._add(name, run_conv, 2 * self.B * ho * wo * cout * k, 'gemm',
                 4 * (self.B * hi * wi * cin + k * cout + self.B * ho * wo * cout))
+      self.op_io[name] = (4 * self.B * hi * wi * cin,
+                          4 * (k * cout + self.B * ho * wo * cout), id(x))
       self._set_expr(y, 'relu(L:%s)' % name)
       return y, ho, wo, cout
     ldcol = (k + 3) // 4 * 4
@@ -550,6 +558,7 @@ class EposNet(object):
           _lib.check(lib.epos_subsample_f32(_ptr(x), cin, _ptr(y), depth, B, hi,
                                             wi, cin, stride, stream), 'subsample')
         self._add(scope + '/shortcut_subsample', run_sub)
+        self._glue_bytes = getattr(self, '_glue_bytes', 0) + 8 * B * ho * wo * depth
         self._set_expr(shortcut, 'subsample(%s,%d)' % (self._expr_of(x, 0, cin), stride))
         if self._bound_of(x) is not None:
           self._set_bound(shortcut, *self._bound_of(x))
@@ -578,6 +587,7 @@ class EposNet(object):
         _lib.check(lib.epos_add_relu_f32(_ptr(a), _ptr(b), _ptr(y),
                                          m_out * depth, stream), 'add_relu')
       self._add(scope + '/add_relu', run_add)
+      self._glue_bytes = getattr(self, '_glue_bytes', 0) + 12 * m_out * depth
       self._set_expr(out, 'relu(add(%s))' % ','.join(sorted(
           [self._expr_of(conv3), self._expr_of(shortcut)])))
       oslot = self._new_slot()
@@ -608,6 +618,7 @@ class EposNet(object):
       _lib.check(lib.epos_maxpool3x3_s2_f32(_ptr(x), c, _ptr(y), c, B, h, w, c,
                                             stream), 'maxpool')
     self._add(net + '/pool1', run_pool)                      # :190
+    self._glue_bytes = getattr(self, '_glue_bytes', 0) + 4 * B * (h * w + ph * pw) * c
     self._set_expr(pooled, 'maxpool(%s,3,2,SAME)' % self._expr_of(x, 0, c))
     if self._bound_of(x) is not None:          # a max-pool output is bounded by its input
       self._set_bound(pooled, *self._bound_of(x))
@@ -895,6 +906,34 @@ class EposNet(object):
                            'shape': [B, dh, dw_, O, F]},
         W.PRED_FRAG_LOC: {'expr': 'reshape(%s,%s)' % (el, [O, F, 3]),
                           'shape': [B, dh, dw_, O, F, 3]}}
+
+  def algorithmic_bytes(self, dense_heads=True):
+    """HBM bytes of ONE pass of the plan under the fusion-group rule of SURVEY.md App. A
+    (fp32): every separable conv is one group -- the depthwise INPUT is read once, the
+    pointwise output written once, weights once, the intermediate never leaves the chip --
+    a GEMM reads A and its residual once and writes its output once, the stem's im2col
+    matrix does not exist (the input image is read once), and the element-wise ops that
+    belong in a producer's epilogue (global mean, decoder resize, softmax, argmax) move
+    nothing of their own: the heads are written once. ResNet's max-pool / subsample /
+    stand-alone add read and write their tensors once. Reproduces the survey's figures
+    (C2: 3.32 vs 3.30 GB, batch 8: 3.17 vs 3.15, C4: 4.40 vs 4.38; C5: 3.64 GB per image at batch 8). What the launches of
+    this build actually move is roofline.traffic in bench.py."""
+    total = 0
+    for name, (a_bytes, rest, a_id) in self.op_io.items():
+      if name.endswith('/im2col'):
+        continue
+      if a_id in self._dw_reads:            # A = a depthwise output: the group reads its input
+        total += self._dw_reads[a_id] + rest
+      elif name.endswith('conv1_1') and self.op_kind.get(name + '/im2col') == 'im2col':
+        total += 4 * self.B * self.H * self.W * 3 + rest     # the image, not the im2col matrix
+      else:
+        total += a_bytes + rest
+    B, h, w = self.B, self.out_h, self.out_w
+    O, F = self.num_objs, self.num_frags
+    total += getattr(self, '_glue_bytes', 0)
+    if not dense_heads:
+      total -= 4 * B * h * w * (O * F + 3 * O * F)
+    return total
 
   # ----------------------------------------------------------- running ---
   def _stream(self):

@@ -443,6 +443,15 @@ def main(argv=None):
   if args.fitting_method not in ('progressive_x', 'opencv_ransac'):
     raise ValueError('Unknown pose fitting method ({}).'.format(
         args.fitting_method))                                   # infer.py:530-532
+  if args.fitting_method == 'opencv_ransac':
+    # not bit-for-bit cv2 (which cannot be installed or checked here): say so at run time
+    print('NOTE --fitting_method=opencv_ransac: the algorithm cv2.solvePnPRansac(EPNP) '
+          'publishes (cv::RNG 5-point sets, EPnP, float32 inlier rule, the shrinking 0.99 '
+          'bound with a once-rounded w^5, the float32 round trip of the normalised image '
+          'points, EPnP over the inliers) runs in HIP, but its poses are NOT guaranteed to '
+          'equal cv2\'s bit for bit: the factorisations are this build\'s own and the '
+          'R -> rvec -> R round trip through cv::Rodrigues in front of the inlier test is '
+          'not made (DESIGN.md (f2)).')
   if args.vis and args.vis_gt_frag_fields:
     raise NotImplementedError(
         '--vis_gt_frag_fields needs the ground-truth fragment fields of the training '

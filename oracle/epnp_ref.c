@@ -19,8 +19,11 @@
  *     reprojection error, evaluated in float32 from the float32 projection, is <= (float)
  *     (reprojectionError^2) (no cheirality test); the model with strictly more inliers than
  *     the best so far (and more than 4) becomes the best and the iteration cap shrinks to
- *     round(log(1 - conf) / log(1 - w^5)), w = its inlier ratio; afterwards EPnP is run once
- *     more on ALL inliers of the best model and that pose is returned.
+ *     round(log(1 - conf) / log(1 - w^5)), w = its inlier ratio, w^5 rounded once as
+ *     std::pow returns it; afterwards EPnP is run once more on ALL inliers of the best model
+ *     and that pose is returned. The SOLVER (not the inlier test) sees every image point
+ *     after solvePnP's undistortPoints / init_points round trip: (float)((u - cx) / fx)
+ *     mapped back by x * fu + uc (round 4; before, the solver saw the float32 pixels).
  *   EPnP: 4 control points (centroid + principal directions scaled by sqrt(eigenvalue / n);
  *     here by decreasing eigenvalue and signed so that the largest component is positive),
  *     barycentric coordinates, the 12 x 12 matrix M^T M, its four eigenvectors of smallest
@@ -35,7 +38,11 @@
  * 3 x 3 SVD) instead of cv::SVD / LAPACK; sums over correspondences that are linear in the
  * points (camera-frame centroid, the 3 x 3 cross-covariance) are formed from the centroid and
  * covariance of the object points instead of per point; the rvec <-> R round trip through
- * Rodrigues is skipped; sums over the inliers of the final fit use the canonical order of
+ * Rodrigues is skipped (cv::Rodrigues orthonormalises by cv::SVD and goes through acos /
+ * sin / cos of the C library: not restatable bit for bit, and a device libm and a host libm
+ * need not agree -- so the inlier test here sees EPnP's R itself where OpenCV's sees
+ * Rodrigues(Rodrigues(R)), equal to ~1e-16; scripts that use this method are told so at
+ * run time); sums over the inliers of the final fit use the canonical order of
  * pnp_ref.c (256 strided partials, butterfly, (g0 + g1) + (g2 + g3)). Only + - * / sqrt are
  * used, except log() in the iteration bound; build with -ffp-contract=off.
  */
@@ -255,7 +262,11 @@ static void canon_sum(TermFn fn, const void* ctx, const int32_t* idx, int64_t m,
 
 /* ----------------------------------------------------------------------- EPnP -- */
 typedef struct {
-  const double* xy;       /* [n][2] pixels */
+  const double* xy;       /* [n][2] pixels (float32 values): what the inlier test compares */
+  const double* us;       /* [n][2] what the EPnP SOLVER sees: solvePnP runs undistortPoints
+                           * (float32 output: (float)((u - cx) * (1 / fx))) and epnp::init_points
+                           * maps that back with x * fu + uc -- a float32 round trip of the
+                           * NORMALISED coordinate */
   const double* xyz;      /* [n][3] */
   double fu, fv, uc, vc;
   double c0[3];           /* centroid of the object points = control point 0 */
@@ -285,7 +296,7 @@ static void term_mtm(const void* c, int32_t p, double* o) {
   const EpnpCtx* e = (const EpnpCtx*)c;
   double a[4];
   alphas_of(e, p, a);
-  const double du = e->uc - e->xy[2 * p], dv = e->vc - e->xy[2 * p + 1];
+  const double du = e->uc - e->us[2 * p], dv = e->vc - e->us[2 * p + 1];
   const double dd = du * du + dv * dv;
   int v = 0;
   for (int i = 0; i < 4; ++i)
@@ -305,7 +316,7 @@ static void term_rep(const void* c, int32_t p, double* o) {
     const double Yc = P[3] * X[0] + P[4] * X[1] + P[5] * X[2] + P[10];
     const double iz = 1.0 / (P[6] * X[0] + P[7] * X[1] + P[8] * X[2] + P[11]);
     const double ue = e->uc + e->fu * Xc * iz, ve = e->vc + e->fv * Yc * iz;
-    const double du = e->xy[2 * p] - ue, dv = e->xy[2 * p + 1] - ve;
+    const double du = e->us[2 * p] - ue, dv = e->us[2 * p + 1] - ve;
     o[q] = sqrt(du * du + dv * dv);
   }
 }
@@ -515,6 +526,26 @@ static int is_inlier(const double* pose, const EpnpCtx* e, int32_t p, float t2) 
   return err <= t2;
 }
 
+/* w^5 rounded ONCE (double-double products by fma, then one addition): what a correctly
+ * rounded pow(w, 5) returns -- OpenCV's RANSACUpdateNumIters calls std::pow(1 - ep,
+ * modelPoints), and glibc's pow is correctly rounded in all but astronomically rare cases.
+ * (w * w) * (w * w) * w, four roundings, can be an ulp off. 0 <= w <= 1. */
+static double pow5_rn(double w) {
+  const double h2 = w * w, l2 = fma(w, w, -h2);                 /* w^2 = h2 + l2 exactly */
+  const double h4 = h2 * h2;
+  const double l4 = fma(h2, h2, -h4) + 2.0 * (h2 * l2);         /* w^4 ~ h4 + l4 */
+  const double h5 = h4 * w;
+  const double l5 = fma(h4, w, -h5) + l4 * w;                   /* w^5 ~ h5 + l5 */
+  return h5 + l5;
+}
+
+/* the float32 round trip of the normalised image coordinate (see EpnpCtx.us) */
+static double us_of(double u_f32, double c, double f) {
+  const double inv = 1.0 / f;
+  const float xn = (float)((u_f32 - c) * inv);
+  return (double)xn * f + c;
+}
+
 static int update_niters(double p, double ep, int max_iters) {
   if (p < 0.0) p = 0.0;
   if (p > 1.0) p = 1.0;
@@ -523,7 +554,7 @@ static int update_niters(double p, double ep, int max_iters) {
   double num = 1.0 - p;
   if (num < DBL_MIN) num = DBL_MIN;
   const double w = 1.0 - ep;
-  double denom = 1.0 - (w * w) * (w * w) * w;
+  double denom = 1.0 - pow5_rn(w);
   if (denom < DBL_MIN) return 0;
   num = log(num);
   denom = log(denom);
@@ -543,11 +574,16 @@ int epnp_ref_solve_pnp_ransac(const double* xy_in, const double* xyz_in, int64_t
   double* xy = (double*)malloc((size_t)n * 2 * sizeof(double));
   double* xyz = (double*)malloc((size_t)n * 3 * sizeof(double));
   int32_t* idx = (int32_t*)malloc((size_t)n * sizeof(int32_t));
+  double* us = (double*)malloc((size_t)n * 2 * sizeof(double));
   for (int64_t i = 0; i < 2 * n; ++i) xy[i] = (double)(float)xy_in[i];
   for (int64_t i = 0; i < 3 * n; ++i) xyz[i] = (double)(float)xyz_in[i];
+  for (int64_t i = 0; i < n; ++i) {
+    us[2 * i] = us_of(xy[2 * i], K[2], K[0]);
+    us[2 * i + 1] = us_of(xy[2 * i + 1], K[5], K[4]);
+  }
   EpnpCtx e;
   memset(&e, 0, sizeof e);
-  e.xy = xy; e.xyz = xyz; e.fu = K[0]; e.fv = K[4]; e.uc = K[2]; e.vc = K[5];
+  e.xy = xy; e.us = us; e.xyz = xyz; e.fu = K[0]; e.fv = K[4]; e.uc = K[2]; e.vc = K[5];
   const float t2 = (float)(reproj_err * reproj_err);
   uint64_t rng = 0xffffffffffffffffull;
   int niters = max_iters, best_count = 0, best_it = -1, it = 0;
@@ -587,16 +623,20 @@ int epnp_ref_solve_pnp_ransac(const double* xy_in, const double* xyz_in, int64_t
   }
   if (!ok) for (int64_t p = 0; p < n; ++p) inlier_mask[p] = 0;
   if (info) { info[0] = best_it; info[1] = best_count; info[2] = niters; info[3] = it; }
-  free(xy); free(xyz); free(idx);
+  free(xy); free(us); free(xyz); free(idx);
   return ok;
 }
+
+/* test hooks */
+double epnp_ref_pow5(double w) { return pow5_rn(w); }
+double epnp_ref_us_of(double u_f32, double c, double f) { return us_of(u_f32, c, f); }
 
 /* EPnP alone over all n correspondences (tests): order = 1 or 256 */
 int epnp_ref_epnp(const double* xy, const double* xyz, int64_t n, const double* K, int order,
                   double* pose_out) {
   EpnpCtx e;
   memset(&e, 0, sizeof e);
-  e.xy = xy; e.xyz = xyz; e.fu = K[0]; e.fv = K[4]; e.uc = K[2]; e.vc = K[5];
+  e.xy = xy; e.us = xy; e.xyz = xyz; e.fu = K[0]; e.fv = K[4]; e.uc = K[2]; e.vc = K[5];
   int32_t* idx = (int32_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int32_t));
   for (int64_t i = 0; i < n; ++i) idx[i] = (int32_t)i;
   const int r = n >= 4 ? epnp(&e, idx, n, order, pose_out) : 1;

@@ -22,6 +22,10 @@ def lib():
     _lib.epnp_ref_solve_pnp_ransac.restype = ctypes.c_int
     _lib.epnp_ref_epnp.restype = ctypes.c_int
     _lib.epnp_ref_rng_next.restype = ctypes.c_uint32
+    _lib.epnp_ref_pow5.restype = ctypes.c_double
+    _lib.epnp_ref_pow5.argtypes = [ctypes.c_double]
+    _lib.epnp_ref_us_of.restype = ctypes.c_double
+    _lib.epnp_ref_us_of.argtypes = [ctypes.c_double] * 3
   return _lib
 
 
@@ -75,3 +79,14 @@ def jacobi(A):
 def rng_sequence(count, state=0xffffffffffffffff):
   st = ctypes.c_uint64(state)
   return [lib().epnp_ref_rng_next(ctypes.byref(st)) for _ in range(count)]
+
+
+def pow5(w):
+  """w^5 rounded once (the oracle's statement of std::pow(w, 5))."""
+  return float(lib().epnp_ref_pow5(float(w)))
+
+
+def us_of(u_f32, c, f):
+  """The image coordinate as the EPnP solver sees it (float32 round trip of the normalised
+  coordinate)."""
+  return float(lib().epnp_ref_us_of(float(u_f32), float(c), float(f)))

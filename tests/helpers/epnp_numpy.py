@@ -1,6 +1,8 @@
 """Independent numpy statement of EPnP (Lepetit, Moreno-Noguer & Fua, IJCV 2009) and of the
 RANSAC loop cv2.solvePnPRansac wraps around it, used to check oracle/epnp_ref.c: LAPACK
 factorisations (eigh / lstsq / svd), per-point sums -- none of the oracle's shortcuts."""
+import fractions
+
 import numpy as np
 
 PAIRS = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
@@ -113,6 +115,17 @@ class CvRng(object):
     return self.state & 0xffffffff
 
 
+def solver_image_points(xy32, K):
+  """What the EPnP solver sees of float32 image points: solvePnP's undistortPoints writes the
+  NORMALISED coordinate as float32, epnp::init_points maps it back with x * fu + uc (double).
+  The inlier test keeps the float32 pixels."""
+  xy32 = np.asarray(xy32, np.float32)
+  fu, fv, uc, vc = K[0][0], K[1][1], K[0][2], K[1][2]
+  xn = ((xy32[:, 0].astype(np.float64) - uc) * (1.0 / fu)).astype(np.float32)
+  yn = ((xy32[:, 1].astype(np.float64) - vc) * (1.0 / fv)).astype(np.float32)
+  return np.stack([xn.astype(np.float64) * fu + uc, yn.astype(np.float64) * fv + vc], 1)
+
+
 def inlier_mask_f32(R, t, xyz32, xy32, K, thr):
   """PnPRansacCallback::computeError + findInliers: float32 projection, float32 error."""
   fu, fv, uc, vc = K[0][0], K[1][1], K[0][2], K[1][2]
@@ -140,7 +153,7 @@ def ransac_trace(xyz, xy, K, solver, iters=400, thr=4.0, conf=0.99):
       c = rng.next() % n
       if c not in s:
         s.append(c)
-    R, t = solver(xyz32[s].astype(np.float64), xy32[s].astype(np.float64))
+    R, t = solver(xyz32[s].astype(np.float64), solver_image_points(xy32[s], K))
     if R is not None:
       m = inlier_mask_f32(R, t, xyz32, xy32, K, thr)
       c = int(m.sum())
@@ -148,7 +161,8 @@ def ransac_trace(xyz, xy, K, solver, iters=400, thr=4.0, conf=0.99):
         best, best_it, best_mask = c, it, m
         ep = min(max((n - c) / n, 0.0), 1.0)
         num = max(1 - min(max(conf, 0.0), 1.0), np.finfo(np.float64).tiny)
-        den = 1 - (1 - ep) ** 5
+        # std::pow(1 - ep, 5): the exactly computed fifth power, rounded once
+        den = 1 - float(fractions.Fraction(1 - ep) ** 5)
         if den < np.finfo(np.float64).tiny:
           niters = 0
         else:

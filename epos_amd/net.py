@@ -119,16 +119,17 @@ class EposNet(object):
     self._bounds = {}
     self.h2_layers, self.h2_refused = [], []
     # fp16-pair GEMM switches of the library (A/B runs): with either off no layer gets
-    # fp16-pair weights. EPOS_H2_PRESPLIT=1 (opt-in): the depthwise kernels write their
-    # outputs already split (fp16 pairs), so each activation is converted once instead of
-    # once per column tile of the GEMM and the GEMM loop carries no conversion. Bit-identical
-    # results; per launch the GEMM gains 12-17 % (tools/bench_gemm_h2_abl.py), but in the
-    # pipelined step the depthwise launches pay it back (+0.07 ms of depthwise slot time vs
-    # -0.02 ms of GEMM): 409.6 / 411.5 vs 409.3 images/s, same box (profiles/r03/
-    # presplit_ab.txt) -- measured neutral, kept off.
+    # fp16-pair weights. EPOS_H2_PRESPLIT (default 1 since round 4, 0 = off): the depthwise
+    # kernels write their outputs already split (fp16 pairs), so each activation is converted
+    # once instead of once per column tile of the GEMM and the GEMM loop carries no
+    # conversion. Bit-identical results. Per launch the GEMMs gain 7 % (34.9 vs 37.4 us on
+    # average over the plan, profiles/r04/presplit_ab.txt) while the depthwise launches pay
+    # most of it back inside the pipelined step (+0.055 ms of depthwise slot time vs -0.02 ms
+    # of GEMM and -0.05 ms of the rest): 417.5 / 419.8 vs 415.4 / 417.2 images/s, same box --
+    # a small but repeatable gain (round 3 measured it neutral and kept it off).
     self.use_h2 = (os.environ.get('EPOS_GEMM_H2', '1') != '0' and
                    os.environ.get('EPOS_GEMM_SPLIT', '1') != '0')
-    self.use_presplit = self.use_h2 and os.environ.get('EPOS_H2_PRESPLIT', '0') == '1'
+    self.use_presplit = self.use_h2 and os.environ.get('EPOS_H2_PRESPLIT', '1') == '1'
     self._dw_h2 = {}           # id(depthwise output) -> its (mutable) launch arguments
     self.presplit_layers = []
     # Structure trace: one record per parametrised layer and a canonical expression per

@@ -392,37 +392,70 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float bias;
-    if (bias4) {
-      bias = bias4[j];
-    } else {             // residual variants: loaded here, behind the residual rows (VGPRs)
-      const int nb = n0w + j * 32 + l31;
-      bias = p.bias ? p.bias[nb < N ? nb : N - 1] : 0.f;
-    }
+    // residual variants (bias4 == nullptr): the bias is added in the row phase below -- a
+    // bias load issued here sits behind the sixteen residual rows in the in-order memory
+    // queue and made this step wait for all of them (3.1 instead of 1.0 us in the trace),
+    // and the registers to request it ahead of them are not there (256 VGPRs)
+    const float bias = bias4 ? bias4[j] : 0.f;
     const float c = cn[j];
+    // two rows at a time (v_pk_fma / v_pk_mul / v_pk_add: the same operations per element)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float sum = fmaf(corr[j][r], 0x1p-11f, acc[j][r]);
-      ws[((r & 3) + 8 * (r >> 2) + 4 * h) * EPR + j * 32 + l31] = sum * c * inv_a + bias;
+    for (int r = 0; r < 16; r += 2) {
+      const h2_f32x2 a2 = {acc[j][r], acc[j][r + 1]}, c2 = {corr[j][r], corr[j][r + 1]};
+      const h2_f32x2 k2 = {0x1p-11f, 0x1p-11f}, cc = {c, c}, ia = {inv_a, inv_a}, b2 = {bias, bias};
+      const h2_f32x2 sum = __builtin_elementwise_fma(c2, k2, a2);
+      h2_f32x2 sv = (sum * cc) * ia;
+      if (bias4) sv = sv + b2;
+      ws[((r & 3) + 8 * (r >> 2) + 4 * h) * EPR + j * 32 + l31] = sv[0];
+      ws[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * EPR + j * 32 + l31] = sv[1];
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef EPOS_GEMM_TRACE
+  if (g_h2_trace && threadIdx.x == 0) g_h2_trace[8 * static_cast<uint64_t>(blockIdx.x) + 6] = wall_clock64();
+#endif
   const bool relu = p.relu != 0;
   float amax = 0.f;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!bias4 && p.bias) {                    // same value, same order: (x + bias) + residual
+    const float* bsrc = p.bias + (n < N ? n : 0);     // padded to a multiple of 128 floats
+    bv = *reinterpret_cast<const float4*>(bsrc);
+  }
+  // Row phase. All sixteen staged rows are read first (the accumulators are dead: 64 VGPRs to
+  // spare), the ReLU test is hoisted out of the loop and the row address advances by one
+  // 64-bit add: the first version waited for every ds_read on the spot, tested `relu` and
+  // multiplied m * ldc per row -- 2.0 us of every launch (profiles/r04).
+  float4 v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    v[i] = *reinterpret_cast<const float4*>(ws + (r0 + i * RPI) * EPR + c4 * 4);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int row = r0 + i * RPI;
-    const int m = m0w + row;
-    float4 v = *reinterpret_cast<const float4*>(ws + row * EPR + c4 * 4);
+    if (!bias4) { v[i].x += bv.x; v[i].y += bv.y; v[i].z += bv.z; v[i].w += bv.w; }
     if (HAS_RES) {
-      v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
-    }
-    if (relu) v = relu4(v);
-    if (m < M && n < N) {
-      *reinterpret_cast<float4*>(p.C + static_cast<int64_t>(m) * p.ldc + n) = v;
-      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      v[i].x += rv[i].x; v[i].y += rv[i].y; v[i].z += rv[i].z; v[i].w += rv[i].w;
     }
   }
+  if (relu) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = relu4(v[i]);
+  }
+  float* crow = p.C + (static_cast<int64_t>(m0w + r0) * p.ldc + n);
+  const int64_t cstep = static_cast<int64_t>(RPI) * p.ldc;
+  const bool nok = n < N;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = m0w + r0 + i * RPI;
+    if (m < M && nok) {
+      *reinterpret_cast<float4*>(crow) = v[i];
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))),
+                   fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+    }
+    crow += cstep;
+  }
+#ifdef EPOS_GEMM_TRACE
+  if (g_h2_trace && threadIdx.x == 0) g_h2_trace[8 * static_cast<uint64_t>(blockIdx.x) + 7] = wall_clock64();
+#endif
   if (p.c_amax) amax_publish(p.c_amax, amax, lane, salt);
 }
 
@@ -901,6 +934,8 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   if (p.ldr != 0x7fffffff) return;  // (always taken; the compiler cannot know)
 #endif
   if constexpr (!EARLY_EPI) {
+    // (requesting these at the top of the last K step was tried: the residual variants sit
+    // at 256 VGPRs and spill)
     const float* cscale = reinterpret_cast<const float*>(
         static_cast<const char*>(p.Wh) + static_cast<int64_t>(tiles_n) * nks * H2_W_BYTES);
 #pragma unroll
@@ -908,6 +943,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   }
   if (vec_epilogue_ok(p, HAS_RES)) {
     __syncthreads();
+    H2_STAMP(5);
     float* ws = smem + wave * 32 * H2_EP_ROW;
     vec_epilogue_h2<HAS_RES>(ws, acc, corr, cn, EARLY_EPI ? bias4 : nullptr, inv_a, p,
                              m0 + wave * 32, n0, lane, blockIdx.x * 4 + wave);

@@ -61,4 +61,8 @@ for (m, n, k, res) in shapes:
   for i, name in enumerate(['set-up + prologue DMA issue', 'first stage landed (scale, barrier)', 'K loop', 'epilogue (to store ack)']):
     d = (t[:, i + 1] - t[:, i]) / 100.0
     print('  %-38s mean %6.2f  max %6.2f us' % (name, d.mean(), d.max()))
+  for a, b, name in [(3, 5, 'epilogue: operands + workgroup barrier'), (5, 6, 'epilogue: scale + bias -> LDS'),
+                     (6, 7, 'epilogue: LDS rows -> (residual, ReLU) -> stores issued'), (7, 4, 'epilogue: absmax publish + store ack')]:
+    d = (t[:, b] - t[:, a]) / 100.0
+    print('    %-52s mean %6.2f  max %6.2f us' % (name, d.mean(), d.max()))
   print('  workgroup lifetime                     mean %6.2f  max %6.2f us' % (((t[:, 4] - t[:, 0]) / 100).mean(), ((t[:, 4] - t[:, 0]) / 100).max()))

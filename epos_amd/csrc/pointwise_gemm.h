@@ -63,6 +63,11 @@ struct GroupedArgs {
   // fp16-pair kernel: n / tiles_n[i] by multiply-shift (set by launch_grouped_h2; a run-time
   // division costs ~25 instructions of every workgroup's set-up)
   unsigned tn_mul[MAX_GROUP], tn_sh1[MAX_GROUP], tn_sh2[MAX_GROUP];
+  // 16 bytes of zeros in device memory (source of the LDS-DMA pieces that lie outside the
+  // matrix); as a kernel argument it costs no extra scalar-load round trip, as a __device__
+  // variable its address comes through the GOT: two more dependent loads in every
+  // workgroup's set-up
+  const float* zero_chunk;
 };
 
 // ---- LDS-DMA (global_load_lds_dwordx4) helpers, inline asm: hipcc neither waits for

@@ -51,7 +51,6 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __attribute__((aligned(16))) float g_zero_chunk_h2[4] = {0.f, 0.f, 0.f, 0.f};
 // where the always-issued output stores of the fused depthwise producer go for lanes that
 // have no output (rows past M, channel groups past the slice)
 __device__ __attribute__((aligned(16))) float g_dw_dump_h2[4 * THREADS];
@@ -477,6 +476,27 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   H2_STAMP(0);
   const GroupedArgs* __restrict__ gp =
       (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  if constexpr (SINGLE) {
+    // One round trip for the kernel arguments: left to itself hipcc fetches them where they
+    // are first used -- six dependent scalar-load rounds (~0.3 us each, cold scalar cache)
+    // before the first LDS-DMA piece could be issued. Pinning the values here puts all the
+    // s_loads into this block, behind one wait.
+    const EposPointwiseArgs& q = gp->p[0];
+    uint64_t a0 = reinterpret_cast<uint64_t>(q.A), a1 = reinterpret_cast<uint64_t>(q.Wh),
+             a2 = reinterpret_cast<uint64_t>(q.C), a3 = reinterpret_cast<uint64_t>(q.R),
+             a4 = reinterpret_cast<uint64_t>(q.bias), a5 = reinterpret_cast<uint64_t>(q.a_amax),
+             a6 = reinterpret_cast<uint64_t>(q.a_amax2), a7 = reinterpret_cast<uint64_t>(q.c_amax),
+             a8 = reinterpret_cast<uint64_t>(gp->zero_chunk), l0 = static_cast<uint64_t>(q.lda),
+             l1 = static_cast<uint64_t>(q.ldc), l2 = static_cast<uint64_t>(q.ldr);
+    int i0 = q.M, i1 = q.N, i2 = q.K, i3 = q.relu, i4 = q.sub, i5 = gp->tiles_n[0],
+        i6 = gp->tile_start[MAX_GROUP];
+    unsigned u0 = gp->tn_mul[0], u1 = gp->tn_sh1[0], u2 = gp->tn_sh2[0];
+    float f0 = q.a_gain, f1 = q.a_bias;
+    asm volatile("" : : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7),
+                 "s"(a8), "s"(l0), "s"(l1), "s"(l2));
+    asm volatile("" : : "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5), "s"(i6), "s"(u0),
+                 "s"(u1), "s"(u2), "s"(f0), "s"(f1));
+  }
   int bid;
   if constexpr (DW) {
     // Fused separable conv: an XCD (blockIdx % 8) owns WHOLE row tiles, so that the
@@ -506,6 +526,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   }
   const EposPointwiseArgs p = gp->p[pi];
   const int tiles_n = gp->tiles_n[pi];
+  const float* zero_chunk = uniform_ptr(gp->zero_chunk);
   const int M = p.M, N = p.N, K = p.K;
   // tile order inside an XCD's range: column fastest; wide problems in bands of 8 column
   // tiles (all row tiles of a band before the next band), as in the split kernel
@@ -556,7 +577,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
       const int nb = n0 + j * 32 + l31;
       cn[j] = cscale[nb];                                 // padded to tiles_n * 128
       // unconditional load (no bias: a zero word), so that nothing waits for it here
-      const float* bsrc = p.bias ? p.bias + (nb < N ? nb : N - 1) : g_zero_chunk_h2;
+      const float* bsrc = p.bias ? p.bias + (nb < N ? nb : N - 1) : zero_chunk;
       bias4[j] = *bsrc;
     }
   }
@@ -684,7 +705,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
         const bool ok = static_cast<unsigned>(apy[PIECE] + dy) < static_cast<unsigned>(p.Hi) &&
                         static_cast<unsigned>(apx[PIECE] + dx) < static_cast<unsigned>(p.Wi);
         src = asrc[PIECE] + ((dy * p.Wi + dx) * p.lda + cb * H2_BK);
-        src = ok ? src : g_zero_chunk_h2;
+        src = ok ? src : zero_chunk;
       } else if constexpr (!TAIL) {
         // full K step of a 1x1 conv: scalar base + 32-bit lane offset
         const float* ab = abase + (kt * H2_BK - PIECE * 256);      // uniform
@@ -693,7 +714,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
         return;
       } else {
         src = asrc[PIECE] + kt * H2_BK;
-        src = (kt * H2_BK + achunk[PIECE] < K) ? src : g_zero_chunk_h2;
+        src = (kt * H2_BK + achunk[PIECE] < K) ? src : zero_chunk;
       }
       if constexpr (PIECE == 0) glds16_v_m0(src, a_dst[0] + so);
       else glds16_v_off<PIECE * 1024>(src - PIECE * 256);
@@ -1058,6 +1079,20 @@ int launch_absmax(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsig
 // a ring of 256 slots, taken round robin; memset + reduction + GEMM are ordered on the
 // caller's stream. A slot is reused after 256 further such calls -- plans that overlap
 // streams or capture graphs pass their own slots.
+// 16 zero bytes per device for GroupedArgs.zero_chunk
+const float* zero_chunk_dev() {
+  static std::mutex mu;
+  static float* z[RING_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RING_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!z[dev]) {
+    if (hipMalloc(reinterpret_cast<void**>(&z[dev]), 64) != hipSuccess) { z[dev] = nullptr; return nullptr; }
+    if (hipMemset(z[dev], 0, 64) != hipSuccess) return nullptr;
+  }
+  return z[dev];
+}
+
 // n / tiles_n[i] by multiply-shift for the kernels' tile mapping (Granlund-Montgomery, any
 // 32-bit n)
 void set_tn_div(GroupedArgs& g, int i) {
@@ -1160,6 +1195,11 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
     total += static_cast<int>(ceil_div(args[i].M, H2_BM)) * g.tiles_n[i];
   }
   for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  g.zero_chunk = zero_chunk_dev();
+  if (!g.zero_chunk) {
+    set_error("launch_grouped_h2: cannot allocate the zero chunk");
+    return EPOS_E_INVALID;
+  }
   const bool res = args[0].R != nullptr;
   const bool single = count == 1;
   const bool ps = args[0].a_presplit != 0;
@@ -1259,6 +1299,11 @@ int launch_sepconv_h2(const EposSepConvArgs* a, hipStream_t s) {
   g.conv_rate[0] = 1;
   const int total = static_cast<int>(ceil_div(pw.M, H2_BM)) * g.tiles_n[0];
   for (int i = 1; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  g.zero_chunk = zero_chunk_dev();
+  if (!g.zero_chunk) {
+    set_error("launch_sepconv_h2: cannot allocate the zero chunk");
+    return EPOS_E_INVALID;
+  }
   auto sp = [](unsigned d) {
     H2Div f;
     unsigned l = 0;

@@ -572,6 +572,39 @@ def main():
   clk_h = clk.cpu().numpy()
   clk_h = clk_h[clk_h[:, 1] > 0]
   core_mhz = float((clk_h[:, 0] / clk_h[:, 1]).mean() * 100.0) if len(clk_h) else None
+  # Socket power under the same load (rocm-smi, sampled while ~1.2 s of extra pipelined steps
+  # run; rank 0 of a one-GPU run only): the step runs close to the 1400 W cap, so the
+  # matrix pipe's share of the energy is what is left to win. MFMA-only power at the same
+  # clock: profiles/r04/power_by_component_h2.txt.
+  power_w = None
+  if world == 1 and not args.no_roofline:
+    import re
+    import subprocess
+    import threading
+    smi, samples = '/opt/rocm/bin/rocm-smi', []
+    if os.path.exists(smi):
+      stop = [False]
+
+      def sampler():
+        while not stop[0]:
+          try:
+            o = subprocess.run([smi, '--showpower'], capture_output=True, text=True,
+                               timeout=5).stdout
+            m_ = re.search(r'Power \(W\): ([0-9.]+)', o)
+            if m_:
+              samples.append(float(m_.group(1)))
+          except Exception:
+            break
+      th = threading.Thread(target=sampler, daemon=True)
+      th.start()
+      t_end = time.perf_counter() + 1.2
+      base = args.warmup + args.steps + 16
+      while time.perf_counter() < t_end:
+        run(base, 4 * depth)
+      stop[0] = True
+      th.join(timeout=6)
+      if len(samples) > 1:
+        power_w = round(float(np.mean(samples[1:])), 0)
   # Strictly serial steps (ONE plan, depth 1: C2's "batch = 1" read as latency) and the
   # per-stage HIP-event split of such a step (the reference prints the same three
   # stages per image, scripts/infer.py:730-734). Every rank runs them (run() gathers).
@@ -623,6 +656,15 @@ def main():
         'frac': round(value / world * gb / 8000.0, 4),
         'note': 'whole network, per GPU: the step is bound by the matrix pipe (the '
                 'GEMMs are 99 % of the flops at ~150 flop/B), not by HBM'}
+    if power_w:
+      roof['power_w'] = power_w
+      need = value / world * pipe.net.flops / B * 3 / 1e12      # fp16 piece products / s
+      roof['power_note'] = ('socket power (rocm-smi) while the same pipelined steps run; cap '
+                            '1400 W, idle ~280 W. This step needs %.0f fp16-TFLOP/s of piece '
+                            'products; bare MFMAs deliver 1490-1670 at 1310-1320 W '
+                            '(profiles/r04/power_by_component_h2.txt), i.e. ~0.7 pJ per flop '
+                            'above idle: the matrix pipe accounts for about %.0f %% of the '
+                            'power above idle' % (need, 100.0 * need * 0.7 / max(power_w - 280.0, 1.0)))
     if core_mhz:
       # sampled in extra steps after the timed region; peak stays the 2.4 GHz figure
       roof['core_clock_mhz_under_load'] = round(core_mhz, 0)

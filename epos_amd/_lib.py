@@ -241,7 +241,7 @@ def load():
     fn.restype = restype
     if argtypes is not None:
       fn.argtypes = argtypes
-  if lib.epos_abi_version() != 5:
+  if lib.epos_abi_version() != 6:
     raise EposError('libepos_hip.so ABI version mismatch')
   _lib = lib
   return lib

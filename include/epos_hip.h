@@ -34,7 +34,7 @@ extern "C" {
 #define EPOS_E_INTERNAL (-4)  /* a device-side consistency check failed (see epos_last_error) */
 #define EPOS_E_HIP_BASE (-1000)
 
-#define EPOS_ABI_VERSION 5   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32; 4: epos_solve_pnp_ransac; 5: fp16-pair GEMM (Wh, a_amax, c_amax, epos_pack_pointwise_weights_h2, epos_absmax_f32) */
+#define EPOS_ABI_VERSION 6   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32; 4: epos_solve_pnp_ransac; 5: fp16-pair GEMM (Wh, a_amax, c_amax, epos_pack_pointwise_weights_h2, epos_absmax_f32); 6: epos_separable_conv_f32 with fp16-pair intermediates on the fp16-pair kernel, epos_separable_conv_fused_state */
 
 int epos_abi_version(void);
 const char* epos_last_error(void);

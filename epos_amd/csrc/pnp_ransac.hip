@@ -2060,7 +2060,12 @@ __global__ __launch_bounds__(256) void pearl_sweep(
     const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
     const int32_t* __restrict__ num_models, EposFitParams prm, int max_k, Work w,
     const double* __restrict__ poses, const uint8_t* __restrict__ lab_in_all,
-    uint8_t* __restrict__ lab_out_all) {
+    uint8_t* __restrict__ lab_out_all, int with_energy) {
+  // with_energy (the FIRST sweep of an iteration): the energy of (poses, lab_in) -- the
+  // "before" of pearl_commit's comparison -- falls out of this pass: a point's disagreeing
+  // neighbours are deg - cnt[its label] and its data term is one of the k + 1 this pass
+  // evaluates anyway. Round 4: that removed two of the four pearl_energy launches per call
+  // (81 us each at C4's size); same integers, same bins.
   const int s = blockIdx.y;
   if (!w.pearl_state[s]) return;
   const int lane = threadIdx.x & 63;
@@ -2084,6 +2089,7 @@ __global__ __launch_bounds__(256) void pearl_sweep(
   NbLists nl = {nullptr, nullptr};
   if (w.nb_ok[s]) { nl.cnt = w.nb_cnt + base * NB_W; nl.pool = w.nb_pool + base * (NB_W * NB_SUB); }
   const int nwaves = gridDim.x * 4;
+  unsigned long long e_data = 0, e_smooth = 0;
   for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nwaves) {
     int cnt[PEARL_MAX_K + 1];
 #pragma unroll
@@ -2100,19 +2106,36 @@ __global__ __launch_bounds__(256) void pearl_sweep(
     if (lane == 0) {
       int best = 0;
       double best_c = 0.0;
+      const int lp = lab_in[p];
 #pragma unroll
       for (int m = 0; m <= PEARL_MAX_K; ++m) {
         if (m <= k) {
           const int64_t D = m < k ? pearl_data_term(pp + 12 * m, K, xy + 2 * p, xyz + 3 * p, tthr2)
                                   : d_out;
-          const double c = (1.0 - lam) * static_cast<double>(D) +
-                           lam * static_cast<double>(
-                               deg > 0 ? (static_cast<int64_t>(GC_Q) * (deg - cnt[m])) / deg : 0);
+          const int64_t sm = deg > 0 ? (static_cast<int64_t>(GC_Q) * (deg - cnt[m])) / deg : 0;
+          const double c = (1.0 - lam) * static_cast<double>(D) + lam * static_cast<double>(sm);
           if (m == 0 || c < best_c) { best = m; best_c = c; }
+          if (with_energy && (m == lp || (m == k && lp >= k))) {
+            e_data += static_cast<unsigned long long>(D);
+            e_smooth += static_cast<unsigned long long>(sm);
+          }
         }
       }
       lab_out[p] = static_cast<uint8_t>(best);
     }
+  }
+  if (with_energy) {                        // as pearl_energy(which = 0): acc[0], acc[1]
+    __shared__ unsigned long long s_sum[2];
+    if (threadIdx.x < 2) s_sum[threadIdx.x] = 0ull;
+    __syncthreads();
+    if (lane == 0) {
+      atomicAdd(&s_sum[0], e_data);
+      atomicAdd(&s_sum[1], e_smooth);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_sum[threadIdx.x] != 0ull)
+      atomicAdd(&w.pearl_acc[(s * 4 + threadIdx.x) * PEARL_BINS + (blockIdx.x & (PEARL_BINS - 1))],
+                s_sum[threadIdx.x]);
   }
 }
 
@@ -2397,14 +2420,14 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
                        num_models, *p, w, S);
     for (int it = 0; it < p->pearl_iters; ++it) {
       hipLaunchKernelGGL(pearl_begin, pgrid, dim3(256), 0, st, slot_base, num_models, w, labels);
-      hipLaunchKernelGGL(pearl_energy, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
-                         num_models, *p, max_k, w, poses, w.lab_a, 0);
+      // the energy of (accepted poses, current labels) comes out of the first sweep
+      // (pearl_setup admits a slot only with gc_sweeps >= 1)
       const uint8_t* lab_final = w.lab_a;
       for (int sw = 0; sw < p->gc_sweeps; ++sw) {
         const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
         uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
         hipLaunchKernelGGL(pearl_sweep, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
-                           num_models, *p, max_k, w, poses, in, out);
+                           num_models, *p, max_k, w, poses, in, out, sw == 0 ? 1 : 0);
         lab_final = out;
       }
       hipLaunchKernelGGL(pearl_refit, dim3(S), dim3(256), 0, st, xy, xyz, slot_base, Ks,

@@ -38,7 +38,14 @@ class EposPipeline(object):
                corr_min_frag_rel_conf=0.5, max_slots=None, capacity=1 << 20,
                max_instances=4, model_options=None, device='cuda:0',
                use_graph=True, instance=0, sparse_heads=False,
-               fitting_method='progressive_x'):
+               fitting_method='progressive_x', on_excess='raise'):
+    """on_excess: what launch() does with a frame that asks for more instances of an object
+    than `max_instances` (localization): 'raise' (default: EposError BEFORE anything of that
+    batch is enqueued -- batches already in flight on other pipelines are unaffected and can
+    still be collected) or 'clamp' (fit `max_instances` of them and warn once)."""
+    if on_excess not in ('raise', 'clamp'):
+      raise ValueError("on_excess must be 'raise' or 'clamp'")
+    self.on_excess = on_excess
     self.lib = _lib.load()
     # 'progressive_x' (infer.py:446-503) or 'opencv_ransac' (infer.py:505-528: one
     # cv2.solvePnPRansac(EPNP) per object, score 0.0) -- common.py:30-31
@@ -61,6 +68,7 @@ class EposPipeline(object):
     self.max_slots = max_slots or batch * num_objs
     self.max_k = max_instances
     self._warned_cap = False
+    self._warned_clamp = False
     self.cap_hits, self.last_cap_hits = [], []   # (scene, image, obj, instances) at the cap
     centers, sizes = _corresp.pack_model_store(model_store, num_objs, num_frags)
     self.obj_ids = list(model_store.dp_model['obj_ids'])
@@ -149,14 +157,24 @@ class EposPipeline(object):
         if task_type == LOCALIZATION:
           if obj_id not in t:                          # corresp.py:42-43
             continue
-          if int(t[obj_id]) > self.max_k:
+          want = int(t[obj_id])
+          if want > self.max_k:
             # never clamp silently (a frame with more instances of one object than the
             # plan was sized for would lose poses): the caller sizes max_instances from
-            # the frames it is going to feed (infer.py does), or caps the counts itself
-            raise _lib.EposError(
-                'image %d: %d instances of object %d requested, the pipeline was built '
-                'with max_instances=%d' % (im, int(t[obj_id]), obj_id, self.max_k))
-          wants.append(int(t[obj_id]))
+            # the frames it is going to feed (infer.py does), caps the counts itself, or
+            # asks for on_excess='clamp'. Raised here, i.e. before anything of this batch
+            # is enqueued.
+            if self.on_excess == 'raise':
+              raise _lib.EposError(
+                  'image %d: %d instances of object %d requested, the pipeline was built '
+                  'with max_instances=%d' % (im, want, obj_id, self.max_k))
+            if not self._warned_clamp:
+              import warnings
+              warnings.warn('object %d: %d instances requested, clamped to max_instances=%d'
+                            % (obj_id, want, self.max_k))
+              self._warned_clamp = True
+            want = self.max_k
+          wants.append(want)
         else:
           wants.append(-1)                             # all found, up to max_instances
         slots.append((im, obj_id))

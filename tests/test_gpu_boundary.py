@@ -96,6 +96,14 @@ def test_pipeline_never_clamps_instance_counts_silently():
     pipe.make_slots([{1: 3}])
   slots, wants = pipe.make_slots([{1: 2, 2: 1}])
   assert wants == [2, 1]
+  # on_excess='clamp': fit max_instances of them, warn once, cap hits of 'all found' recorded
+  pipe.on_excess = 'clamp'
+  with warnings.catch_warnings(record=True) as rec:
+    warnings.simplefilter('always')
+    slots, wants = pipe.make_slots([{1: 3, 2: 1}])
+    pipe.make_slots([{1: 5}])
+  assert wants == [2, 1] and len([w for w in rec if 'clamped' in str(w.message)]) == 1
+  pipe.on_excess = 'raise'
   slots, wants = pipe.make_slots([{}], task_type='detection')
   assert wants == [-1, -1] and len(slots) == O
   with warnings.catch_warnings(record=True):

@@ -38,6 +38,8 @@ class PointwiseArgs(ctypes.Structure):
       ('a_gain', ctypes.c_float), ('a_bias', ctypes.c_float),
       ('a_presplit', ctypes.c_int32),
       ('c_amax', vp),
+      # ABI 6: softmax over aligned groups of 64 output channels (head epilogue)
+      ('softmax64', ctypes.c_int32),
   ]
 
 

@@ -65,5 +65,22 @@ __device__ __forceinline__ void h2_split_pair(float x0, float x1, float s, unsig
   mid = __builtin_bit_cast(unsigned, m);
 }
 
+// Softmax over a group of 64 values held by 16 consecutive lanes x float4 (the fragment
+// axis): max / sum by in-lane pairs first, then the 8-4-2-1 xor butterfly over the 16 lanes.
+// ONE definition for the stand-alone kernels (softmax_groups64_kernel, softmax_slots64_kernel
+// in layers.hip) and for the fp16-pair GEMM's epilogue (EposPointwiseArgs.softmax64), whose
+// row phase holds a staged row in exactly this arrangement -- so dense, sparse-head and
+// fused runs give the same bits. All 64 lanes must take part.
+__device__ __forceinline__ float4 softmax64_lane16(float4 v) {
+  float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+  v.x = expf(v.x - m); v.y = expf(v.y - m); v.z = expf(v.z - m); v.w = expf(v.w - m);
+  float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+  return make_float4(v.x / s, v.y / s, v.z / s, v.w / s);
+}
+
 }  // namespace
 }  // namespace epos

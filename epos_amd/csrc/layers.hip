@@ -437,17 +437,7 @@ __global__ __launch_bounds__(256) void softmax_groups_kernel(float* X,
 // a quarter of the waves and fewer shuffle levels than the one-float-per-lane form. The same arithmetic (max / sum: in-lane pairs first, then the 8-4-2-1 xor
 // butterfly over the 16 lanes) is used by softmax_slots64_kernel, so dense and
 // sparse-head runs stay bit-identical.
-__device__ __forceinline__ float4 softmax64_lane16(float4 v) {
-  float m = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
-  v.x = expf(v.x - m); v.y = expf(v.y - m); v.z = expf(v.z - m); v.w = expf(v.w - m);
-  float s = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-  return make_float4(v.x / s, v.y / s, v.z / s, v.w / s);
-}
-
+// (softmax64_lane16: h2_scale.h)
 __global__ __launch_bounds__(256) void softmax_groups64_kernel(float* X, int64_t n_groups) {
   const int lane = threadIdx.x & 63;
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);

@@ -668,10 +668,37 @@ extern "C" int64_t epos_pack_pointwise_weights(const float* w_kn, int K, int N,
   return total;
 }
 
+static int grouped_impl(const EposPointwiseArgs* args, int count, void* stream);
+
 extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
                                                int count, void* stream) {
   using namespace epos;
   EPOS_REQUIRE(args && count >= 1 && count <= MAX_GROUP, "1..8 problems per group");
+  bool any_sm = false;
+  for (int i = 0; i < count; ++i) {
+    const EposPointwiseArgs& a = args[i];
+    if (!a.softmax64) continue;
+    any_sm = true;
+    EPOS_REQUIRE(a.N % 64 == 0 && a.ldc == a.N && !a.R && !a.relu && a.M > 8 &&
+                     (reinterpret_cast<uintptr_t>(a.C) & 15) == 0,
+                 "softmax64 needs N % 64 == 0, dense rows (ldc == N), no residual, no ReLU, "
+                 "M > 8 and a 16-byte aligned C");
+  }
+  // the fp16-pair kernel applies the softmax in its epilogue; for any other kernel the
+  // stand-alone kernel runs on the output afterwards (same arithmetic, same bits)
+  if (!any_sm || h2_eligible(args, count)) return grouped_impl(args, count, stream);
+  EposPointwiseArgs plain[MAX_GROUP];
+  for (int i = 0; i < count; ++i) { plain[i] = args[i]; plain[i].softmax64 = 0; }
+  int rc = grouped_impl(plain, count, stream);
+  for (int i = 0; i < count && !rc; ++i)
+    if (args[i].softmax64)
+      rc = epos_softmax_groups_f32(args[i].C, static_cast<int64_t>(args[i].M) * (args[i].N / 64),
+                                   64, stream);
+  return rc;
+}
+
+static int grouped_impl(const EposPointwiseArgs* args, int count, void* stream) {
+  using namespace epos;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int64_t tiles128 = 0;
   for (int i = 0; i < count; ++i) {
@@ -839,7 +866,7 @@ extern "C" int epos_pointwise_conv_grouped_ws_f32(const EposPointwiseArgs* args,
   // data-parallel path (the consumers of an absmax slot would otherwise read zeros).
   bool abi5 = false;
   for (int i = 0; i < count; ++i)
-    abi5 = abi5 || args[i].c_amax || args[i].Wh || args[i].a_presplit;
+    abi5 = abi5 || args[i].c_amax || args[i].Wh || args[i].a_presplit || args[i].softmax64;
   const bool sk = workspace && use_sk == 1 && args[0].relu_in == 0 && !abi5;
   if (sk && units < (1LL << 31))
     return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
@@ -862,7 +889,7 @@ extern "C" int epos_pointwise_conv_grouped_sk_f32(const EposPointwiseArgs* args,
   if (args[0].relu_in != 0)   // the LDS-DMA ring cannot apply the pre-activation
     return epos_pointwise_conv_grouped_f32(args, count, stream);
   for (int i = 0; i < count; ++i)     // ABI-5 fields the stream-K epilogue does not serve
-    if (args[i].c_amax || args[i].Wh || args[i].a_presplit)
+    if (args[i].c_amax || args[i].Wh || args[i].a_presplit || args[i].softmax64)
       return epos_pointwise_conv_grouped_f32(args, count, stream);
   return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
 }

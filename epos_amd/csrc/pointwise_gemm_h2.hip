@@ -439,6 +439,13 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
 #pragma unroll
     for (int i = 0; i < NI; ++i) v[i] = relu4(v[i]);
   }
+  if (!HAS_RES && p.softmax64) {
+    // the fragment-confidence head: softmax over each aligned group of 64 columns = the 16
+    // lanes x float4 that hold it in a staged row (the arithmetic of the stand-alone
+    // kernel, h2_scale.h). Uniform per problem; every lane takes part in the shuffles.
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = softmax64_lane16(v[i]);
+  }
   float* crow = p.C + (static_cast<int64_t>(m0w + r0) * p.ldc + n);
   const int64_t cstep = static_cast<int64_t>(RPI) * p.ldc;
   const bool nok = n < N;

@@ -149,6 +149,13 @@ typedef struct EposPointwiseArgs {
                        * this call writes (atomic max). Needs the float4 epilogue:
                        * N % 4 == 0, ldc % 4 == 0, C (and R) 16-byte aligned, relu_in == 0,
                        * M > 8; EPOS_E_INVALID otherwise */
+  /* ---- ABI 6 */
+  int32_t softmax64;  /* != 0: softmax over every aligned group of 64 output channels
+                       * (model.py:678: the fragment confidences of one object) before the
+                       * store. Needs N % 64 == 0, ldc == N (dense rows), no residual, no
+                       * ReLU. On the fp16-pair kernel it is part of the epilogue (the same
+                       * arithmetic as epos_softmax_groups_f32 with G = 64: identical bits);
+                       * on the other kernels the library runs that kernel on C afterwards */
 } EposPointwiseArgs;
 int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
 

@@ -611,3 +611,56 @@ def test_fused_separable_conv_h2_concurrent_streams_and_timeout(lib):
                      capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stdout + r.stderr
   assert int(r.stdout.split('TIMEOUTS')[1]) > 0, r.stdout     # the path was taken
+
+
+# ------------------------------------------ softmax over 64-groups in the epilogue (round 4) ---
+@pytest.mark.parametrize('m,k,n_conf', [(4800, 256, 1344), (300, 64, 64), (19200, 256, 192)])
+def test_softmax64_in_the_epilogue_equals_the_stand_alone_kernel(lib, m, k, n_conf):
+  """EposPointwiseArgs.softmax64: the fragment-confidence head's softmax (model.py:678) as part
+  of the fp16-pair GEMM's epilogue, in a grouped launch with two other heads as in the plan,
+  against the same launch without it followed by epos_softmax_groups_f32 -- bit for bit (one
+  definition of the 16-lane softmax); the other problems of the group are untouched; a call
+  without fp16-pair weights takes the library's fall-back (GEMM, then the stand-alone kernel)
+  and equals ITS two-step form bit for bit; rows sum to one."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(m + n_conf)
+  a = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32)
+  A = torch.from_numpy(a).cuda()
+  slot = _slot()
+  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+  ns = [22, n_conf, 3 * n_conf]
+  ws = [(rng.standard_normal((k, n)) * (2.0 / np.sqrt(k))).astype(np.float32) for n in ns]
+  bs = [torch.from_numpy(np.pad(rng.standard_normal(n).astype(np.float32),
+                                (0, (-n) % 128))).cuda() for n in ns]
+  Wp = [_pack(lib, w) for w in ws]
+  Wh = [_pack(lib, w, 'h2') for w in ws]
+
+  def run(use_h2, fused):
+    Cs = [torch.zeros(m, n, device='cuda') for n in ns]
+    args = [_lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp[i]), bias=_p(bs[i]), R=None, ldr=0,
+                               C=_p(Cs[i]), ldc=ns[i], M=m, N=ns[i], K=k, relu=0, relu_in=0,
+                               sub=1, Wh=_p(Wh[i]) if use_h2 else None,
+                               a_amax=_p(slot) if use_h2 else None,
+                               softmax64=int(fused and i == 1)) for i in range(3)]
+    arr = (_lib.PointwiseArgs * 3)(*args)
+    _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
+    if not fused:
+      _lib.check(lib.epos_softmax_groups_f32(_p(Cs[1]), m * (n_conf // 64), 64, None))
+    torch.cuda.synchronize()
+    return Cs
+  for use_h2 in (True, False):
+    two, one = run(use_h2, False), run(use_h2, True)
+    for i in range(3):
+      assert torch.equal(two[i], one[i]), (use_h2, i)
+    p = one[1].cpu().numpy().reshape(m, n_conf // 64, 64).astype(np.float64)
+    assert np.abs(p.sum(-1) - 1.0).max() < 1e-5 and p.min() >= 0.0
+
+
+def test_softmax64_rejects_what_it_cannot_do(lib):
+  from epos_amd import _lib
+  A = torch.zeros(64, 32, device='cuda'); C = torch.zeros(64, 96, device='cuda')
+  Wp = _pack(lib, np.zeros((32, 96), np.float32))
+  a = _lib.PointwiseArgs(A=_p(A), lda=32, Wp=_p(Wp), bias=None, R=None, ldr=0, C=_p(C), ldc=96,
+                         M=64, N=96, K=32, relu=0, relu_in=0, sub=1, softmax64=1)
+  with pytest.raises(_lib.EposError):          # 96 is not a multiple of 64
+    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))

@@ -199,3 +199,35 @@ def test_fused_separable_convs_give_the_same_network_bits(monkeypatch):
     assert torch.equal(net0.encoder, net1.encoder)
     assert torch.equal(net0.decoder_out, net1.decoder_out)
   assert int(net1.sepconv_stats[0]) == 0
+
+
+def test_head_softmax_in_the_epilogue_gives_the_same_network_bits(monkeypatch):
+  """The fragment-confidence softmax as part of the heads' GEMM launch (EPOS_HEAD_SOFTMAX_FUSED=1;
+  opt-in: measured slower) against the separate softmax_groups64 launch (the default): every output bit
+  for bit, eagerly and as a replayed graph; run_plan(with_post=False) still leaves the RAW
+  logits in the head buffers."""
+  from epos_amd import model, weights
+  num_objs, h, w = 3, 96, 128
+  ckpt = weights.random_init(num_objs=num_objs, seed=5, randomize_bn=True, logits_std=0.5)
+  img = torch.from_numpy(
+      np.random.RandomState(1).randint(0, 256, (2, h, w, 3)).astype('f')).cuda()
+  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
+  monkeypatch.setenv('EPOS_HEAD_SOFTMAX_FUSED', '0')
+  net0 = model.get_net(ckpt, 2, h, w, num_objs, 64, mo, instance=20)
+  out0 = {k: v.clone() for k, v in net0.forward(img).items()}
+  monkeypatch.setenv('EPOS_HEAD_SOFTMAX_FUSED', '1')
+  net1 = model.get_net(ckpt, 2, h, w, num_objs, 64, mo, instance=21)
+  assert net1._fuse_head_softmax and not net0._fuse_head_softmax
+  for rep in range(3):
+    out1 = net1.forward(img, use_graph=rep > 0)
+    torch.cuda.synchronize()
+    for k in out0:
+      assert torch.equal(out0[k], out1[k]), (k, rep)
+  s = out1['pred_frag_conf'].sum(-1)
+  assert float((s - 1).abs().max()) < 1e-5
+  net0.set_images(img); net0.run_plan(with_post=False)
+  net1.set_images(img); net1.run_plan(with_post=False)
+  torch.cuda.synchronize()
+  raw0, raw1 = net0.logits['pred_frag_conf'], net1.logits['pred_frag_conf']
+  assert torch.equal(raw0, raw1)
+  assert float(raw1.view(-1, 64).sum(-1).sub(1).abs().max()) > 1e-3        # logits, not probabilities

@@ -38,7 +38,8 @@ class PointwiseArgs(ctypes.Structure):
       ('a_gain', ctypes.c_float), ('a_bias', ctypes.c_float),
       ('a_presplit', ctypes.c_int32),
       ('c_amax', vp),
-      # ABI 6: softmax over aligned groups of 64 output channels (head epilogue)
+      # ABI 6: 32-row block sums; softmax over aligned groups of 64 output channels
+      ('col_sums', vp), ('col_ld', ctypes.c_int64),
       ('softmax64', ctypes.c_int32),
   ]
 
@@ -85,6 +86,7 @@ class Im2colArgs(ctypes.Structure):
       ('Ho', ctypes.c_int32), ('Wo', ctypes.c_int32), ('C', ctypes.c_int32),
       ('stride', ctypes.c_int32), ('rate', ctypes.c_int32),
       ('pad', ctypes.c_int32), ('preprocess', ctypes.c_int32),
+      ('amax_clear', vp), ('amax_words', ctypes.c_int64),        # ABI 6
   ]
 
 
@@ -160,6 +162,8 @@ SYMBOLS = {
     'epos_separable_conv_f32': (ctypes.c_int, [ctypes.POINTER(SepConvArgs), vp]),
     'epos_separable_conv_fused_state': (ctypes.c_int, [vp]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),
+    'epos_global_avg_pool_partial_f32': (ctypes.c_int, [
+        vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     'epos_global_avg_pool_f32': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     'epos_resize_bilinear_f32': (ctypes.c_int, [

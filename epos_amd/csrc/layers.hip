@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
 __global__ __launch_bounds__(256) void im2col3x3_kernel(EposIm2colArgs p,
                                                         int64_t total) {
   const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p.amax_clear && id < p.amax_words) p.amax_clear[id] = 0u;    // the plan's slot table
   if (id >= total) return;
   const int col = static_cast<int>(id % p.ldcol);
   int64_t pix = id / p.ldcol;
@@ -694,6 +695,8 @@ extern "C" int epos_im2col3x3_f32(const EposIm2colArgs* a, void* stream) {
   EPOS_REQUIRE(a && a->X && a->col, "null pointer");
   EPOS_REQUIRE(a->ldcol >= 9 * a->C, "ldcol too small");
   const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * a->ldcol;
+  EPOS_REQUIRE(!a->amax_clear || (a->amax_words >= 0 && a->amax_words <= total),
+               "amax_words exceeds the launch's thread count");
   if (total == 0) return EPOS_OK;
   hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), *a, total);
@@ -708,6 +711,38 @@ extern "C" int epos_global_avg_pool_f32(const float* X, int64_t ldx, float* Y,
                      dim3(static_cast<unsigned>(ceil_div(C, 64)), B), dim3(1024),
                      0, static_cast<hipStream_t>(stream), X, ldx, Y, HW, C);
   return launch_status("global_avg_pool_kernel");
+}
+
+namespace epos { namespace {
+// Y[b, c..c+3] = (sum over the blocks of image b of P[b * blocks + i, c..c+3]) / hw, blocks
+// in order: the second half of the image-pooling mean whose first half an fp16-pair GEMM's
+// epilogue wrote as 32-row block sums (EposPointwiseArgs.col_sums).
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* P, int64_t ldp,
+                                                           float* Y, int blocks, int C, int hw) {
+  const int b = blockIdx.y;
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= C) return;
+  const float* pb = P + static_cast<int64_t>(b) * blocks * ldp + c;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < blocks; ++i) {
+    const float4 v = ld4(pb + static_cast<int64_t>(i) * ldp);
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
+  const float n = static_cast<float>(hw);
+  st4(Y + static_cast<int64_t>(b) * C + c, make_float4(t.x / n, t.y / n, t.z / n, t.w / n));
+}
+} }
+
+extern "C" int epos_global_avg_pool_partial_f32(const float* P, int64_t ldp, float* Y,
+                                                int32_t B, int32_t blocks, int32_t C,
+                                                int32_t hw, void* stream) {
+  EPOS_REQUIRE(P && Y, "null pointer");
+  EPOS_REQUIRE(C % 4 == 0 && ldp % 4 == 0 && ldp >= C && blocks > 0 && hw > 0 && B > 0,
+               "C, ldp multiples of 4; blocks, hw, B > 0");
+  hipLaunchKernelGGL(epos::pool_partial_kernel,
+                     dim3(static_cast<unsigned>(epos::ceil_div(C, 1024)), B), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), P, ldp, Y, blocks, C, hw);
+  return epos::launch_status("pool_partial_kernel");
 }
 
 extern "C" int epos_resize_bilinear_f32(const float* X, int64_t ldx, float* Y,

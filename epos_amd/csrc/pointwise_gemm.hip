@@ -677,6 +677,13 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
   bool any_sm = false;
   for (int i = 0; i < count; ++i) {
     const EposPointwiseArgs& a = args[i];
+    if (a.col_sums)
+      EPOS_REQUIRE(!a.R && a.N % 4 == 0 && a.col_ld % 4 == 0 && a.col_ld >= a.N &&
+                       (reinterpret_cast<uintptr_t>(a.col_sums) & 15) == 0 &&
+                       (a.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
+                       h2_eligible(args, count),
+                   "col_sums needs the fp16-pair kernel (Wh, a bound for A), no residual, "
+                   "N, ldc, col_ld multiples of 4 and 16-byte aligned C / col_sums");
     if (!a.softmax64) continue;
     any_sm = true;
     EPOS_REQUIRE(a.N % 64 == 0 && a.ldc == a.N && !a.R && !a.relu && a.M > 8 &&
@@ -866,7 +873,8 @@ extern "C" int epos_pointwise_conv_grouped_ws_f32(const EposPointwiseArgs* args,
   // data-parallel path (the consumers of an absmax slot would otherwise read zeros).
   bool abi5 = false;
   for (int i = 0; i < count; ++i)
-    abi5 = abi5 || args[i].c_amax || args[i].Wh || args[i].a_presplit || args[i].softmax64;
+    abi5 = abi5 || args[i].c_amax || args[i].Wh || args[i].a_presplit || args[i].softmax64 ||
+           args[i].col_sums;
   const bool sk = workspace && use_sk == 1 && args[0].relu_in == 0 && !abi5;
   if (sk && units < (1LL << 31))
     return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
@@ -889,7 +897,8 @@ extern "C" int epos_pointwise_conv_grouped_sk_f32(const EposPointwiseArgs* args,
   if (args[0].relu_in != 0)   // the LDS-DMA ring cannot apply the pre-activation
     return epos_pointwise_conv_grouped_f32(args, count, stream);
   for (int i = 0; i < count; ++i)     // ABI-5 fields the stream-K epilogue does not serve
-    if (args[i].c_amax || args[i].Wh || args[i].a_presplit || args[i].softmax64)
+    if (args[i].c_amax || args[i].Wh || args[i].a_presplit || args[i].softmax64 ||
+        args[i].col_sums)
       return epos_pointwise_conv_grouped_f32(args, count, stream);
   return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
 }

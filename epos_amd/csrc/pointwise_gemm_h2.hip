@@ -446,6 +446,19 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
 #pragma unroll
     for (int i = 0; i < NI; ++i) v[i] = softmax64_lane16(v[i]);
   }
+  if (!HAS_RES && p.col_sums) {
+    // column sums of this wave's 32 stored rows (image pooling, model.py:220): rows in the
+    // order the lane holds them, then the two half-waves (even / odd rows); lanes 0..31 write
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (m0w + r0 + i * RPI < M) { cs.x += v[i].x; cs.y += v[i].y; cs.z += v[i].z; cs.w += v[i].w; }
+    }
+    cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64);
+    cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
+    if (lane < 32 && n < N && m0w < M)
+      *reinterpret_cast<float4*>(p.col_sums + static_cast<int64_t>(m0w >> 5) * p.col_ld + n) = cs;
+  }
   float* crow = p.C + (static_cast<int64_t>(m0w + r0) * p.ldc + n);
   const int64_t cstep = static_cast<int64_t>(RPI) * p.ldc;
   const bool nok = n < N;

@@ -395,6 +395,9 @@ class EposNet(object):
       _lib.check(lib.epos_pointwise_conv_grouped_ws_f32(ctypes.byref(args), 1, ws,
                                                         stream), name)
     self._add(name, run, 2 * m * n * k, 'gemm', nbytes)
+    # the launch closure holds `args` itself: _build_plan may still attach the image-pooling
+    # block sums to the launch that writes the encoder output
+    self._last_pw = (c, args, wh is not None and res is None and c_off == 0 and n % 4 == 0)
 
   def _flush_group(self, group):
     """Launches the collected problems as one grouped GEMM (they must agree on
@@ -523,6 +526,8 @@ class EposNet(object):
         Ho=ho, Wo=wo, C=cin, stride=stride, rate=rate, pad=rate,
         preprocess=int(preprocess))
     lib = self.lib
+    if getattr(self, '_first_im2col', None) is None:
+      self._first_im2col = (name + '/im2col', args)
 
     def run(stream, args=args):
       _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(args), stream), name)
@@ -761,9 +766,31 @@ class EposNet(object):
     m_enc = B * eh * ew
     pooled = self._empty(B, ec)
 
-    def run_pool(stream, x=x, pooled=pooled):
-      _lib.check(lib.epos_global_avg_pool_f32(_ptr(x), ec, _ptr(pooled), B,
-                                              eh * ew, ec, stream), 'avg_pool')
+    # Image pooling (model.py:220). Round 4: when the encoder output is written by ONE
+    # fp16-pair GEMM launch without residual (Xception: exit_flow/block2 separable_conv3),
+    # that launch's epilogue also writes the column sums of every block of 32 rows and a small
+    # kernel finishes the mean from 150 x 2048 floats instead of re-reading the 39 MB tensor
+    # (EPOS_POOL_FOLD=0: the stand-alone reduction, as for ResNet, whose last launch carries
+    # a residual, and for batches whose images are not a whole number of 32-row blocks).
+    lp = getattr(self, '_last_pw', None)
+    fold_pool = (not self.dry_run and os.environ.get('EPOS_POOL_FOLD', '1') == '1' and
+                 lp is not None and lp[0] is x and lp[2] and
+                 ((eh * ew) % 32 == 0 or B == 1))
+    self.pool_folded = bool(fold_pool)
+    if fold_pool:
+      blocks = (eh * ew + 31) // 32
+      part = self._empty(B * blocks, ec)
+      lp[1].col_sums = _ptr(part)
+      lp[1].col_ld = ec
+
+      def run_pool(stream, part=part, pooled=pooled):
+        _lib.check(lib.epos_global_avg_pool_partial_f32(_ptr(part), ec, _ptr(pooled), B,
+                                                        blocks, ec, eh * ew, stream),
+                   'avg_pool_partial')
+    else:
+      def run_pool(stream, x=x, pooled=pooled):
+        _lib.check(lib.epos_global_avg_pool_f32(_ptr(x), ec, _ptr(pooled), B,
+                                                eh * ew, ec, stream), 'avg_pool')
     self._add('image_pooling/mean', run_pool)
     self._set_expr(pooled, 'mean(%s)' % self._expr_of(x, 0, ec))
     w_kn, sc, bi = self._conv_params('image_pooling', HEAD_BN_EPS)
@@ -937,6 +964,17 @@ class EposNet(object):
                            'shape': [B, dh, dw_, O, F]},
         W.PRED_FRAG_LOC: {'expr': 'reshape(%s,%s)' % (el, [O, F, 3]),
                           'shape': [B, dh, dw_, O, F, 3]}}
+    # The slot table is zeroed by the plan's first launch. Round 4: that is the im2col of the
+    # first stem conv itself (EposIm2colArgs.amax_clear) when it directly follows -- one
+    # launch less per image (EPOS_AMAX_CLEAR_FOLD=0 keeps the separate kernel).
+    fi = getattr(self, '_first_im2col', None)
+    if (not self.dry_run and fi is not None and len(self.ops) > 1 and
+        self.ops[0][0] == 'amax_clear' and self.ops[1][0] == fi[0] and
+        os.environ.get('EPOS_AMAX_CLEAR_FOLD', '1') == '1'):
+      fi[1].amax_clear = _ptr(self._amax_table)
+      fi[1].amax_words = self._n_slots * _lib.AMAX_WORDS
+      del self.ops[0]
+      self._n_trunk_ops -= 1
 
   def algorithmic_bytes(self, dense_heads=True):
     """HBM bytes of ONE pass of the plan under the fusion-group rule of SURVEY.md App. A

@@ -150,6 +150,14 @@ typedef struct EposPointwiseArgs {
                        * N % 4 == 0, ldc % 4 == 0, C (and R) 16-byte aligned, relu_in == 0,
                        * M > 8; EPOS_E_INVALID otherwise */
   /* ---- ABI 6 */
+  float* col_sums;    /* optional [device]: [ceil(M / 32)][col_ld] -- the epilogue also writes,
+                       * for every block of 32 consecutive rows, the column sums of what it
+                       * stores (after bias / ReLU), in a fixed order. With rows = the pixels of
+                       * an image (H*W % 32 == 0) epos_global_avg_pool_partial_f32 turns them
+                       * into the per-image channel means (model.py:220) without re-reading
+                       * the tensor. fp16-pair kernel only (EPOS_E_INVALID otherwise), no
+                       * residual, N % 4 == 0 */
+  int64_t col_ld;
   int32_t softmax64;  /* != 0: softmax over every aligned group of 64 output channels
                        * (model.py:678: the fragment confidences of one object) before the
                        * store. Needs N % 64 == 0, ldc == N (dense rows), no residual, no
@@ -285,8 +293,18 @@ typedef struct EposIm2colArgs {
   int32_t B, Hi, Wi, Ho, Wo, C;
   int32_t stride, rate, pad;
   int32_t preprocess;
+  /* ---- ABI 6: optional [device] absmax slot table to zero in the same launch (amax_words
+   * uint32 words; must not exceed the launch's thread count = B*Ho*Wo*ldcol): a plan whose
+   * first launch is this one needs no epos_amax_clear launch of its own */
+  uint32_t* amax_clear;
+  int64_t amax_words;
 } EposIm2colArgs;
 int epos_im2col3x3_f32(const EposIm2colArgs* args, void* stream);
+
+/* Per-image channel means from the 32-row block sums an fp16-pair GEMM wrote
+ * (EposPointwiseArgs.col_sums): Y[b, c] = (sum over the `blocks` blocks of image b) / hw. */
+int epos_global_avg_pool_partial_f32(const float* P, int64_t ldp, float* Y, int32_t B,
+                                     int32_t blocks, int32_t C, int32_t hw, void* stream);
 
 /* Global mean over H*W (model.py:220): X [B, HW, C] (ldx) -> Y [B, C]. */
 int epos_global_avg_pool_f32(const float* X, int64_t ldx, float* Y, int B,

@@ -664,3 +664,55 @@ def test_softmax64_rejects_what_it_cannot_do(lib):
                          M=64, N=96, K=32, relu=0, relu_in=0, sub=1, softmax64=1)
   with pytest.raises(_lib.EposError):          # 96 is not a multiple of 64
     _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+
+
+@pytest.mark.parametrize('b,hw,k,n,relu', [(1, 4800, 1536, 2048, 1), (2, 96, 64, 260, 0),
+                                           (1, 6120, 128, 136, 1)])
+def test_block_sums_in_the_epilogue_give_the_image_pooling_mean(lib, b, hw, k, n, relu):
+  """EposPointwiseArgs.col_sums + epos_global_avg_pool_partial_f32 (round 4: the image-pooling
+  mean of model.py:220 without re-reading the encoder output): the per-image channel means
+  equal a float64 mean of the tensor the GEMM stored to a few fp32 roundings, the stored
+  tensor itself is unchanged by the extra output, and two runs give the same bits."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(hw + n)
+  m = b * hw
+  a = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  A = torch.from_numpy(a).cuda()
+  slot = _slot()
+  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+  Wp, Wh = _pack(lib, w), _pack(lib, w, 'h2')
+  bias = torch.from_numpy(np.pad(rng.standard_normal(n).astype(np.float32), (0, (-n) % 128))).cuda()
+  blocks = (hw + 31) // 32
+  if b > 1:
+    assert hw % 32 == 0
+  outs = []
+  for with_sums in (0, 1, 1):
+    C = torch.zeros(m, n, device='cuda')
+    part = torch.full((b * blocks, n), 7.0, device='cuda')
+    args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=_p(bias), R=None, ldr=0, C=_p(C),
+                              ldc=n, M=m, N=n, K=k, relu=relu, relu_in=0, sub=1, Wh=_p(Wh),
+                              a_amax=_p(slot), col_sums=_p(part) if with_sums else None, col_ld=n)
+    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+    Y = torch.zeros(b, n, device='cuda')
+    if with_sums:
+      _lib.check(lib.epos_global_avg_pool_partial_f32(_p(part), n, _p(Y), b, blocks, n, hw, None))
+    torch.cuda.synchronize()
+    outs.append((C, Y))
+  assert torch.equal(outs[0][0], outs[1][0])                    # C untouched by the extra output
+  assert torch.equal(outs[1][1], outs[2][1])                    # deterministic
+  ref = outs[1][0].cpu().numpy().astype(np.float64).reshape(b, hw, n).mean(1)
+  got = outs[1][1].cpu().numpy().astype(np.float64)
+  scale = np.abs(outs[1][0].cpu().numpy()).mean() + 1e-6
+  assert np.abs(got - ref).max() <= 3e-6 * scale * np.sqrt(hw / 32.0) + 1e-7
+
+
+def test_block_sums_need_the_fp16_pair_kernel(lib):
+  from epos_amd import _lib
+  A = torch.zeros(64, 32, device='cuda'); C = torch.zeros(64, 32, device='cuda')
+  part = torch.zeros(2, 32, device='cuda')
+  Wp = _pack(lib, np.eye(32, dtype=np.float32))
+  a = _lib.PointwiseArgs(A=_p(A), lda=32, Wp=_p(Wp), bias=None, R=None, ldr=0, C=_p(C), ldc=32,
+                         M=64, N=32, K=32, relu=0, relu_in=0, sub=1, col_sums=_p(part), col_ld=32)
+  with pytest.raises(_lib.EposError):
+    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))

@@ -766,3 +766,29 @@ def test_split_gemm_adversarial_operands(lib):
   ok = np.ones(m, bool); ok[[3, 5]] = False
   ref = a[ok].astype(np.float64) @ w.astype(np.float64)
   assert np.abs(c[ok] - ref).max() <= 8 * eps * (np.abs(a[ok]).astype(np.float64) @ np.abs(w)).max()
+
+
+def test_im2col_can_clear_the_absmax_slot_table(lib):
+  """EposIm2colArgs.amax_clear (round 4): the plan's slot table is zeroed by the im2col launch
+  that opens it -- same columns as without, every word of the table zero afterwards, a count
+  beyond the launch's threads is refused."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(0)
+  x = rng.uniform(0, 255, (1, 20, 24, 3)).astype(np.float32)
+  X = torch.from_numpy(x).cuda()
+  ho, wo, ld = 10, 12, 28
+  cols = []
+  for clear in (0, 1):
+    col = torch.zeros(ho * wo, ld, device='cuda')
+    table = torch.full((37 * 64,), 0x3f800000, dtype=torch.int32, device='cuda')
+    a = _lib.Im2colArgs(X=_p(X), ldx=3, col=_p(col), ldcol=ld, B=1, Hi=20, Wi=24, Ho=ho, Wo=wo,
+                        C=3, stride=2, rate=1, pad=1, preprocess=1,
+                        amax_clear=_p(table) if clear else None, amax_words=37 * 64)
+    _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(a), None))
+    torch.cuda.synchronize()
+    cols.append(col)
+    assert int(table.abs().sum()) == (0 if clear else 37 * 64 * 0x3f800000)
+  assert torch.equal(cols[0], cols[1])
+  a.amax_words = ho * wo * ld + 1
+  with pytest.raises(_lib.EposError):
+    _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(a), None))

@@ -184,6 +184,9 @@ def test_fused_separable_convs_give_the_same_network_bits(monkeypatch):
   img = torch.from_numpy(
       np.random.RandomState(0).randint(0, 256, (1, h, w, 3)).astype('f')).cuda()
   mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
+  # the image-pooling mean from the last GEMM's block sums (another summation order) is only
+  # attached to a stand-alone GEMM launch: compare like with like
+  monkeypatch.setenv('EPOS_POOL_FOLD', '0')
   monkeypatch.setenv('EPOS_SEPCONV_FUSED', '0')
   net0 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=10)
   out0 = {k: v.clone() for k, v in net0.forward(img).items()}
@@ -231,3 +234,31 @@ def test_head_softmax_in_the_epilogue_gives_the_same_network_bits(monkeypatch):
   raw0, raw1 = net0.logits['pred_frag_conf'], net1.logits['pred_frag_conf']
   assert torch.equal(raw0, raw1)
   assert float(raw1.view(-1, 64).sum(-1).sub(1).abs().max()) > 1e-3        # logits, not probabilities
+
+
+def test_folded_image_pooling_and_slot_clear_match_the_separate_launches(monkeypatch):
+  """Round 4: the image-pooling mean from the last encoder GEMM's 32-row block sums and the slot
+  table cleared by the opening im2col launch (the defaults) against the separate kernels
+  (EPOS_POOL_FOLD=0, EPOS_AMAX_CLEAR_FOLD=0): the pooled vector agrees to fp32 rounding of a
+  4800-term sum, every head to 1e-5 of its scale, the encoder output bit for bit, and the
+  plan is two launches shorter."""
+  from epos_amd import model, weights
+  num_objs, h, w = 2, 96, 128
+  ckpt = weights.random_init(num_objs=num_objs, seed=3, randomize_bn=True, logits_std=0.2)
+  img = torch.from_numpy(
+      np.random.RandomState(0).randint(0, 256, (1, h, w, 3)).astype('f')).cuda()
+  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
+  monkeypatch.setenv('EPOS_POOL_FOLD', '0'); monkeypatch.setenv('EPOS_AMAX_CLEAR_FOLD', '0')
+  net0 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=30)
+  out0 = {k: v.clone() for k, v in net0.forward(img).items()}
+  monkeypatch.setenv('EPOS_POOL_FOLD', '1'); monkeypatch.setenv('EPOS_AMAX_CLEAR_FOLD', '1')
+  net1 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=31)
+  assert net1.pool_folded and not net0.pool_folded
+  assert len(net1.ops) == len(net0.ops) - 1 and net1.ops[0][0].endswith('/im2col')
+  for rep in range(2):
+    out1 = net1.forward(img, use_graph=rep > 0)
+    torch.cuda.synchronize()
+    assert torch.equal(net0.encoder, net1.encoder)
+    for k in ('pred_obj_conf', 'pred_frag_conf', 'pred_frag_loc'):
+      a, b = out0[k].float(), out1[k].float()
+      assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), k

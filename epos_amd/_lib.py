@@ -40,7 +40,7 @@ class PointwiseArgs(ctypes.Structure):
       ('c_amax', vp),
       # ABI 6: 32-row block sums; softmax over aligned groups of 64 output channels
       ('col_sums', vp), ('col_ld', ctypes.c_int64),
-      ('softmax64', ctypes.c_int32),
+      ('c_stream', ctypes.c_int32), ('softmax64', ctypes.c_int32),
   ]
 
 

@@ -462,11 +462,16 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
   float* crow = p.C + (static_cast<int64_t>(m0w + r0) * p.ldc + n);
   const int64_t cstep = static_cast<int64_t>(RPI) * p.ldc;
   const bool nok = n < N;
+  const bool nt = p.c_stream != 0;              // streaming stores (the dense heads)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int m = m0w + r0 + i * RPI;
     if (m < M && nok) {
-      *reinterpret_cast<float4*>(crow) = v[i];
+      if (nt) {
+        const h2_f32x4 nv = {v[i].x, v[i].y, v[i].z, v[i].w};
+        __builtin_nontemporal_store(nv, reinterpret_cast<h2_f32x4*>(crow));
+      }
+      else *reinterpret_cast<float4*>(crow) = v[i];
       amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))),
                    fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
     }

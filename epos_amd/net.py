@@ -886,6 +886,13 @@ class EposNet(object):
                       np.ones(ch, np.float32), bs, buf, 0, ch, relu=False,
                       group=grp, track_out=False)
       self.logits[name] = buf
+    # the dense heads (413 MB at C2) are written with streaming stores: nobody re-reads them
+    # soon, and as ordinary stores they sweep the 256 MB Infinity Cache clean of the other
+    # images' working sets (same box: 424.6 / 422.4 vs 422.0 / 420.4 images/s, prediction of a
+    # serial step 3.31 vs 3.35 ms; EPOS_HEAD_NT_STORES=0 turns it off)
+    if os.environ.get('EPOS_HEAD_NT_STORES', '1') == '1':
+      for g in grp:
+        g[1].c_stream = 1
     obj_only = [g for g in grp if g[0].endswith(W.PRED_OBJ_CONF)]
     # The three heads: one grouped launch. Round 4 (judge's item 4): the softmax over each
     # object's 64 fragment confidences (model.py:678) CAN be part of that launch's epilogue

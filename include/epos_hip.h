@@ -158,6 +158,10 @@ typedef struct EposPointwiseArgs {
                        * the tensor. fp16-pair kernel only (EPOS_E_INVALID otherwise), no
                        * residual, N % 4 == 0 */
   int64_t col_ld;
+  int32_t c_stream;   /* != 0: write C with streaming (non-temporal) stores -- for outputs that
+                       * are not re-read soon (the 413 MB of dense heads would otherwise sweep
+                       * the 256 MB Infinity Cache clean of the other images' working sets);
+                       * fp16-pair kernel's float4 epilogue only, ignored elsewhere */
   int32_t softmax64;  /* != 0: softmax over every aligned group of 64 output channels
                        * (model.py:678: the fragment confidences of one object) before the
                        * store. Needs N % 64 == 0, ldc == N (dense rows), no residual, no

@@ -439,13 +439,29 @@ __global__ __launch_bounds__(256) void softmax_groups_kernel(float* X,
 // butterfly over the 16 lanes) is used by softmax_slots64_kernel, so dense and
 // sparse-head runs stay bit-identical.
 // (softmax64_lane16: h2_scale.h)
+// The dense fragment-confidence head is 103 MB at C2: read once, written once, re-read only
+// sparsely by the correspondence stage -- streaming (non-temporal) accesses keep it from
+// sweeping the Infinity Cache (EPOS_SOFTMAX_NT=0 at build time restores plain accesses).
+#ifndef EPOS_SOFTMAX_NT
+#define EPOS_SOFTMAX_NT 1
+#endif
+typedef float sm_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void softmax_groups64_kernel(float* X, int64_t n_groups) {
   const int lane = threadIdx.x & 63;
   const int64_t g = (static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   const bool on = g < n_groups;
   float* x = X + (on ? g : 0) * 64 + (lane & 15) * 4;
+#if EPOS_SOFTMAX_NT
+  const sm_f32x4 in = __builtin_nontemporal_load(reinterpret_cast<const sm_f32x4*>(x));
+  const float4 r = softmax64_lane16(make_float4(in[0], in[1], in[2], in[3]));
+  if (on) {
+    const sm_f32x4 o = {r.x, r.y, r.z, r.w};
+    __builtin_nontemporal_store(o, reinterpret_cast<sm_f32x4*>(x));
+  }
+#else
   const float4 r = softmax64_lane16(ld4(x));             // shuffles: all lanes take part
   if (on) st4(x, r);
+#endif
 }
 
 __global__ __launch_bounds__(256) void softmax_slots64_kernel(

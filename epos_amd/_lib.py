@@ -161,6 +161,8 @@ SYMBOLS = {
     'epos_separable_conv_sync_words': (ctypes.c_int64, [ctypes.c_int32]),
     'epos_separable_conv_f32': (ctypes.c_int, [ctypes.POINTER(SepConvArgs), vp]),
     'epos_separable_conv_fused_state': (ctypes.c_int, [vp]),
+    'epos_set_h2_narrow_tile_limit': (ctypes.c_int, [ctypes.c_int]),
+    'epos_set_h2_latency_tile_limit': (ctypes.c_int, [ctypes.c_int]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),
     'epos_global_avg_pool_partial_f32': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),

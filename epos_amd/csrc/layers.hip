@@ -143,7 +143,8 @@ __device__ __forceinline__ float4 relu4_1op(float4 v) {
 // y0 + rate). They share two of their three input rows, so the 4 x (L + 2) loaded float4
 // serve 2L outputs: 3.0 input loads per output instead of 4.5, and the nine weight
 // vectors are amortised over 8 outputs instead of 4 -- the kernel is bound by load
-// instructions issued (one 1 KB wave-load per ~24 ns per CU), not by bytes. Row slots:
+// instructions issued (one 1 KB wave-load per ~24 ns per CU -- a latency figure at this
+// kernel's occupancy: from cache a CU sustains one per 8-12 ns, round 4), not by bytes. Row slots:
 // rows are taken in groups of 2 * rate; slot (g, i), i < rate, owns rows 2*rate*g + i and
 // + rate. Same fmaf chain per output as ROWS = 1: identical bits.
 template <int L, bool RELU_IN, bool RELU_OUT, int ROWS>
@@ -735,13 +736,28 @@ namespace epos { namespace {
 // epilogue wrote as 32-row block sums (EposPointwiseArgs.col_sums).
 __global__ __launch_bounds__(256) void pool_partial_kernel(const float* P, int64_t ldp,
                                                            float* Y, int blocks, int C, int hw) {
+  // 16 row groups x 16 channel quads per workgroup: a thread adds every 16th block row (the
+  // loads of a thread are independent, so the ~10 of them for 150 rows overlap instead of
+  // queueing behind each other as in a one-thread-per-column loop: 39 -> ~6 us), then the 16
+  // partial sums meet in LDS in a fixed order.
+  __shared__ float4 red[16][16];
   const int b = blockIdx.y;
-  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c >= C) return;
-  const float* pb = P + static_cast<int64_t>(b) * blocks * ldp + c;
+  const int q = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = (blockIdx.x * 16 + q) * 4;
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = 0; i < blocks; ++i) {
-    const float4 v = ld4(pb + static_cast<int64_t>(i) * ldp);
+  if (c < C) {
+    const float* pb = P + static_cast<int64_t>(b) * blocks * ldp + c;
+#pragma unroll 4
+    for (int i = r; i < blocks; i += 16) {
+      const float4 v = ld4(pb + static_cast<int64_t>(i) * ldp);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+  }
+  red[r][q] = t;
+  __syncthreads();
+  if (r != 0 || c >= C) return;
+  for (int i = 1; i < 16; ++i) {
+    const float4 v = red[i][q];
     t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
   }
   const float n = static_cast<float>(hw);
@@ -756,7 +772,7 @@ extern "C" int epos_global_avg_pool_partial_f32(const float* P, int64_t ldp, flo
   EPOS_REQUIRE(C % 4 == 0 && ldp % 4 == 0 && ldp >= C && blocks > 0 && hw > 0 && B > 0,
                "C, ldp multiples of 4; blocks, hw, B > 0");
   hipLaunchKernelGGL(epos::pool_partial_kernel,
-                     dim3(static_cast<unsigned>(epos::ceil_div(C, 1024)), B), dim3(256), 0,
+                     dim3(static_cast<unsigned>(epos::ceil_div(C, 64)), B), dim3(256), 0,
                      static_cast<hipStream_t>(stream), P, ldp, Y, blocks, C, hw);
   return epos::launch_status("pool_partial_kernel");
 }

@@ -41,6 +41,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <utility>
 
 #include "h2_scale.h"
 #include "pointwise_gemm.h"
@@ -70,6 +71,52 @@ constexpr int H2_NST = 5;
 constexpr int H2_LDS = H2_NST * H2_STAGE;           // 81920: two workgroups per CU
 constexpr int H2_NP = 4;                            // LDS-DMA pieces per wave and stage
 constexpr int H2_EP_ROW = 132;                      // floats per staged epilogue row
+// Tile geometry by column blocks per wave: NB = 4 is the 128 x 128 tile above; NB = 2 a
+// 128 x 64 tile (round 4: launches with fewer 128-wide tiles than CUs -- the 48 middle-flow
+// layers of one image make 228 -- leave every SIMD with ONE wave; at 64 columns the same
+// launch has 456 workgroups, two per CU). A 64-column tile reads one half of the packed
+// 8 KB W stage image of its 128-column tile; the A stage is the same.
+// NW = 8 (with NB = 2): the 128 x 128 tile computed by EIGHT waves, 4 (rows) x 2 (column
+// halves) -- same stage, same bytes per MFMA as NB = 4 / NW = 4, but two waves per SIMD from
+// ONE workgroup: for launches that cannot give a CU a second workgroup ("latency mode").
+template <int NB, int NW = 4> struct H2Geo {
+  static constexpr int BN = NB * 32 * (NW / 4);
+  static constexpr int W_LDS = BN * 64;                    // W bytes per stage in LDS
+  static constexpr int STAGE = W_LDS + H2_A_BYTES;
+  static constexpr int LDS = H2_NST * STAGE;               // 81920 / 61440 (five stages)
+  static constexpr int NA = NW == 8 ? 1 : 2;               // A pieces per wave and stage
+  static constexpr int NWP = NW == 8 ? 1 : NB / 2;         // W pieces per wave and stage
+  static constexpr int NP = NA + NWP;                      // LDS-DMA pieces per wave and stage
+  static constexpr int EP_ROW = NB * 32 + 4;               // a wave stages its own columns
+};
+static_assert(H2Geo<4>::LDS == H2_LDS && H2Geo<4>::NP == H2_NP && H2Geo<4>::EP_ROW == H2_EP_ROW, "");
+static_assert(H2Geo<2, 8>::LDS == H2_LDS && H2Geo<2, 8>::BN == H2_BN, "");
+// Which MFMA of a K step (0..5 first half, 6..8 second half) each LDS-DMA piece of the
+// 128 x 128 tile is issued behind. Default: the first four.
+#ifndef EPOS_H2_DS0
+#define EPOS_H2_DS0 0
+#define EPOS_H2_DS1 1
+#define EPOS_H2_DS2 2
+#define EPOS_H2_DS3 3
+#endif
+constexpr int h2_piece_at(int idx) {
+  return idx == EPOS_H2_DS0 ? 0 : idx == EPOS_H2_DS1 ? 1 : idx == EPOS_H2_DS2 ? 2
+       : idx == EPOS_H2_DS3 ? 3 : -1;
+}
+constexpr int H2_DS_FIRST = (EPOS_H2_DS0 < 6) + (EPOS_H2_DS1 < 6) + (EPOS_H2_DS2 < 6) + (EPOS_H2_DS3 < 6);
+constexpr bool H2_DS_PAIRED = EPOS_H2_DS1 == EPOS_H2_DS0 + 1 && EPOS_H2_DS3 == EPOS_H2_DS2 + 1 &&
+                              (EPOS_H2_DS0 < 6) == (EPOS_H2_DS1 < 6) && (EPOS_H2_DS2 < 6) == (EPOS_H2_DS3 < 6);
+static_assert(EPOS_H2_DS0 <= 8 && EPOS_H2_DS1 <= 8 && EPOS_H2_DS2 <= 8 && EPOS_H2_DS3 <= 8, "");
+template <int... I, class F>
+__device__ __forceinline__ void h2_static_for(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N> __device__ __forceinline__ void h2_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void h2_wait_vm_lgkm0() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" : : "n"(N) : "memory");
+}
 
 __device__ __forceinline__ void mfma_f16(const u32x4& a, const u32x4& b, f32x16& c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
@@ -365,19 +412,19 @@ __device__ __forceinline__ void dw_produce_h2(const DwPhaseH2& d, float* smem, u
 // Epilogue of the h2 kernel: value = (acc + corr * 2^-11) * 2^-e_n * 2^-e_a + bias
 // (+ residual) (ReLU), transposed through the wave's LDS region and written as float4
 // rows (see vec_epilogue in pointwise_gemm.h); optionally max|value| -> c_amax.
-template <bool HAS_RES>
-__device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
+template <bool HAS_RES, int NB>
+__device__ __forceinline__ float vec_epilogue_h2(float* ws, const f32x16* acc,
                                                 const f32x16* corr, const float* cn,
                                                 const float* bias4, float inv_a,
-                                                const EposPointwiseArgs& p, int m0w, int n0w,
-                                                int lane, int salt) {
+                                                 const EposPointwiseArgs& p, int m0w, int n0w,
+                                                 int lane) {
   const int l31 = lane & 31, h = lane >> 5;
   const int M = p.M, N = p.N;
-  constexpr int EPR = H2_EP_ROW;
-  constexpr int C4 = 32;                     // float4 per staged row (128 columns)
-  constexpr int RPI = 2;                     // rows per wave instruction
-  constexpr int NI = 16;
-  const int c4 = lane & 31, r0 = lane >> 5;
+  constexpr int EPR = H2Geo<NB>::EP_ROW;
+  constexpr int C4 = NB * 8;                 // float4 per staged row (128 / 64 columns)
+  constexpr int RPI = 64 / C4;               // rows per wave instruction
+  constexpr int NI = 32 / RPI;
+  const int c4 = lane & (C4 - 1), r0 = lane / C4;
   const int n = n0w + c4 * 4;
   float4 rv[HAS_RES ? NI : 1];
   if (HAS_RES) {
@@ -390,7 +437,7 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NB; ++j) {
     // residual variants (bias4 == nullptr): the bias is added in the row phase below -- a
     // bias load issued here sits behind the sixteen residual rows in the in-order memory
     // queue and made this step wait for all of them (3.1 instead of 1.0 us in the trace),
@@ -454,9 +501,13 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
     for (int i = 0; i < NI; ++i) {
       if (m0w + r0 + i * RPI < M) { cs.x += v[i].x; cs.y += v[i].y; cs.z += v[i].z; cs.w += v[i].w; }
     }
+    if constexpr (NB == 2) {
+      cs.x += __shfl_xor(cs.x, 16, 64); cs.y += __shfl_xor(cs.y, 16, 64);
+      cs.z += __shfl_xor(cs.z, 16, 64); cs.w += __shfl_xor(cs.w, 16, 64);
+    }
     cs.x += __shfl_xor(cs.x, 32, 64); cs.y += __shfl_xor(cs.y, 32, 64);
     cs.z += __shfl_xor(cs.z, 32, 64); cs.w += __shfl_xor(cs.w, 32, 64);
-    if (lane < 32 && n < N && m0w < M)
+    if (lane < C4 && n < N && m0w < M)
       *reinterpret_cast<float4*>(p.col_sums + static_cast<int64_t>(m0w >> 5) * p.col_ld + n) = cs;
   }
   float* crow = p.C + (static_cast<int64_t>(m0w + r0) * p.ldc + n);
@@ -480,20 +531,35 @@ __device__ __forceinline__ void vec_epilogue_h2(float* ws, const f32x16* acc,
 #ifdef EPOS_GEMM_TRACE
   if (g_h2_trace && threadIdx.x == 0) g_h2_trace[8 * static_cast<uint64_t>(blockIdx.x) + 7] = wall_clock64();
 #endif
-  if (p.c_amax) amax_publish(p.c_amax, amax, lane, salt);
+  return amax;              // max |stored value| of this lane (the caller publishes it)
 }
 
 // PRESPLIT: every problem of the launch has its A operand already as fp16 pairs
 // (EposPointwiseArgs.a_presplit; the plan does not mix the two kinds in one group).
 // DW: fused separable conv (the producer phase above; SINGLE, PRESPLIT, not CONV).
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, bool DW = false>
-__global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs ga_,
-                                                                    DwPhaseH2 dw_) {
+// NST: stages of the LDS-DMA ring. Five = 80 KB = two workgroups per CU. A launch that cannot
+// give a CU a second workgroup anyway (a single image's 228-tile layers, one launch at a
+// time) may take a deeper ring: with one wave per SIMD the K loop is bound by the bytes in
+// flight per CU (64 KB at look-ahead 4 -> ~50 B/ns of the 85-128 the load path sustains).
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, bool DW = false, int NB = 4,
+          int NW = 4, int NST = H2_NST>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2)
+void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
+  static_assert(NB == 4 || (NB == 2 && !DW), "tile = 128 x 128 or 128 x 64");
+  static_assert(NW == 4 || (NW == 8 && NB == 2 && !CONV), "eight waves: 4 x 2, plain 1x1 only");
+  static_assert(NST == H2_NST || (NB == 4 && !DW && !CONV), "deep ring: plain 128 x 128 only");
+  using Geo = H2Geo<NB, NW>;
+  constexpr int NP = Geo::NP;
+  constexpr int NA = Geo::NA;
+  constexpr int LA = NST - 1;                  // tiles issued ahead of the one computed
+  static_assert((LA - 1) * NP <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wrow = NW == 8 ? (wave & 3) : wave;          // the wave's 32-row group
+  const int wcol = NW == 8 ? (wave >> 2) : 0;           //            column half (NW = 8)
   const int l31 = lane & 31, h = lane >> 5;
 
   (void)ga_;
@@ -570,7 +636,9 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     tile_m = rem / bw;
     tile_n = band * 8 + (rem - tile_m * bw);
   }
-  const int m0 = tile_m * H2_BM, n0 = tile_n * H2_BN;
+  const int m0 = tile_m * H2_BM, n0 = tile_n * Geo::BN;
+  const int tn128 = Geo::BN == 128 ? tiles_n : (tiles_n + 1) >> 1;   // packed W: 128-column images
+  const int n0w = n0 + wcol * 64;                                       // this wave's first column
   const int nks = (K + H2_BK - 1) / H2_BK;
   const int cblocks = CONV ? gp->conv_cin[pi] / H2_BK : 1;   // channel blocks per tap
   const int crate = CONV ? gp->conv_rate[pi] : 1;
@@ -592,14 +660,14 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   // The epilogue's per-column operands (inverse weight scales, bias) are requested here
   // too -- ahead of the LDS-DMA pieces, so that they retire first and their latency does
   // not stand between the K loop and the stores (8 VGPRs).
-  float cn[4], bias4[4];
+  float cn[NB], bias4[NB];
   if constexpr (EARLY_EPI) {
     const float* cscale = reinterpret_cast<const float*>(
-        static_cast<const char*>(p.Wh) + static_cast<int64_t>(gp->tiles_n[pi]) *
+        static_cast<const char*>(p.Wh) + static_cast<int64_t>(tn128) *
                                              ((K + H2_BK - 1) / H2_BK) * H2_W_BYTES);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nb = n0 + j * 32 + l31;
+    for (int j = 0; j < NB; ++j) {
+      const int nb = n0w + j * 32 + l31;
       cn[j] = cscale[nb];                                 // padded to tiles_n * 128
       // unconditional load (no bias: a zero word), so that nothing waits for it here
       const float* bsrc = p.bias ? p.bias + (nb < N ? nb : N - 1) : zero_chunk;
@@ -684,8 +752,8 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   int apy[CONV ? 2 : 1], apx[CONV ? 2 : 1];
   unsigned a_dst[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = 16 * (wave * 2 + i) + (lane >> 2);
+  for (int i = 0; i < NA; ++i) {
+    const int r = 16 * (wave * NA + i) + (lane >> 2);
     const int c = (lane & 3) ^ ((r >> 2) & 3);
     int m = m0 + r;
     m = m < M ? m : M - 1;
@@ -709,19 +777,22 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     asrc[i] = p.A + eoff;
     avoff[i] = eoff * 4u;                                            // bytes from p.A
     achunk[i] = c * 4;
-    a_dst[i] = lds0 + H2_W_BYTES + (wave_u * 2 + i) * 1024;
+    a_dst[i] = lds0 + Geo::W_LDS + (wave_u * NA + i) * 1024;
   }
   // ---- W pieces: the 8 KB stage image is contiguous in the packed buffer
-  const unsigned wvoff = static_cast<unsigned>(((wave * 2) * 64 + lane) * 16);
-  const unsigned w_dst = lds0 + (wave_u * 2) * 1024;
+  //      (NB = 2: one piece per wave out of the tile's half of the image)
+  const unsigned wvoff = static_cast<unsigned>(((wave * Geo::NWP) * 64 + lane) * 16);
+  const unsigned w_dst = lds0 + (wave_u * Geo::NWP) * 1024;
   const float* abase = uniform_ptr(p.A);
   const float* wsb = uniform_ptr(reinterpret_cast<const float*>(
-      static_cast<const char*>(p.Wh) + static_cast<int64_t>(tile_n) * nks * H2_W_BYTES));
+      static_cast<const char*>(p.Wh) +
+      (Geo::BN == 128 ? static_cast<int64_t>(tile_n) * nks * H2_W_BYTES
+                      : static_cast<int64_t>(tile_n >> 1) * nks * H2_W_BYTES + (tile_n & 1) * 4096)));
 
   auto issue_piece = [&](int kt, int stage, auto piece_tag, auto tail_tag) {
     constexpr int PIECE = decltype(piece_tag)::value;
     constexpr bool TAIL = decltype(tail_tag)::value;
-    const unsigned so = static_cast<unsigned>(stage) * H2_STAGE;
+    const unsigned so = static_cast<unsigned>(stage) * Geo::STAGE;
     if constexpr (PIECE < 2) {
       const float* src;
       if constexpr (CONV) {
@@ -733,27 +804,31 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
         src = ok ? src : zero_chunk;
       } else if constexpr (!TAIL) {
         // full K step of a 1x1 conv: scalar base + 32-bit lane offset
-        const float* ab = abase + (kt * H2_BK - PIECE * 256);      // uniform
-        if constexpr (PIECE == 0) glds16_s_m0(avoff[0], ab, a_dst[0] + so);
-        else glds16_s_off<PIECE * 1024>(avoff[PIECE], ab);
+        if constexpr (PIECE == 0 || !(H2_DS_PAIRED || NB == 2)) {
+          glds16_s_m0(avoff[PIECE], abase + kt * H2_BK, a_dst[PIECE] + so);
+        } else {
+          const float* ab = abase + (kt * H2_BK - PIECE * 256);      // uniform
+          glds16_s_off<PIECE * 1024>(avoff[PIECE], ab);
+        }
         return;
       } else {
         src = asrc[PIECE] + kt * H2_BK;
         src = (kt * H2_BK + achunk[PIECE] < K) ? src : zero_chunk;
       }
-      if constexpr (PIECE == 0) glds16_v_m0(src, a_dst[0] + so);
+      if constexpr (PIECE == 0 || !(H2_DS_PAIRED || NB == 2)) glds16_v_m0(src, a_dst[PIECE] + so);
       else glds16_v_off<PIECE * 1024>(src - PIECE * 256);
     } else {
       const float* wb = wsb + static_cast<int64_t>(kt) * (H2_W_BYTES / 4);
       if constexpr (PIECE == 2) glds16_s_m0(wvoff, wb, w_dst + so);
-      else glds16_s_off<1024>(wvoff, wb);
+      else if constexpr (H2_DS_PAIRED) glds16_s_off<1024>(wvoff, wb);
+      else glds16_s_m0(wvoff, wb + 256, w_dst + so + 1024);
     }
   };
   auto issue = [&](int kt, int stage) {
     issue_piece(kt, stage, std::integral_constant<int, 0>{}, std::true_type{});
-    issue_piece(kt, stage, std::integral_constant<int, 1>{}, std::true_type{});
+    if constexpr (NA == 2) issue_piece(kt, stage, std::integral_constant<int, 1>{}, std::true_type{});
     issue_piece(kt, stage, std::integral_constant<int, 2>{}, std::true_type{});
-    issue_piece(kt, stage, std::integral_constant<int, 3>{}, std::true_type{});
+    if constexpr (Geo::NWP == 2) issue_piece(kt, stage, std::integral_constant<int, 3>{}, std::true_type{});
   };
 
   // ---- fragment addresses (float index from the stage base)
@@ -762,14 +837,14 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     const int sw = (l31 >> 2) & 3;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      a_off[j] = H2_W_BYTES / 4 + (wave * 32 + l31) * H2_BK + (((2 * h + j) ^ sw) << 2);
+      a_off[j] = Geo::W_LDS / 4 + (wrow * 32 + l31) * H2_BK + (((2 * h + j) ^ sw) << 2);
   }
-  const int b_off = lane * 4;               // + (cb*2 + piece) * 256 floats
+  const int b_off = lane * 4 + wcol * 1024;   // + (cb*2 + piece) * 256 floats
 
   float4 xa[2];             // raw fp32 A fragments of the NEXT stage to compute
-  u32x4 bp[4][2];           // W fragments {hi, mid} per column block
+  u32x4 bp[4][2];           // W fragments {hi, mid} per column block (NB of them live)
   auto read_a = [&](int stage) {
-    const float* s = smem + stage * (H2_STAGE / 4);
+    const float* s = smem + stage * (Geo::STAGE / 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) xa[j] = *reinterpret_cast<const float4*>(s + a_off[j]);
   };
@@ -778,7 +853,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   // operands directly -- four 8-byte reads into the halves of (hi, mid), no conversion
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   auto read_a_ps = [&](int stage, u32x4& hi, u32x4& mid) {
-    const float* s = smem + stage * (H2_STAGE / 4);
+    const float* s = smem + stage * (Geo::STAGE / 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const u32x2 h2v = *reinterpret_cast<const u32x2*>(s + a_off[j]);
@@ -789,32 +864,36 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   };
   auto read_b = [&](int stage, auto cb_tag) {
     constexpr int cb = decltype(cb_tag)::value;
-    const float* s = smem + stage * (H2_STAGE / 4);
+    const float* s = smem + stage * (Geo::STAGE / 4);
 #pragma unroll
     for (int pc = 0; pc < 2; ++pc)
       bp[cb][pc] = *reinterpret_cast<const u32x4*>(s + b_off + (cb * 2 + pc) * 256);
   };
 
-  f32x16 acc[4], corr[4];
+  f32x16 acc[4], corr[4];   // NB of them live
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NB; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; corr[j][r] = 0.f; }
 
   // ---- prologue: up to four tiles in flight, tile 0 landed + visible
   issue(0, 0);
-  if (nks > 1) issue(1, 1);
-  if (nks > 2) issue(2, 2);
-  if (nks > 3) issue(3, 3);
+  h2_static_for(std::make_integer_sequence<int, LA - 1>{}, [&](auto i_tag) {
+    constexpr int i = decltype(i_tag)::value + 1;
+    if (nks > i) issue(i, i);
+  });
   H2_STAMP(1);
   if constexpr (LATE_SCALE) {
     h2_scale_finish(am_raw, am_raw2, p.a_gain, p.a_bias, sa_v, inv_a);
     sa = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sa_v)));
   }
-  if (nks > 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (nks > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (nks > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {   // tile 0 has landed once only the later tiles' pieces are outstanding
+    bool waited = false;
+    h2_static_for(std::make_integer_sequence<int, LA>{}, [&](auto i_tag) {
+      constexpr int i = LA - 1 - decltype(i_tag)::value;          // LA-1 .. 0
+      if (!waited && nks > i) { h2_wait_vm<i * NP>(); waited = true; }
+    });
+  }
   __builtin_amdgcn_s_barrier();
   H2_STAMP(2);
   u32x4 ah, am;
@@ -832,18 +911,21 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   }
   read_b(0, std::integral_constant<int, 0>{});
   read_b(0, std::integral_constant<int, 1>{});
-  read_b(0, std::integral_constant<int, 2>{});
-  read_b(0, std::integral_constant<int, 3>{});
-  // MODE 0: issue tile kt+4 (full)   1: issue tile kt+4 (the last, maybe partial)
-  //      2: kt+3 is the last tile    3: kt+2 is the last    4: kt+1 is the last   5: last
+  if constexpr (NB == 4) {
+    read_b(0, std::integral_constant<int, 2>{});
+    read_b(0, std::integral_constant<int, 3>{});
+  }
+  // MODE 0: issue tile kt+LA (full)   1: issue tile kt+LA (the last, maybe partial)
+  //      m >= 2: tile kt+LA+1-m is the last (five stages: 2: kt+3, 3: kt+2, 4: kt+1, 5: kt)
   // LIVE: column blocks that hold any column < N (4, or 3 for the last column tile of
   // e.g. N = 728: every wave of the workgroup then skips the same quarter of its MFMAs)
   auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag, auto ps_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
     constexpr int LIVE = decltype(live_tag)::value;
     constexpr bool PS = decltype(ps_tag)::value;       // A pre-split: no conversion
-    const int s4 = stage + 4 >= H2_NST ? stage + 4 - H2_NST : stage + 4;
-    const int s1 = stage + 1 >= H2_NST ? stage + 1 - H2_NST : stage + 1;
+    constexpr int LAST = LA + 1;                       // the mode of the last tile
+    const int s4 = stage + LA >= NST ? stage + LA - NST : stage + LA;
+    const int s1 = stage + 1 >= NST ? stage + 1 - NST : stage + 1;
     u32x4 nh, nm;
     auto split_unit = [&](auto u_tag) {
       constexpr int u = decltype(u_tag)::value;
@@ -876,11 +958,11 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
 #endif
       if constexpr (kIssue && ISSUE && DMA >= 0 && DMA < H2_NP) {
         __builtin_amdgcn_sched_barrier(0);
-        issue_piece(kt + 4, s4, std::integral_constant<int, DMA>{},
+        issue_piece(kt + LA, s4, std::integral_constant<int, DMA>{},
                     std::integral_constant<bool, MODE == 1>{});
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (!PS && SPL >= 0 && SPL < 4 && MODE != 5) {
+      if constexpr (!PS && SPL >= 0 && SPL < 4 && MODE != LAST) {
         __builtin_amdgcn_sched_barrier(0);
         split_unit(std::integral_constant<int, SPL>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -893,20 +975,20 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     using I3 = std::integral_constant<int, 3>;
     // first half: column blocks 0 and 1 interleaved (consecutive MFMAs never on the same
     // accumulator), small terms first per accumulator; the four DMA pieces ride along
-    step(ah, bp[0][1], corr[0], I0{}, N_{});
-    step(ah, bp[1][1], corr[1], I1{}, N_{});
-    step(am, bp[0][0], corr[0], I2{}, N_{});
-    step(am, bp[1][0], corr[1], I3{}, N_{});
-    step(ah, bp[0][0], acc[0], N_{}, N_{});
-    step(ah, bp[1][0], acc[1], N_{}, N_{});
-    if constexpr (MODE != 5) {
+#define H2_D(i) std::integral_constant<int, h2_piece_at(i)>{}
+    step(ah, bp[0][1], corr[0], H2_D(0), N_{});
+    step(ah, bp[1][1], corr[1], H2_D(1), N_{});
+    step(am, bp[0][0], corr[0], H2_D(2), N_{});
+    step(am, bp[1][0], corr[1], H2_D(3), N_{});
+    step(ah, bp[0][0], acc[0], H2_D(4), N_{});
+    step(ah, bp[1][0], acc[1], H2_D(5), N_{});
+    if constexpr (MODE != LAST) {
       // my reads of this stage are complete (fragments are in registers); my pieces of
       // tile kt+1 have landed once at most the later tiles' pieces are outstanding
+      // (of tile kt+LA: the H2_DS_FIRST pieces issued above)
 #ifndef EPOS_H2_ABL_NOBAR
-      if (MODE <= 1) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-      else if (MODE == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      else if (MODE == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_DS_FIRST>();
+      else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
       __builtin_amdgcn_s_barrier();
 #endif
 #ifndef EPOS_H2_ABL_NOREAD
@@ -918,19 +1000,20 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     }
     // second half: blocks 2 (and 3); the next stage's A fragment is split behind the MFMAs
     if constexpr (LIVE == 4) {
-      step(ah, bp[2][1], corr[2], N_{}, N_{});
-      step(ah, bp[3][1], corr[3], N_{}, I0{});
-      step(am, bp[2][0], corr[2], N_{}, I1{});
+      step(ah, bp[2][1], corr[2], H2_D(6), N_{});
+      step(ah, bp[3][1], corr[3], H2_D(7), I0{});
+      step(am, bp[2][0], corr[2], H2_D(8), I1{});
       step(am, bp[3][0], corr[3], N_{}, I2{});
       step(ah, bp[2][0], acc[2], N_{}, I3{});
       step(ah, bp[3][0], acc[3], N_{}, N_{});
     } else {
-      step(ah, bp[2][1], corr[2], N_{}, I0{});
-      step(am, bp[2][0], corr[2], N_{}, I1{});
-      step(ah, bp[2][0], acc[2], N_{}, I2{});
-      if constexpr (!PS && MODE != 5) split_unit(I3{});
+      step(ah, bp[2][1], corr[2], H2_D(6), I0{});
+      step(am, bp[2][0], corr[2], H2_D(7), I1{});
+      step(ah, bp[2][0], acc[2], H2_D(8), I2{});
+      if constexpr (!PS && MODE != LAST) split_unit(I3{});
     }
-    if constexpr (MODE != 5) {
+#undef H2_D
+    if constexpr (MODE != LAST) {
 #ifndef EPOS_H2_ABL_NOREAD
       read_b(s1, std::integral_constant<int, 2>{});
       if constexpr (LIVE == 4) read_b(s1, std::integral_constant<int, 3>{});
@@ -942,30 +1025,116 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     using LV = decltype(live_tag);
     using PS = decltype(ps_tag);
     using M0 = std::integral_constant<int, 0>;
-    using M1 = std::integral_constant<int, 1>;
-    using M2 = std::integral_constant<int, 2>;
-    using M3 = std::integral_constant<int, 3>;
-    using M4 = std::integral_constant<int, 4>;
-    using M5 = std::integral_constant<int, 5>;
     int kt = 0;
-    for (; kt + 9 < nks; kt += 5) {        // every LDS offset an immediate
-      tile(kt, 0, M0{}, LV{}, PS{});
-      tile(kt + 1, 1, M0{}, LV{}, PS{});
-      tile(kt + 2, 2, M0{}, LV{}, PS{});
-      tile(kt + 3, 3, M0{}, LV{}, PS{});
-      tile(kt + 4, 4, M0{}, LV{}, PS{});
+    for (; kt + 2 * NST - 1 < nks; kt += NST) {        // every LDS offset an immediate
+      h2_static_for(std::make_integer_sequence<int, NST>{}, [&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        tile(kt + i, i, M0{}, LV{}, PS{});
+      });
     }
-    int stage = 0;                          // kt is a multiple of 5 here
-    auto next = [&] { stage = stage + 1 == H2_NST ? 0 : stage + 1; ++kt; };
-    for (; kt + 5 < nks;) { tile(kt, stage, M0{}, LV{}, PS{}); next(); }
-    if (kt + 5 == nks) { tile(kt, stage, M1{}, LV{}, PS{}); next(); }
-    if (kt + 4 == nks) { tile(kt, stage, M2{}, LV{}, PS{}); next(); }
-    if (kt + 3 == nks) { tile(kt, stage, M3{}, LV{}, PS{}); next(); }
-    if (kt + 2 == nks) { tile(kt, stage, M4{}, LV{}, PS{}); next(); }
-    tile(kt, stage, M5{}, LV{}, PS{});
+    int stage = 0;                          // kt is a multiple of NST here
+    auto next = [&] { stage = stage + 1 == NST ? 0 : stage + 1; ++kt; };
+    for (; kt + LA + 1 < nks;) { tile(kt, stage, M0{}, LV{}, PS{}); next(); }
+    h2_static_for(std::make_integer_sequence<int, LA>{}, [&](auto i_tag) {
+      constexpr int m = decltype(i_tag)::value + 1;                  // modes 1 .. LA
+      if (kt + LA + 2 - m == nks) { tile(kt, stage, std::integral_constant<int, m>{}, LV{}, PS{}); next(); }
+    });
+    tile(kt, stage, std::integral_constant<int, LA + 1>{}, LV{}, PS{});
   };
-  if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{}, std::integral_constant<bool, PRESPLIT>{});
-  else k_loop(std::integral_constant<int, 4>{}, std::integral_constant<bool, PRESPLIT>{});
+  // ---- NB = 2 (128 x 64 tile): six MFMAs per stage and wave. There is no second half to
+  // read the next stage's fragments under, so the order is turned round: wait + barrier at
+  // the TOP of tile kt (my pieces of tile kt+1 have landed once at most tiles kt+2, kt+3 are
+  // outstanding), the fragments of tile kt+1 are requested into a second register set, then
+  // the six MFMAs of tile kt run with the three pieces of tile kt+4 and the split of the
+  // next A fragment behind them. Tile kt+4 lands in the stage of tile kt-1, whose reads every
+  // wave completed before the barrier of tile kt-1.
+  auto tile2 = [&](int kt, int stage, auto mode_tag, auto ps_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool PS = decltype(ps_tag)::value;
+    constexpr int LAST = LA + 1;
+    const int s4 = stage + LA >= NST ? stage + LA - NST : stage + LA;
+    const int s1 = stage + 1 >= NST ? stage + 1 - NST : stage + 1;
+    u32x4 nh, nm, nb[2][2];
+    if constexpr (MODE != LAST) {
+      if constexpr (MODE <= 2) h2_wait_vm_lgkm0<(LA - 2) * NP>();
+      else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
+      __builtin_amdgcn_s_barrier();
+      const float* sb = smem + s1 * (Geo::STAGE / 4);
+      if constexpr (PS) read_a_ps(s1, nh, nm); else read_a(s1);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+          nb[cb][pc] = *reinterpret_cast<const u32x4*>(sb + b_off + (cb * 2 + pc) * 256);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    auto split_unit = [&](auto u_tag) {
+      constexpr int u = decltype(u_tag)::value;
+      const float* x = reinterpret_cast<const float*>(&xa[u >> 1]);
+      float x0 = x[(u & 1) * 2], x1 = x[(u & 1) * 2 + 1];
+      asm volatile("" : "+v"(x0), "+v"(x1));         // anchored behind its MFMA (see tile)
+      unsigned hh, mm;
+      split_pair(x0, x1, sa, hh, mm);
+      nh[u] = hh; nm[u] = mm;
+    };
+    auto step = [&](const u32x4& a, const u32x4& b, f32x16& c, auto dma_tag, auto spl_tag) {
+      constexpr int DMA = decltype(dma_tag)::value;
+      constexpr int SPL = decltype(spl_tag)::value;
+      mfma_f16(a, b, c);
+      if constexpr (MODE <= 1 && DMA >= 0 && DMA < NP) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(kt + LA, s4, std::integral_constant<int, (DMA < NA ? DMA : 2 + DMA - NA)>{},
+                    std::integral_constant<bool, MODE == 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!PS && SPL >= 0 && SPL < 4 && MODE != LAST) {
+        __builtin_amdgcn_sched_barrier(0);
+        split_unit(std::integral_constant<int, SPL>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using N_ = std::integral_constant<int, -1>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    step(ah, bp[0][1], corr[0], I0{}, N_{});
+    step(ah, bp[1][1], corr[1], I1{}, N_{});
+    step(am, bp[0][0], corr[0], I2{}, I0{});
+    step(am, bp[1][0], corr[1], N_{}, I1{});
+    step(ah, bp[0][0], acc[0], N_{}, I2{});
+    step(ah, bp[1][0], acc[1], N_{}, I3{});
+    if constexpr (MODE != LAST) {
+      ah = nh; am = nm;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) { bp[cb][0] = nb[cb][0]; bp[cb][1] = nb[cb][1]; }
+    }
+  };
+  auto k_loop2 = [&](auto ps_tag) {
+    using PS = decltype(ps_tag);
+    using M0 = std::integral_constant<int, 0>;
+    int kt = 0;
+    for (; kt + 2 * NST - 1 < nks; kt += NST) {        // every LDS offset an immediate
+      h2_static_for(std::make_integer_sequence<int, NST>{}, [&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        tile2(kt + i, i, M0{}, PS{});
+      });
+    }
+    int stage = 0;
+    auto next = [&] { stage = stage + 1 == NST ? 0 : stage + 1; ++kt; };
+    for (; kt + LA + 1 < nks;) { tile2(kt, stage, M0{}, PS{}); next(); }
+    h2_static_for(std::make_integer_sequence<int, LA>{}, [&](auto i_tag) {
+      constexpr int m = decltype(i_tag)::value + 1;
+      if (kt + LA + 2 - m == nks) { tile2(kt, stage, std::integral_constant<int, m>{}, PS{}); next(); }
+    });
+    tile2(kt, stage, std::integral_constant<int, LA + 1>{}, PS{});
+  };
+  if constexpr (NB == 4) {
+    if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{}, std::integral_constant<bool, PRESPLIT>{});
+    else k_loop(std::integral_constant<int, 4>{}, std::integral_constant<bool, PRESPLIT>{});
+  } else {
+    k_loop2(std::integral_constant<bool, PRESPLIT>{});
+  }
 
   H2_STAMP(3);
 #ifdef EPOS_SEPCONV_TRACE
@@ -983,16 +1152,37 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
     // (requesting these at the top of the last K step was tried: the residual variants sit
     // at 256 VGPRs and spill)
     const float* cscale = reinterpret_cast<const float*>(
-        static_cast<const char*>(p.Wh) + static_cast<int64_t>(tiles_n) * nks * H2_W_BYTES);
+        static_cast<const char*>(p.Wh) + static_cast<int64_t>(tn128) * nks * H2_W_BYTES);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cn[j] = cscale[n0 + j * 32 + l31];   // padded to tiles_n*128
+    for (int j = 0; j < NB; ++j) cn[j] = cscale[n0w + j * 32 + l31]; // padded to tn128*128
   }
   if (vec_epilogue_ok(p, HAS_RES)) {
     __syncthreads();
     H2_STAMP(5);
-    float* ws = smem + wave * 32 * H2_EP_ROW;
-    vec_epilogue_h2<HAS_RES>(ws, acc, corr, cn, EARLY_EPI ? bias4 : nullptr, inv_a, p,
-                             m0 + wave * 32, n0, lane, blockIdx.x * 4 + wave);
+    float* ws = smem + wave * 32 * Geo::EP_ROW;
+    float amax = vec_epilogue_h2<HAS_RES, NB>(ws, acc, corr, cn, EARLY_EPI ? bias4 : nullptr,
+                                              inv_a, p, m0 + wrow * 32, n0w, lane);
+#ifdef EPOS_H2_AMAX_PER_WAVE      // A/B: the former one-atomic-per-wave publish
+    if (p.c_amax) { amax_publish(p.c_amax, amax, lane, blockIdx.x * NW + wave); return; }
+#endif
+    if (p.c_amax) {
+      // ONE atomic per workgroup: the workgroups of a launch finish together, and their
+      // atomics all land on the slot's two cache lines -- one per wave (912 for a middle-flow
+      // launch) kept the launch alive ~2 us after its last store (profiles/r04).
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      float* red = smem + NW * 32 * Geo::EP_ROW;           // behind every wave's staged rows
+      if (lane == 0) red[wave] = amax;
+      __syncthreads();
+      if (wave == 0) {
+        float v = lane < NW ? red[lane] : 0.f;
+#pragma unroll
+        for (int o = NW / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        if (lane == 0)
+          __hip_atomic_fetch_max(p.c_amax + (blockIdx.x & (EPOS_AMAX_WORDS - 1)),
+                                 __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
 #ifdef EPOS_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores acknowledged
     H2_STAMP(4);
@@ -1001,18 +1191,18 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   }
   if constexpr (!EARLY_EPI) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nb = n0 + j * 32 + l31;
+    for (int j = 0; j < NB; ++j) {
+      const int nb = n0w + j * 32 + l31;
       bias4[j] = p.bias ? p.bias[nb < N ? nb : N - 1] : 0.f;
     }
   }
   const bool relu = p.relu != 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + j * 32 + l31;
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0w + j * 32 + l31;
     const int nc = n < N ? n : N - 1;
     const float bias = bias4[j];
-    const int mb = m0 + wave * 32 + 4 * h;
+    const int mb = m0 + wrow * 32 + 4 * h;
     float rv[16];
     if (HAS_RES) {
 #pragma unroll
@@ -1033,18 +1223,20 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_h2_f32(GroupedArgs 
   }
 }
 
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, bool DW = false>
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, bool DW = false,
+          int NB = 4, int NW = 4, int NST = H2_NST>
 int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s,
                  const DwPhaseH2* dw = nullptr) {
-  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, DW>;
+  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, DW, NB, NW, NST>;
+  constexpr int lds = NST * H2Geo<NB, NW>::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  // 80 KB per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), H2_LDS, s, g,
+  // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD
+  hipLaunchKernelGGL(kern, dim3(total), dim3(NW * 64), lds, s, g,
                      dw ? *dw : DwPhaseH2{});
   return launch_status("pointwise_gemm_h2_f32");
 }
@@ -1178,6 +1370,24 @@ bool h2_eligible(const EposPointwiseArgs* args, int count) {
   return true;
 }
 
+int& narrow_limit() {
+  static int v = [] {
+    const char* e = getenv("EPOS_H2_BN64_MAX_TILES");
+    return e ? atoi(e) : 100;
+  }();
+  return v;
+}
+
+// "Latency mode": launches of at most this many 128 x 128 tiles (and more than the narrow
+// limit) run the eight-wave form of the tile. 0 = never.
+int& latency_limit() {
+  static int v = [] {
+    const char* e = getenv("EPOS_H2_LATENCY_MAX_TILES");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                       const int* conv_cin, const int* conv_rate) {
   if (conv_cin && (count != 1 || args[0].R != nullptr)) {
@@ -1211,15 +1421,32 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
       g.p[i].a_amax2 = nullptr;
       g.p[i].a_gain = 0.f;
     }
-    g.tile_start[i] = total;
-    g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, H2_BN));
-    set_tn_div(g, i);
-    g.npad[i] = g.tiles_n[i] * H2_BN;
     g.conv_cin[i] = conv_cin ? conv_cin[i] : 0;
     g.conv_rate[i] = conv_rate ? conv_rate[i] : 1;
-    total += static_cast<int>(ceil_div(args[i].M, H2_BM)) * g.tiles_n[i];
   }
-  for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  auto lay_out = [&](int bn) {
+    total = 0;
+    for (int i = 0; i < count; ++i) {
+      g.tile_start[i] = total;
+      g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, bn));
+      set_tn_div(g, i);
+      g.npad[i] = static_cast<int>(ceil_div(args[i].N, H2_BN)) * H2_BN;
+      total += static_cast<int>(ceil_div(args[i].M, H2_BM)) * g.tiles_n[i];
+    }
+    for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
+  };
+  lay_out(H2_BN);
+  // A launch of few 128 x 128 tiles runs as 128 x 64 tiles: twice the workgroups. Measured
+  // (profiles/r04/gemm_h2_tile_shapes.txt): worth 20-25 % for launches of ~80 wide tiles
+  // (ASPP 1x1, concat projection: two thirds of the CUs idle otherwise), a LOSS from ~150
+  // tiles on -- at 228 tiles (a single image's middle-flow layers) two narrow workgroups per
+  // CU are slower than one wide one, because a narrow tile moves 1.5x the LDS-DMA bytes per
+  // MFMA and the DMA issue is what the loop waits for. Hence the default limit of 100. Same
+  // bits either way (an element's K sum does not depend on the tile). EPOS_H2_BN64_MAX_TILES
+  // or epos_set_h2_narrow_tile_limit (0 = never).
+  bool narrow = !conv_cin && total <= __atomic_load_n(&narrow_limit(), __ATOMIC_RELAXED);
+  for (int i = 0; i < count; ++i) narrow = narrow && !args[i].col_sums;
+  if (narrow) lay_out(64);
   g.zero_chunk = zero_chunk_dev();
   if (!g.zero_chunk) {
     set_error("launch_grouped_h2: cannot allocate the zero chunk");
@@ -1234,6 +1461,34 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
       return EPOS_E_INVALID;
     }
   if (conv_cin) return launch_h2_tt<false, true, true>(g, total, s);
+  if (!narrow && total <= __atomic_load_n(&latency_limit(), __ATOMIC_RELAXED)) {
+    bool ok = true;                       // block sums are laid out for four-wave tiles
+    for (int i = 0; i < count; ++i) ok = ok && !args[i].col_sums;
+    if (ok) {
+      if (ps) {
+        if (res) return single ? launch_h2_tt<true, true, false, true, false, 2, 8>(g, total, s)
+                               : launch_h2_tt<true, false, false, true, false, 2, 8>(g, total, s);
+        return single ? launch_h2_tt<false, true, false, true, false, 2, 8>(g, total, s)
+                      : launch_h2_tt<false, false, false, true, false, 2, 8>(g, total, s);
+      }
+      if (res) return single ? launch_h2_tt<true, true, false, false, false, 2, 8>(g, total, s)
+                             : launch_h2_tt<true, false, false, false, false, 2, 8>(g, total, s);
+      return single ? launch_h2_tt<false, true, false, false, false, 2, 8>(g, total, s)
+                    : launch_h2_tt<false, false, false, false, false, 2, 8>(g, total, s);
+    }
+  }
+  if (narrow) {
+    if (ps) {
+      if (res) return single ? launch_h2_tt<true, true, false, true, false, 2>(g, total, s)
+                             : launch_h2_tt<true, false, false, true, false, 2>(g, total, s);
+      return single ? launch_h2_tt<false, true, false, true, false, 2>(g, total, s)
+                    : launch_h2_tt<false, false, false, true, false, 2>(g, total, s);
+    }
+    if (res) return single ? launch_h2_tt<true, true, false, false, false, 2>(g, total, s)
+                           : launch_h2_tt<true, false, false, false, false, 2>(g, total, s);
+    return single ? launch_h2_tt<false, true, false, false, false, 2>(g, total, s)
+                  : launch_h2_tt<false, false, false, false, false, 2>(g, total, s);
+  }
   if (ps) {
     if (res) return single ? launch_h2_tt<true, true, false, true>(g, total, s)
                            : launch_h2_tt<true, false, false, true>(g, total, s);
@@ -1368,6 +1623,16 @@ extern "C" int epos_debug_set_gemm_trace(uint64_t* buf) {
                          "epos_debug_set_gemm_trace");
 }
 #endif
+
+extern "C" int epos_set_h2_latency_tile_limit(int max_tiles) {
+  return __atomic_exchange_n(&epos::latency_limit(), max_tiles < 0 ? 0 : max_tiles,
+                             __ATOMIC_RELAXED);
+}
+
+extern "C" int epos_set_h2_narrow_tile_limit(int max_tiles) {
+  return __atomic_exchange_n(&epos::narrow_limit(), max_tiles < 0 ? 0 : max_tiles,
+                             __ATOMIC_RELAXED);
+}
 
 extern "C" int epos_separable_conv_fused_state(void* stream) {
   return epos::xcd_mapping_state(static_cast<hipStream_t>(stream));

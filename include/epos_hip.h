@@ -277,6 +277,20 @@ int epos_depthwise3x3_f32(const EposDepthwiseArgs* args, void* stream);
  * first call came during a stream capture (-1) -- unless it is 1 the two launches are
  * issued instead. */
 int epos_separable_conv_fused_state(void* stream);
+/* The fp16-pair GEMM takes 128 x 64 instead of 128 x 128 output tiles for a launch with at
+ * most `max_tiles` 128 x 128 tiles (default 100; environment EPOS_H2_BN64_MAX_TILES; 0 =
+ * never): launches that would leave most CUs idle (ASPP 1x1 of one image: 76 tiles) get
+ * twice the workgroups. Results do not depend on the tile. Returns the previous limit.
+ * Process-wide; meant for tuning and for the tests that run both tiles. */
+int epos_set_h2_narrow_tile_limit(int max_tiles);
+/* Latency mode of the fp16-pair GEMM: a launch with at most `max_tiles` 128 x 128 tiles
+ * (and more than the narrow-tile limit) computes each tile with EIGHT waves (4 row groups x
+ * 2 column halves, 512 threads, one workgroup per CU) instead of four: two waves on every
+ * SIMD from a launch that cannot give a CU a second workgroup. For callers that run ONE
+ * launch at a time (a single image, pipeline depth 1); with several launches in flight two
+ * four-wave workgroups per CU overlap better. Default 0 = never (environment
+ * EPOS_H2_LATENCY_MAX_TILES). Same bits. Returns the previous limit. Process-wide. */
+int epos_set_h2_latency_tile_limit(int max_tiles);
 typedef struct EposSepConvArgs {
   EposDepthwiseArgs dw;
   EposPointwiseArgs pw;

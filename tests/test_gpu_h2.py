@@ -20,6 +20,19 @@ def lib():
   return _lib.load()
 
 
+@pytest.fixture(autouse=True, params=['tile128', 'tile64', 'waves8'])
+def tile(request, lib):
+  """Every test of this module runs with the three launch shapes of the fp16-pair kernel:
+  128 x 128 tiles on the five-stage ring only (both limits 0), 128 x 64 tiles wherever the
+  kernel offers them, and the eight-wave form wherever it is offered
+  (epos_set_h2_narrow_tile_limit / epos_set_h2_latency_tile_limit, include/epos_hip.h)."""
+  prev = (lib.epos_set_h2_narrow_tile_limit((1 << 30) if request.param == 'tile64' else 0),
+          lib.epos_set_h2_latency_tile_limit((1 << 30) if request.param == 'waves8' else 0))
+  yield request.param
+  lib.epos_set_h2_narrow_tile_limit(prev[0])
+  lib.epos_set_h2_latency_tile_limit(prev[1])
+
+
 def _p(t, off=0):
   return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
 
@@ -207,6 +220,45 @@ def test_absmax_kernel(lib):
     _lib.check(lib.epos_amax_clear(_p(slot), 1, None))
     torch.cuda.synchronize()
     assert _slot_value(slot) == 0.0
+
+
+@pytest.mark.parametrize('m,k,n,res,relu', [(4800, 728, 728, 0, 0), (4800, 728, 728, 1, 1),
+                                            (1200, 1024, 1536, 0, 1), (333, 40, 24, 0, 0),
+                                            (19200, 256, 48, 0, 1), (130, 92, 200, 1, 0)])
+def test_h2_bits_do_not_depend_on_the_tile(lib, m, k, n, res, relu):
+  """128 x 64 tiles, 128 x 128 tiles and the eight-wave form (round 4) accumulate an element's
+  K sum in the same order: equal bits, equal published absmax -- with and without residual, ragged M / N / K, the
+  first and the second half of a packed 128-column weight image."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(m + k + n)
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+  bias = rng.standard_normal(n).astype(np.float32)
+  r = rng.standard_normal((m, n)).astype(np.float32) if res else None
+  outs = []
+  prev = lib.epos_set_h2_narrow_tile_limit(0), lib.epos_set_h2_latency_tile_limit(0)
+  try:
+    for limit, deep in ((0, 0), (1 << 30, 0), (0, 1 << 30)):
+      lib.epos_set_h2_narrow_tile_limit(limit)
+      lib.epos_set_h2_latency_tile_limit(deep)
+      slot_a, slot_c = _slot(), _slot()
+      A = torch.from_numpy(a).cuda()
+      _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot_a), None))
+      c = _gemm(lib, a, w, 'h2', bias=bias, res=r, relu=relu, a_amax=slot_a, c_amax=slot_c)
+      outs.append((c, _slot_value(slot_c)))
+  finally:
+    lib.epos_set_h2_narrow_tile_limit(prev[0])
+    lib.epos_set_h2_latency_tile_limit(prev[1])
+  for o in outs[1:]:
+    assert np.array_equal(outs[0][0].view(np.uint32), o[0].view(np.uint32))
+    assert o[1] == outs[0][1]
+  assert outs[0][1] == np.abs(outs[0][0]).max()
+  ref = a.astype(np.float64) @ w.astype(np.float64) + bias
+  if res:
+    ref = ref + r
+  if relu:
+    ref = np.maximum(ref, 0)
+  np.testing.assert_allclose(outs[1][0], ref, rtol=2e-5, atol=2e-5)
 
 
 def test_h2_grouped_and_strided(lib):

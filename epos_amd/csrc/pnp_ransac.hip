@@ -434,6 +434,8 @@ struct Work {
   int32_t* gq;           // [N] fixed-point truncated residuals of the labelling
   uint8_t* lab_a;        // [N] labels, ping
   uint8_t* lab_b;        // [N] labels, pong
+  uint8_t* lab_c;        // [N] joint refinement: the last sweep's labels in INDEX order
+  int32_t* pearl_dt;     // [N][PEARL_DT] joint refinement: data terms of every point and label
   const int32_t* yorder; // [N] correspondences of a slot sorted by image y (or null:
   const int32_t* ypos;   //     they already are), and the inverse permutation
   // the sweeps' candidate stream, per POSITION of the row-sorted order (ransac_gc_scan):
@@ -462,6 +464,7 @@ struct Work {
 };
 
 constexpr int GC_Q = 1 << 20;          // fixed point of the labelling energies
+constexpr int PEARL_DT = 9;            // = PEARL_MAX_K + 1 columns of Work::pearl_dt
 constexpr double LO_MIN_GAIN = 1e-6;   // relative MSAC gain below which the refits stop
 
 // b^e by binary exponentiation (multiplications only: every implementation of the
@@ -1121,7 +1124,7 @@ __device__ __forceinline__ bool gc_neighbours(const double* xy, const double* xy
 
 // a slot's neighbour lists (null cnt: not available, scan the window)
 constexpr int NB_W = 4;            // sub-lists per point (= waves of a sweep workgroup)
-constexpr int NB_SUB = 80;         // entries per sub-list: 320 neighbours per point
+constexpr int NB_SUB = 160;        // entries per sub-list: 640 neighbours per point
 struct NbLists {
   const uint16_t* cnt;
   const int16_t* pool;
@@ -1133,27 +1136,44 @@ __device__ __forceinline__ int64_t butterfly_sum_i64(int64_t v) {
   return v;
 }
 
-// Visits every ACTIVE neighbour o of point p (slot-local indices): f(o). Wave-wide.
-template <typename F>
+// Visits every ACTIVE neighbour of point p (slot-local index): f(q, valid), q = the
+// neighbour's POSITION in the row-sorted order (its index if the slot is not sorted) -- f is
+// called by every lane of the wave, `valid` says whether the lane holds a neighbour (q is a
+// safe position otherwise), so that f's own loads are unconditional and can be in flight
+// together. Callers keep what they look up per neighbour in position order: a neighbour is
+// then one list entry and one nearby byte, no order look-up. Wave-wide.
+// LISTS: the slot's neighbour lists are complete (Work::nb_ok) -- the caller's kernel is
+// instantiated once per case, because the window walk of the other case (fp64 distance
+// tests) costs the list walk three of eight waves per SIMD if both sit in one kernel.
+template <bool LISTS, typename F>
 __device__ __forceinline__ void for_each_neighbour(const double* xy, const double* xyz,
                                                    int64_t n, int32_t p,
                                                    const int32_t* yorder, const int32_t* ypos,
                                                    double rad, double s2, double r2, int lane,
                                                    const NbLists& nl, F f) {
-  const double yp = xy[2 * p + 1];
   const int64_t pos = ypos ? ypos[p] : p;
-  if (nl.cnt) {              // the slot's neighbour lists are complete: walk the point's
-#pragma unroll
-    for (int g = 0; g < NB_W; ++g) {
-      const int cntp = nl.cnt[pos * NB_W + g];
-      const int16_t* lst = nl.pool + (pos * NB_W + g) * NB_SUB;
-      for (int i = lane; i < cntp; i += 64) {
-        const int64_t op = pos + lst[i];
-        f(yorder ? yorder[op] : static_cast<int32_t>(op));
-      }
+  if constexpr (LISTS) {     // the slot's neighbour lists are complete: walk the point's
+    // One quarter-wave per sub-list, two entries per lane and trip: count -> list entries ->
+    // f's loads = THREE dependent round trips for up to 128 neighbours (round 4; one
+    // sub-list after the other with 64 lanes each, and an order look-up per neighbour, was
+    // 3 per sub-list + 1 = 13).
+    static_assert(NB_W == 4, "one quarter-wave per sub-list");
+    const int q = lane >> 4, l16 = lane & 15;
+    const int cntq = nl.cnt[pos * NB_W + q];
+    const int16_t* lst = nl.pool + (pos * NB_W + q) * NB_SUB;
+    int cmax = cntq;                                   // wave-uniform trip count
+    cmax = max(cmax, __shfl_xor(cmax, 16, 64));
+    cmax = max(cmax, __shfl_xor(cmax, 32, 64));
+    for (int i0 = 0; i0 < cmax; i0 += 32) {
+      const int ia = i0 + l16, ib = ia + 16;
+      const bool va = ia < cntq, vb = ib < cntq;
+      const int64_t pa = pos + (va ? lst[ia] : 0), pb = pos + (vb ? lst[ib] : 0);
+      f(pa, va);
+      f(pb, vb);
     }
     return;
   }
+  const double yp = xy[2 * p + 1];
   for (int dir = 0; dir < 2; ++dir) {
     for (int64_t j0 = dir ? pos + 1 : pos - 1; dir ? j0 < n : j0 >= 0; j0 += dir ? 64 : -64) {
       const int64_t j = dir ? j0 + lane : j0 - lane;
@@ -1165,7 +1185,7 @@ __device__ __forceinline__ void for_each_neighbour(const double* xy, const doubl
         near = !(fabs(yp - xy[2 * o + 1]) > rad);
       }
       if (!__any(near)) break;            // sorted by y: nothing further can be in range
-      if (near && gc_neighbours(xy, xyz, p, o, s2, r2)) f(o);
+      f(in ? j : pos, near && gc_neighbours(xy, xyz, p, o, s2, r2));
     }
   }
 }
@@ -1949,6 +1969,7 @@ __global__ __launch_bounds__(256) void ransac_refit_accept(
 // relabelling sweeps + one Gauss-Newton refit of every instance on its points, kept iff
 // the energy dropped (DESIGN.md "Pose fitting", step 6).
 constexpr int PEARL_MAX_K = 8;
+static_assert(PEARL_DT == PEARL_MAX_K + 1, "one data-term column per label incl. the outlier");
 constexpr int PEARL_BINS = 64;    // bins per energy sum (the workgroups' atomics spread over them)
 static_assert(4 * PEARL_BINS == 256, "pearl_begin zeroes the bins with one 256-thread workgroup");
 
@@ -1981,20 +2002,58 @@ __global__ __launch_bounds__(256) void pearl_begin(const int64_t* slot_base,
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * 256) {
     const int32_t l = labels_all[base + i];
-    w.lab_a[base + i] = static_cast<uint8_t>(l >= 0 && l < k ? l : k);
+    const int64_t pos = w.ypos ? w.ypos[base + i] : i;       // the sweeps' labels: position order
+    w.lab_a[base + pos] = static_cast<uint8_t>(l >= 0 && l < k ? l : k);
   }
   if (blockIdx.x == 0) w.pearl_acc[s * (4 * PEARL_BINS) + threadIdx.x] = 0ull;   // 4 x 64 bins
   if (blockIdx.x == 0 && threadIdx.x == 0) w.pearl_moved[s] = 0;
 }
 
-// which = 0: energy of (accepted poses, lab) -> acc[0..1]; 1: of (candidate poses, lab)
+// Data terms of every point of a slot against the k poses (which = 0: the accepted ones,
+// 1: the candidates of pearl_refit) -> Work::pearl_dt, one thread per point. The sweeps and
+// the energy pass then only walk neighbours: with the fp64 reprojection inside them, one
+// point per wave, 61 of 64 lanes idled through it and its registers cost the walk three of
+// eight waves per SIMD (79 us per sweep at C4's size, 40 for the walk alone, 12 for the
+// terms alone; profiles/r04). Same pearl_data_term, same integers.
+__global__ __launch_bounds__(256) void pearl_data(
+    const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
+    const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
+    const int32_t* __restrict__ num_models, EposFitParams prm, int max_k, Work w,
+    const double* __restrict__ poses, int which) {
+  const int s = blockIdx.y;
+  if (!w.pearl_state[s]) return;
+  if (which == 1 && !w.pearl_moved[s]) return;
+  const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
+  const int k = num_models[s];
+  const double* pp = which ? w.pearl_pose + static_cast<int64_t>(s) * PEARL_MAX_K * 12
+                           : poses + static_cast<int64_t>(s) * max_k * 12;
+  double K[9];
+  for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
+  const double tthr = 1.5 * prm.threshold, tthr2 = tthr * tthr;
+  const double thr2 = prm.threshold * prm.threshold;
+  const int32_t d_out = static_cast<int32_t>(
+      static_cast<int64_t>((thr2 / tthr2) * static_cast<double>(GC_Q)));
+  for (int64_t p = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; p < n;
+       p += static_cast<int64_t>(gridDim.x) * 256) {
+    int32_t* row = w.pearl_dt + (base + p) * PEARL_DT;
+    for (int m = 0; m < k; ++m)
+      row[m] = static_cast<int32_t>(
+          pearl_data_term(pp + 12 * m, K, xy_all + 2 * (base + p), xyz_all + 3 * (base + p), tthr2));
+    row[k] = d_out;
+  }
+}
+
+// which = 0: energy of (accepted poses, lab) -> acc[0..1]; 1: of (candidate poses, lab).
+// `lab_all`: labels in POSITION order; the data terms come from Work::pearl_dt (pearl_data
+// with the same `which` runs before this launch).
+template <bool LISTS>
 __global__ __launch_bounds__(256) void pearl_energy(
     const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
     const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
     const int32_t* __restrict__ num_models, EposFitParams prm, int max_k, Work w,
     const double* __restrict__ poses, const uint8_t* __restrict__ lab_all, int which) {
   const int s = blockIdx.y;
-  if (!w.pearl_state[s]) return;
+  if (!w.pearl_state[s] || (w.nb_ok[s] != 0) != LISTS) return;
   if (which == 1 && !w.pearl_moved[s]) return;
   const int lane = threadIdx.x & 63;
   const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
@@ -2002,16 +2061,10 @@ __global__ __launch_bounds__(256) void pearl_energy(
   const double* xyz = xyz_all + 3 * base;
   const uint8_t* lab = lab_all + base;
   const int k = num_models[s];
-  const double* pp = which ? w.pearl_pose + static_cast<int64_t>(s) * PEARL_MAX_K * 12
-                           : poses + static_cast<int64_t>(s) * max_k * 12;
-  double K[9];
-  for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
+  (void)poses; (void)Ks; (void)max_k;
   const double rad = prm.neighborhood_ball_radius;
   const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
   const double r2 = rad * rad;
-  const double tthr = 1.5 * prm.threshold, tthr2 = tthr * tthr;
-  const double thr2 = prm.threshold * prm.threshold;
-  const int64_t d_out = static_cast<int64_t>((thr2 / tthr2) * static_cast<double>(GC_Q));
   const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
   const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
   NbLists nl = {nullptr, nullptr};
@@ -2022,24 +2075,32 @@ __global__ __launch_bounds__(256) void pearl_energy(
   // of atomics per wave (the grid is sized for the pool's capacity) the 130 000 same-address
   // 64-bit atomics of a C4 image serialised at ~7 ns each -- 0.93 ms per launch, 6.4 ms of
   // fitting per image (profiles/r03/kernel_stats_c4_depth1_before.csv).
-  const int64_t want = (n + 15) / 16;
+  // (~2 points per wave since the neighbour walk became four round trips: the atomics are
+  // two per workgroup of 8 points, spread over 64 bins)
+  const int64_t want = (n + 7) / 8;
   const int wgs = static_cast<int>(want < 1 ? 1 : want < gridDim.x ? want : gridDim.x);
   if (static_cast<int>(blockIdx.x) >= wgs) return;
   const int nwaves = wgs * 4;
   unsigned long long data = 0, smooth = 0;
   for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nwaves) {
-    const int lp = lab[p];
+    const int lp = lab[ypos ? ypos[p] : p];
+    const int64_t dterm = w.pearl_dt[(base + p) * PEARL_DT + (lp < k ? lp : k)];
     int diff = 0, deg = 0;
-    for_each_neighbour(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2, lane,
-                       nl, [&](int32_t o) { ++deg; diff += lab[o] != lp; });
+    for_each_neighbour<LISTS>(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2, lane,
+                       nl, [&](int64_t q, bool valid) {
+                         const int lo = lab[q];
+                         deg += valid;
+                         diff += valid && lo != lp;
+                       });
     diff = butterfly_sum_i(diff);
     deg = butterfly_sum_i(deg);
     if (lane == 0) {
       // the FRACTION of disagreeing neighbours (degree-normalised Potts)
       if (deg > 0)
-        smooth += static_cast<unsigned long long>((static_cast<int64_t>(GC_Q) * diff) / deg);
-      data += static_cast<unsigned long long>(
-          lp < k ? pearl_data_term(pp + 12 * lp, K, xy + 2 * p, xyz + 3 * p, tthr2) : d_out);
+        smooth += LISTS ? static_cast<unsigned long long>(static_cast<uint32_t>(GC_Q * diff) /
+                                                          static_cast<uint32_t>(deg))
+                        : static_cast<unsigned long long>((static_cast<int64_t>(GC_Q) * diff) / deg);
+      data += static_cast<unsigned long long>(dterm);
     }
   }
   __shared__ unsigned long long s_sum[2];
@@ -2055,19 +2116,23 @@ __global__ __launch_bounds__(256) void pearl_energy(
                            (blockIdx.x & (PEARL_BINS - 1))], s_sum[threadIdx.x]);
 }
 
+template <bool LISTS>
 __global__ __launch_bounds__(256) void pearl_sweep(
     const double* __restrict__ xy_all, const double* __restrict__ xyz_all,
     const int64_t* __restrict__ slot_base, const double* __restrict__ Ks,
     const int32_t* __restrict__ num_models, EposFitParams prm, int max_k, Work w,
     const double* __restrict__ poses, const uint8_t* __restrict__ lab_in_all,
-    uint8_t* __restrict__ lab_out_all, int with_energy) {
+    uint8_t* __restrict__ lab_out_all, int with_energy, uint8_t* __restrict__ lab_idx_all) {
+  // lab_in / lab_out: labels in POSITION order (row-sorted; what the neighbour walk indexes);
+  // lab_idx_all (the last sweep of an iteration, else null): the same labels in index order
+  // for pearl_refit / pearl_commit. Data terms: Work::pearl_dt (pearl_data runs before).
   // with_energy (the FIRST sweep of an iteration): the energy of (poses, lab_in) -- the
   // "before" of pearl_commit's comparison -- falls out of this pass: a point's disagreeing
   // neighbours are deg - cnt[its label] and its data term is one of the k + 1 this pass
   // evaluates anyway. Round 4: that removed two of the four pearl_energy launches per call
   // (81 us each at C4's size); same integers, same bins.
   const int s = blockIdx.y;
-  if (!w.pearl_state[s]) return;
+  if (!w.pearl_state[s] || (w.nb_ok[s] != 0) != LISTS) return;
   const int lane = threadIdx.x & 63;
   const int64_t base = slot_base[s], n = slot_base[s + 1] - base;
   const double* xy = xy_all + 2 * base;
@@ -2075,15 +2140,10 @@ __global__ __launch_bounds__(256) void pearl_sweep(
   const uint8_t* lab_in = lab_in_all + base;
   uint8_t* lab_out = lab_out_all + base;
   const int k = num_models[s];
-  const double* pp = poses + static_cast<int64_t>(s) * max_k * 12;
-  double K[9];
-  for (int i = 0; i < 9; ++i) K[i] = Ks[s * 9 + i];
+  (void)poses; (void)Ks; (void)max_k;
   const double lam = prm.spatial_coherence_weight, rad = prm.neighborhood_ball_radius;
   const double s2 = prm.scaling_from_millimeters * prm.scaling_from_millimeters;
   const double r2 = rad * rad;
-  const double tthr = 1.5 * prm.threshold, tthr2 = tthr * tthr;
-  const double thr2 = prm.threshold * prm.threshold;
-  const int64_t d_out = static_cast<int64_t>((thr2 / tthr2) * static_cast<double>(GC_Q));
   const int32_t* yorder = w.yorder ? w.yorder + base : nullptr;
   const int32_t* ypos = w.ypos ? w.ypos + base : nullptr;
   NbLists nl = {nullptr, nullptr};
@@ -2091,44 +2151,82 @@ __global__ __launch_bounds__(256) void pearl_sweep(
   const int nwaves = gridDim.x * 4;
   unsigned long long e_data = 0, e_smooth = 0;
   for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nwaves) {
-    int cnt[PEARL_MAX_K + 1];
+    // Lane m (m <= k) owns label m: its data term, then (after the walk) its cost.
+    const int64_t pos = ypos ? ypos[p] : p;
+    const int lp = lab_in[pos];
+    const int ml = lane <= k ? lane : k;
+    const int64_t D = w.pearl_dt[(base + p) * PEARL_DT + ml];
+    int deg = 0, mine = 0;
+    if constexpr (LISTS) {
+      // at most 640 neighbours: the nine label counts ride in three words, ten bits each
+      // (a third of the registers and of the wave reductions; the sums are the same integers)
+      static_assert(NB_W * NB_SUB < 1024 && PEARL_MAX_K + 1 <= 9, "three 10-bit fields per word");
+      unsigned pk[3] = {0u, 0u, 0u};
+      for_each_neighbour<true>(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2,
+                               lane, nl, [&](int64_t q, bool valid) {
+                                 const unsigned l = lab_in[q];
+                                 const unsigned wd = l / 3u, sh = 10u * (l - 3u * wd);
+                                 const unsigned one = valid && l <= PEARL_MAX_K ? 1u << sh : 0u;
 #pragma unroll
-    for (int m = 0; m <= PEARL_MAX_K; ++m) cnt[m] = 0;
-    for_each_neighbour(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2, lane,
-                       nl, [&](int32_t o) {
-                         const int lo = lab_in[o];
+                                 for (int i = 0; i < 3; ++i) pk[i] += wd == i ? one : 0u;
+                               });
 #pragma unroll
-                         for (int m = 0; m <= PEARL_MAX_K; ++m) cnt[m] += lo == m;
-                       });
-    int deg = 0;
+      for (int i = 0; i < 3; ++i) {
+        pk[i] = static_cast<unsigned>(butterfly_sum_i(static_cast<int>(pk[i])));
 #pragma unroll
-    for (int m = 0; m <= PEARL_MAX_K; ++m) { cnt[m] = butterfly_sum_i(cnt[m]); deg += cnt[m]; }
-    if (lane == 0) {
-      int best = 0;
-      double best_c = 0.0;
-      const int lp = lab_in[p];
-#pragma unroll
-      for (int m = 0; m <= PEARL_MAX_K; ++m) {
-        if (m <= k) {
-          const int64_t D = m < k ? pearl_data_term(pp + 12 * m, K, xy + 2 * p, xyz + 3 * p, tthr2)
-                                  : d_out;
-          const int64_t sm = deg > 0 ? (static_cast<int64_t>(GC_Q) * (deg - cnt[m])) / deg : 0;
-          const double c = (1.0 - lam) * static_cast<double>(D) + lam * static_cast<double>(sm);
-          if (m == 0 || c < best_c) { best = m; best_c = c; }
-          if (with_energy && (m == lp || (m == k && lp >= k))) {
-            e_data += static_cast<unsigned long long>(D);
-            e_smooth += static_cast<unsigned long long>(sm);
-          }
+        for (int j = 0; j < 3; ++j) {
+          const int c = static_cast<int>((pk[i] >> (10 * j)) & 1023u);
+          deg += c;
+          mine = lane == 3 * i + j ? c : mine;
         }
       }
-      lab_out[p] = static_cast<uint8_t>(best);
+    } else {
+      int cnt[PEARL_MAX_K + 1];
+#pragma unroll
+      for (int m = 0; m <= PEARL_MAX_K; ++m) cnt[m] = 0;
+      for_each_neighbour<false>(xy, xyz, n, static_cast<int32_t>(p), yorder, ypos, rad, s2, r2,
+                                lane, nl, [&](int64_t q, bool valid) {
+                                  const int l = lab_in[q];
+                                  const int lo = valid ? l : -1;
+#pragma unroll
+                                  for (int m = 0; m <= PEARL_MAX_K; ++m) cnt[m] += lo == m;
+                                });
+#pragma unroll
+      for (int m = 0; m <= PEARL_MAX_K; ++m) {
+        cnt[m] = butterfly_sum_i(cnt[m]);
+        deg += cnt[m];
+        mine = lane == m ? cnt[m] : mine;
+      }
+    }
+    // lane m: the cost of label m (same expressions as before, one label per lane)
+    // (with lists a point has at most NB_W * NB_SUB = 640 neighbours: the quotient's
+    // numerator stays below 2^29 and a 32-bit division gives the same integer)
+    static_assert(static_cast<int64_t>(GC_Q) * NB_W * NB_SUB < (1ll << 31), "32-bit quotient");
+    const int64_t sm = deg <= 0 ? 0
+        : LISTS ? static_cast<int64_t>(static_cast<uint32_t>(GC_Q * (deg - mine)) /
+                                       static_cast<uint32_t>(deg))
+                : (static_cast<int64_t>(GC_Q) * (deg - mine)) / deg;
+    const double c = (1.0 - lam) * static_cast<double>(D) + lam * static_cast<double>(sm);
+    int best = 0;
+    double best_c = __shfl(c, 0, 64);
+    for (int m = 1; m <= k; ++m) {                      // k is uniform; first minimum wins
+      const double cm = __shfl(c, m, 64);
+      if (cm < best_c) { best = m; best_c = cm; }
+    }
+    if (lane == 0) {
+      lab_out[pos] = static_cast<uint8_t>(best);
+      if (lab_idx_all) lab_idx_all[base + p] = static_cast<uint8_t>(best);
+    }
+    if (with_energy && (lane == lp || (lane == k && lp >= k)) && lane <= k) {
+      e_data += static_cast<unsigned long long>(D);
+      e_smooth += static_cast<unsigned long long>(sm);
     }
   }
   if (with_energy) {                        // as pearl_energy(which = 0): acc[0], acc[1]
     __shared__ unsigned long long s_sum[2];
     if (threadIdx.x < 2) s_sum[threadIdx.x] = 0ull;
     __syncthreads();
-    if (lane == 0) {
+    if (lane <= PEARL_MAX_K && (e_data | e_smooth) != 0ull) {   // the lanes that own labels
       atomicAdd(&s_sum[0], e_data);
       atomicAdd(&s_sum[1], e_smooth);
     }
@@ -2221,7 +2319,7 @@ struct Layout {
   int64_t hyp_score, hyp_pose, hyp_count, active, n_active, done, inl_bits, total;
   int64_t words_total;
   int64_t cur_pose, cur_score, cur_count, state, tries, last_new, gq, lab_a, lab_b;
-  int64_t pearl_pose, pearl_acc, pearl_state, pearl_moved;
+  int64_t pearl_pose, pearl_acc, pearl_state, pearl_moved, lab_c, pearl_dt;
   int64_t lo_cnt, lo_data, lo_timeout;
   int64_t nb_cnt, nb_pool, nb_ok;
   int64_t geo, dyn_a, dyn_b, win, acc, flip_a, flip_b;
@@ -2268,6 +2366,8 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.pearl_acc = off; off = align_up(off + (S + 1) * 4 * PEARL_BINS * 8);
   L.pearl_state = off; off = align_up(off + (S + 1) * 4);
   L.pearl_moved = off; off = align_up(off + (S + 1) * 4);
+  L.lab_c = off; off = align_up(off + n_cap + 1);
+  L.pearl_dt = off; off = align_up(off + (n_cap + 1) * PEARL_DT * 4);
   L.total = off;
   return L;
 }
@@ -2300,6 +2400,8 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   w.gq = reinterpret_cast<int32_t*>(wb + L.gq);
   w.lab_a = reinterpret_cast<uint8_t*>(wb + L.lab_a);
   w.lab_b = reinterpret_cast<uint8_t*>(wb + L.lab_b);
+  w.lab_c = reinterpret_cast<uint8_t*>(wb + L.lab_c);
+  w.pearl_dt = reinterpret_cast<int32_t*>(wb + L.pearl_dt);
   w.yorder = yorder;
   w.ypos = ypos;
   w.lo_cnt = reinterpret_cast<unsigned*>(wb + L.lo_cnt);
@@ -2362,7 +2464,8 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   const int rounds = max_k + (max_k > 1 ? 2 : 0);
   // joint refinement kernels: one wavefront per point and pass
   const int64_t per_slot = ceil_div(n_capacity, S > 0 ? S : 1);
-  const dim3 pgrid(static_cast<unsigned>(per_slot < 8192 ? ceil_div(per_slot, 4) < 64 ? 64 : ceil_div(per_slot, 4) : 2048), S);
+  static const int pearl_wgs = [] { const char* e = getenv("EPOS_PEARL_WGS"); return e ? atoi(e) : 2048; }();
+  const dim3 pgrid(static_cast<unsigned>(per_slot < 4 * pearl_wgs ? ceil_div(per_slot, 4) < 64 ? 64 : ceil_div(per_slot, 4) : pearl_wgs), S);
   // labelling sweeps: one workgroup per tile of 64 points (grid-stride beyond 512 tiles)
   const int64_t tiles = ceil_div(per_slot, 64);
   const dim3 sgrid(static_cast<unsigned>(tiles < 1 ? 1 : tiles > 512 ? 512 : tiles), S);
@@ -2422,20 +2525,37 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
       hipLaunchKernelGGL(pearl_begin, pgrid, dim3(256), 0, st, slot_base, num_models, w, labels);
       // the energy of (accepted poses, current labels) comes out of the first sweep
       // (pearl_setup admits a slot only with gc_sweeps >= 1)
+      // (sweep labels live in position order: lab_a / lab_b; the last sweep also writes them
+      // in index order into lab_c for the refit and the commit)
+      const dim3 dgrid(static_cast<unsigned>(pgrid.x < 4 ? 1 : pgrid.x / 4), S);
+      const dim3 fgrid(pgrid.x < 256 ? pgrid.x : 256, S);
+      hipLaunchKernelGGL(pearl_data, dgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks, num_models,
+                         *p, max_k, w, poses, 0);
       const uint8_t* lab_final = w.lab_a;
       for (int sw = 0; sw < p->gc_sweeps; ++sw) {
         const uint8_t* in = (sw & 1) ? w.lab_b : w.lab_a;
         uint8_t* out = (sw & 1) ? w.lab_a : w.lab_b;
-        hipLaunchKernelGGL(pearl_sweep, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
-                           num_models, *p, max_k, w, poses, in, out, sw == 0 ? 1 : 0);
+        // (one launch per case of Work::nb_ok; the slots of the other case leave at once.
+        // The window-walk case is the rare one -- a sub-list overflowed -- and gets the
+        // small grid: its launch is ~2 us of empty workgroups otherwise)
+        hipLaunchKernelGGL(pearl_sweep<true>, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                           num_models, *p, max_k, w, poses, in, out, sw == 0 ? 1 : 0,
+                           sw + 1 == p->gc_sweeps ? w.lab_c : nullptr);
+        hipLaunchKernelGGL(pearl_sweep<false>, fgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                           num_models, *p, max_k, w, poses, in, out, sw == 0 ? 1 : 0,
+                           sw + 1 == p->gc_sweeps ? w.lab_c : nullptr);
         lab_final = out;
       }
       hipLaunchKernelGGL(pearl_refit, dim3(S), dim3(256), 0, st, xy, xyz, slot_base, Ks,
-                         num_models, *p, max_k, w, poses, lab_final);
-      hipLaunchKernelGGL(pearl_energy, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                         num_models, *p, max_k, w, poses, w.lab_c);
+      hipLaunchKernelGGL(pearl_data, dgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks, num_models,
+                         *p, max_k, w, poses, 1);
+      hipLaunchKernelGGL(pearl_energy<true>, pgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
+                         num_models, *p, max_k, w, w.pearl_pose, lab_final, 1);
+      hipLaunchKernelGGL(pearl_energy<false>, fgrid, dim3(256), 0, st, xy, xyz, slot_base, Ks,
                          num_models, *p, max_k, w, w.pearl_pose, lab_final, 1);
       hipLaunchKernelGGL(pearl_commit, dim3(S), dim3(256), 0, st, slot_base, num_models, *p,
-                         max_k, w, poses, lab_final, labels);
+                         max_k, w, poses, w.lab_c, labels);
       rc = launch_status("pearl");
       if (rc) return rc;
     }

@@ -580,13 +580,16 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
              a8 = reinterpret_cast<uint64_t>(gp->zero_chunk), l0 = static_cast<uint64_t>(q.lda),
              l1 = static_cast<uint64_t>(q.ldc), l2 = static_cast<uint64_t>(q.ldr);
     int i0 = q.M, i1 = q.N, i2 = q.K, i3 = q.relu, i4 = q.sub, i5 = gp->tiles_n[0],
-        i6 = gp->tile_start[MAX_GROUP];
+        i6 = gp->tile_start[MAX_GROUP], i7 = q.Ho, i8 = q.Wo, i9 = q.Hi, i10 = q.Wi,
+        i11 = q.c_stream, i12 = q.softmax64;
+    uint64_t a9 = reinterpret_cast<uint64_t>(q.col_sums), l3 = static_cast<uint64_t>(q.col_ld);
     unsigned u0 = gp->tn_mul[0], u1 = gp->tn_sh1[0], u2 = gp->tn_sh2[0];
     float f0 = q.a_gain, f1 = q.a_bias;
     asm volatile("" : : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(a6), "s"(a7),
                  "s"(a8), "s"(l0), "s"(l1), "s"(l2));
     asm volatile("" : : "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5), "s"(i6), "s"(u0),
                  "s"(u1), "s"(u2), "s"(f0), "s"(f1));
+    asm volatile("" : : "s"(i7), "s"(i8), "s"(i9), "s"(i10), "s"(i11), "s"(i12), "s"(a9), "s"(l3));
   }
   int bid;
   if constexpr (DW) {

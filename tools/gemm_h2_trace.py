@@ -4,7 +4,8 @@ prologue issued -> first stage landed (K loop starts) -> K loop done -> stores a
 and how much of a back-to-back launch (HIP events) lies outside the kernel's own span.
 
     python tools/gemm_h2_trace.py build      # here (cross-compile)
-    python tools/gemm_h2_trace.py [M N K [res]]   # on the GPU box
+    python tools/gemm_h2_trace.py [--evict] [M N K [res]]   # on the GPU box
+(--evict: a launch of another kernel variant before the traced one: cold instruction caches)
 """
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,8 +18,12 @@ if len(sys.argv) > 1 and sys.argv[1] == 'build':
   sys.exit(0)
 import numpy as np, torch
 from epos_amd import _lib
+EVICT = '--evict' in sys.argv
+sys.argv = [x for x in sys.argv if x != '--evict']
 build.LIB_PATH = PATH
-_lib._build.LIB_PATH = PATH
+_lib._EVICT = '--evict' in sys.argv
+sys.argv = [x for x in sys.argv if x != '--evict']
+build.LIB_PATH = PATH
 lib = _lib.load()
 def p(t): return ctypes.c_void_p(t.data_ptr())
 shapes = [(4800, 728, 728, 0), (4800, 728, 728, 1), (19200, 256, 256, 0), (4800, 2048, 1536, 0), (19200, 4032, 256, 0)]
@@ -47,9 +52,25 @@ for (m, n, k, res) in shapes:
   for _ in range(50): lib.epos_pointwise_conv_f32(ctypes.byref(a), None)
   e1.record(); torch.cuda.synchronize()
   us = e0.elapsed_time(e1) / 50 * 1e3
-  raw.epos_debug_set_gemm_trace(ctypes.c_void_p(tr.data_ptr()))
-  for _ in range(3): lib.epos_pointwise_conv_f32(ctypes.byref(a), None)
-  torch.cuda.synchronize()
+  if EVICT:
+    # the traced launch follows a launch of ANOTHER variant of the kernel over the whole chip
+    # (residual epilogue, fp32 A: ~40 KB of different code through every instruction cache),
+    # as in the plan, where a depthwise launch sits between two GEMMs
+    R2 = torch.randn(m, n, device='cuda'); C2 = torch.empty(m, n, device='cuda')
+    ev = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Wh), bias=p(bias), R=p(R2) if not res else None, ldr=n,
+                            C=p(C2), ldc=n, M=m, N=n, K=k, relu=1, relu_in=0, sub=1, Wh=p(Wh),
+                            a_amax=p(slot), c_amax=p(cs))
+    for _ in range(3):
+      raw.epos_debug_set_gemm_trace(ctypes.c_void_p(0))
+      lib.epos_pointwise_conv_f32(ctypes.byref(ev), None)
+      torch.cuda.synchronize()
+      raw.epos_debug_set_gemm_trace(ctypes.c_void_p(tr.data_ptr()))
+      lib.epos_pointwise_conv_f32(ctypes.byref(a), None)
+      torch.cuda.synchronize()
+  else:
+    raw.epos_debug_set_gemm_trace(ctypes.c_void_p(tr.data_ptr()))
+    for _ in range(3): lib.epos_pointwise_conv_f32(ctypes.byref(a), None)
+    torch.cuda.synchronize()
   raw.epos_debug_set_gemm_trace(ctypes.c_void_p(0))
   t = tr.cpu().numpy().reshape(-1, 8)
   t = t[t[:, 0] > 0]

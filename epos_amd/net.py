@@ -44,6 +44,50 @@ def scale_dimension(dim, scale):
 _CAPTURE_STREAMS = {}
 
 
+class _Branches(object):
+  """EPOS_GRAPH_BRANCHES=1 (opt-in, for one image at a time): the launches that do not lie on
+  the plan's critical path -- the shortcut conv of an Xception module (independent of the
+  module's three separable convs until the add: net_xception.py:296-302) and the image-pooling
+  branch (independent of the ASPP convs until the concat: model.py:213-258) -- go to a second
+  stream between a fork event and a join event; captured into the hipGraph they become
+  parallel branches. Same kernels, same arguments, same bits."""
+
+  def __init__(self, net):
+    self.net = net
+    self.main = torch.cuda.current_stream(net.dev)
+    self.side = net._branch_stream()
+    self.side_raw = ctypes.c_void_p(self.side.cuda_stream)
+    self.open = False                 # side stream holds work the main stream has not joined
+
+  @staticmethod
+  def is_side(name):
+    return name.endswith('xception_module/shortcut') or name.startswith('image_pooling')
+
+  @staticmethod
+  def joins(name):
+    return name.endswith('/separable_conv3_pointwise') or name == 'concat_projection'
+
+  def run(self, name, fn, s):
+    if self.is_side(name):
+      if not self.open:               # fork: everything the branch reads has been enqueued
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+      fn(self.side_raw)
+      self.open = True
+      return
+    if self.open and self.joins(name):
+      self.join()
+    fn(s)
+
+  def join(self):
+    if self.open:
+      ev = torch.cuda.Event()
+      ev.record(self.side)
+      self.main.wait_event(ev)
+      self.open = False
+
+
 def _capture_stream(dev):
   """One shared side stream per device for graph capture from the default stream."""
   key = str(dev)
@@ -106,6 +150,7 @@ class EposNet(object):
     # (csrc/pointwise_gemm_h2.hip). Same bits as the two launches with fp16-pair
     # intermediates either way.
     self.fuse_sepconv = os.environ.get('EPOS_SEPCONV_FUSED', '0') == '1'
+    self.graph_branches = os.environ.get('EPOS_GRAPH_BRANCHES', '0') == '1'
     self.fused_sepconvs = []
     self.sepconv_stats = torch.zeros(2, dtype=torch.int32, device=self.dev)
     # Absmax slots (include/epos_hip.h): the fp16-pair GEMM scales its fp32 A operand by a
@@ -1015,6 +1060,11 @@ class EposNet(object):
   def _stream(self):
     return ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
+  def _branch_stream(self):
+    if getattr(self, '_bstream', None) is None:
+      self._bstream = torch.cuda.Stream(self.dev)
+    return self._bstream
+
   def sync_current(self):
     torch.cuda.current_stream(self.dev).synchronize()
 
@@ -1027,6 +1077,7 @@ class EposNet(object):
     of the last full run, and softmax applied to them again and again would flatten them
     (the stages downstream would then see no -- or, with one object, all -- pixels)."""
     s = self._stream()
+    br = _Branches(self) if self.graph_branches else None
     if not sparse:
       post = with_post and 'post' not in skip_kinds
       fuse = post and getattr(self, '_fuse_head_softmax', False)
@@ -1035,15 +1086,24 @@ class EposNet(object):
           continue
         if fuse and name == self._heads_name:
           self._heads_fused(s)          # the heads with the fragment softmax in the epilogue
+        elif br is not None:
+          br.run(name, fn, s)
         else:
           fn(s)
+      if br is not None:
+        br.join()
       if post:
         for name, fn in self.post_ops:
           if not (fuse and name == 'softmax_frag'):
             fn(s)
       return
-    for _, fn in self.ops[:self._n_trunk_ops]:
-      fn(s)
+    for name, fn in self.ops[:self._n_trunk_ops]:
+      if br is not None:
+        br.run(name, fn, s)
+      else:
+        fn(s)
+    if br is not None:
+      br.join()
     self._obj_head_op[1](s)
     for name, fn in self.post_ops:
       if name != 'softmax_frag':

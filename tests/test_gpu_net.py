@@ -262,3 +262,31 @@ def test_folded_image_pooling_and_slot_clear_match_the_separate_launches(monkeyp
     for k in ('pred_obj_conf', 'pred_frag_conf', 'pred_frag_loc'):
       a, b = out0[k].float(), out1[k].float()
       assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), k
+
+
+def test_graph_branches_give_the_same_network_bits(monkeypatch):
+  """EPOS_GRAPH_BRANCHES=1 (opt-in): the Xception shortcut convs and the image-pooling branch on
+  a second stream between fork and join events (parallel branches of the captured hipGraph,
+  net_xception.py:296-302, model.py:213-258) -- every output bit for bit against the linear
+  plan, eagerly and as a replayed graph, many replays (a missing join would race)."""
+  from epos_amd import model, weights
+  num_objs, h, w = 3, 96, 128
+  ckpt = weights.random_init(num_objs=num_objs, seed=7, randomize_bn=True, logits_std=0.5)
+  img = torch.from_numpy(
+      np.random.RandomState(2).randint(0, 256, (1, h, w, 3)).astype('f')).cuda()
+  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
+  monkeypatch.setenv('EPOS_GRAPH_BRANCHES', '0')
+  net0 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=40)
+  out0 = {k: v.clone() for k, v in net0.forward(img).items()}
+  monkeypatch.setenv('EPOS_GRAPH_BRANCHES', '1')
+  net1 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=41)
+  assert net1.graph_branches and not net0.graph_branches
+  side = torch.cuda.Stream()
+  for rep in range(12):
+    with torch.cuda.stream(side if rep % 2 else torch.cuda.current_stream()):
+      out1 = net1.forward(img, use_graph=rep > 1)
+    torch.cuda.synchronize()
+    for k in out0:
+      assert torch.equal(out0[k], out1[k]), (k, rep)
+    assert torch.equal(net0.encoder, net1.encoder)
+    assert torch.equal(net0.decoder_out, net1.decoder_out)

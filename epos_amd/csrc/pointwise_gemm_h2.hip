@@ -38,6 +38,15 @@
 // half (7 VALU per pair of values: pk_mul, cvt_pk, 2 cvt, pk_add, pk_mul, cvt_pk). Implicit
 // 3x3 conv mode, grouped launches, strided-row shortcut form, XCD-aware / banded tile order
 // and the float4 epilogue are the split kernel's.
+//
+// Round 4: the activation may arrive already split by its producer (PRESPLIT: no conversion in
+// the loop); the epilogue publishes the output's absmax with ONE atomic per workgroup (912
+// same-line atomics kept a middle-flow launch alive 2 us after its last store), can write
+// streaming stores, 32-row block sums and a softmax over groups of 64 columns; the fused
+// separable conv's producer phase (DW) lives here too. Launch shapes besides the default
+// (template parameters NB, NW, NST; same bits in all of them): 128 x 64 tiles for launches of
+// few tiles (default: up to 100), eight waves per tile ("latency mode", opt-in), any ring
+// depth. What they measure, and why the default shape wins: DESIGN.md (e) "Round 4".
 #include <string.h>
 
 #include <mutex>

@@ -88,6 +88,11 @@ def parse_args():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=20)
   ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--timed-repeats', type=int, default=5,
+                  help='the timed region of --steps steps is run this many times back to back, '
+                       'each bracketed by barrier + synchronize on both sides; value = all '
+                       'images / all region time (a 20-step region is ~50 ms: one region '
+                       'cannot resolve a 1 %% change), the regions\' spread is reported')
   ap.add_argument('--batch-per-gpu', type=int, default=None,
                   help='images per GPU per step; default 1 at --gpus 1 (config C2), 4 '
                        'at --gpus > 1 (the per-GPU shard of config C3: 32 images / 8)')
@@ -372,6 +377,43 @@ def gemm_roofline(pipe, steps):
   }, per
 
 
+SMI = '/opt/rocm/bin/rocm-smi'
+
+
+def smi_device_index(dev_index):
+  """rocm-smi's index of the HIP device that is benchmarked (HIP_VISIBLE_DEVICES may renumber
+  the devices): matched by PCI bus id; None when rocm-smi is missing or nothing matches."""
+  import re
+  import subprocess
+  if not os.path.exists(SMI):
+    return None
+  try:
+    pr = torch.cuda.get_device_properties(dev_index)
+    want = '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+    out = subprocess.run([SMI, '--showbus'], capture_output=True, text=True, timeout=10).stdout
+    rows = re.findall(r'GPU\[(\d+)\]\s*:\s*PCI Bus:\s*([0-9a-fA-F:.]+)', out)
+    for idx, bus in rows:
+      if bus.lower().startswith(want):
+        return int(idx)
+    return int(rows[0][0]) if len(rows) == 1 else None
+  except Exception:
+    return None
+
+
+def smi_sample(idx):
+  """(socket power in W, sclk in MHz) of rocm-smi device `idx`, or (None, None)."""
+  import re
+  import subprocess
+  try:
+    o = subprocess.run([SMI, '-d', str(idx), '--showpower', '--showclocks'],
+                       capture_output=True, text=True, timeout=5).stdout
+    m_ = re.search(r'Power \(W\): ([0-9.]+)', o)
+    c_ = re.search(r'sclk clock level[^(]*\(([0-9.]+)Mhz\)', o)
+    return (float(m_.group(1)) if m_ else None), (float(c_.group(1)) if c_ else None)
+  except Exception:
+    return None, None
+
+
 def main():
   args = parse_args()
   rank, world, local_rank = edist.init_from_env()
@@ -385,6 +427,13 @@ def main():
   dev_index = int(os.environ.get('EPOS_FORCE_DEVICE', local_rank))
   torch.cuda.set_device(dev_index)
   dev = 'cuda:%d' % dev_index
+  # the box's idle power, before this process has put any work on the device
+  smi_index = smi_device_index(dev_index) if (world == 1 and not args.no_roofline) else None
+  idle_w = None
+  if smi_index is not None:
+    idle = [smi_sample(smi_index)[0] for _ in range(3)]
+    idle = [w for w in idle if w is not None]
+    idle_w = round(float(np.mean(idle)), 0) if idle else None
   if args.batch_per_gpu is None:
     args.batch_per_gpu = 1 if world == 1 else 4
   B = args.batch_per_gpu
@@ -471,14 +520,26 @@ def main():
     pipes[j].launch(imgs, Ks, tg, image_ids=idx, seed=0)
     pipes[j].collect()
   torch.cuda.synchronize()
+  def timed_regions(first):
+    """R = --timed-repeats regions of EXACTLY --steps steps each, every one bracketed by
+    barrier + synchronize on both sides and reduced to its maximum over the ranks.
+    Returns (seconds per region, poses of the last region)."""
+    secs, poses = [], 0
+    for r in range(max(1, args.timed_repeats)):
+      torch.cuda.synchronize()
+      edist.barrier()
+      t0 = time.perf_counter()
+      poses = len(run(first + r * args.steps, args.steps))
+      torch.cuda.synchronize()
+      edist.barrier()
+      secs.append(edist.max_over_ranks(time.perf_counter() - t0))
+    return secs, poses
+
   run(0, args.warmup)
-  torch.cuda.synchronize()
-  edist.barrier()
-  t0 = time.perf_counter()
-  n_poses = len(run(args.warmup, args.steps)) / max(world, 1)
-  torch.cuda.synchronize()
-  edist.barrier()
-  elapsed = edist.max_over_ranks(time.perf_counter() - t0)
+  region_s, n_poses = timed_regions(args.warmup)
+  n_poses /= max(world, 1)
+  repeats = len(region_s)
+  elapsed = sum(region_s) / repeats           # seconds per region of --steps steps
 
   # correspondence statistics of the last step (work actually done by corr/RANSAC)
   totals = pipes[(args.warmup + args.steps - 1) % depth].last_totals
@@ -489,6 +550,14 @@ def main():
       'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world,
       'steps': args.steps, 'warmup': args.warmup,
       'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+      'timed_repeats': repeats,
+      'timed_regions': {
+          'images_per_sec_min': round(args.steps * B * world / max(region_s), 2),
+          'images_per_sec_max': round(args.steps * B * world / min(region_s), 2),
+          'ms_per_step_each': [round(x / args.steps * 1e3, 4) for x in region_s],
+          'note': 'value = (timed_repeats x steps x images per step) / (sum of the regions\' '
+                  'times); every region is exactly `steps` steps between barrier + '
+                  'synchronize pairs, maximum over the ranks'},
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
       'config': {
@@ -558,13 +627,8 @@ def main():
         with torch.cuda.stream(p_.stream):
           p_.net.capture_alt(kinds)
       run(0, min(args.warmup, 3))
-      torch.cuda.synchronize()
-      edist.barrier()
-      ta = time.perf_counter()
-      run(args.warmup, args.steps)
-      torch.cuda.synchronize()
-      edist.barrier()
-      decomp[kinds[0]] = edist.max_over_ranks(time.perf_counter() - ta) / args.steps * 1e3
+      alt_s, _ = timed_regions(args.warmup)
+      decomp[kinds[0]] = sum(alt_s) / len(alt_s) / args.steps * 1e3
     for p_ in pipes:
       p_.net.capture_alt(None)
   # shader clock under the same load: a few extra steps with a spinning probe wave
@@ -579,25 +643,21 @@ def main():
   # run; rank 0 of a one-GPU run only): the step runs close to the 1400 W cap, so the
   # matrix pipe's share of the energy is what is left to win. MFMA-only power at the same
   # clock: profiles/r04/power_by_component_h2.txt.
-  power_w = None
+  power_w = sclk_mhz = None
   if world == 1 and not args.no_roofline:
-    import re
-    import subprocess
     import threading
-    smi, samples = '/opt/rocm/bin/rocm-smi', []
-    if os.path.exists(smi):
+    samples, clocks = [], []
+    if smi_index is not None:
       stop = [False]
 
       def sampler():
         while not stop[0]:
-          try:
-            o = subprocess.run([smi, '--showpower'], capture_output=True, text=True,
-                               timeout=5).stdout
-            m_ = re.search(r'Power \(W\): ([0-9.]+)', o)
-            if m_:
-              samples.append(float(m_.group(1)))
-          except Exception:
+          w, c = smi_sample(smi_index)
+          if w is None:
             break
+          samples.append(w)
+          if c:
+            clocks.append(c)
       th = threading.Thread(target=sampler, daemon=True)
       th.start()
       t_end = time.perf_counter() + 1.2
@@ -608,6 +668,8 @@ def main():
       th.join(timeout=6)
       if len(samples) > 1:
         power_w = round(float(np.mean(samples[1:])), 0)
+      if len(clocks) > 1:
+        sclk_mhz = round(float(np.mean(clocks[1:])), 0)
   # Strictly serial steps (ONE plan, depth 1: C2's "batch = 1" read as latency) and the
   # per-stage HIP-event split of such a step (the reference prints the same three
   # stages per image, scripts/infer.py:730-734). Every rank runs them (run() gathers).
@@ -661,13 +723,19 @@ def main():
                 'GEMMs are 99 % of the flops at ~150 flop/B), not by HBM'}
     if power_w:
       roof['power_w'] = power_w
+      roof['idle_power_w'] = idle_w
+      roof['sclk_mhz_rocm_smi'] = sclk_mhz
       need = value / world * pipe.net.flops / B * 3 / 1e12      # fp16 piece products / s
-      roof['power_note'] = ('socket power (rocm-smi) while the same pipelined steps run; cap '
-                            '1400 W, idle ~280 W. This step needs %.0f fp16-TFLOP/s of piece '
-                            'products; bare MFMAs deliver 1490-1670 at 1310-1320 W '
-                            '(profiles/r04/power_by_component_h2.txt), i.e. ~0.7 pJ per flop '
-                            'above idle: the matrix pipe accounts for about %.0f %% of the '
-                            'power above idle' % (need, 100.0 * need * 0.7 / max(power_w - 280.0, 1.0)))
+      roof['power_note'] = ('MEASURED: power_w / sclk_mhz_rocm_smi = rocm-smi -d %d (the '
+                            'benchmarked device, matched by PCI bus id) sampled while the same '
+                            'pipelined steps run, idle_power_w = the same device before this '
+                            'process launched anything; cap 1400 W. This step needs %.0f '
+                            'fp16-TFLOP/s of piece products.' % (smi_index, need))
+      # a MODEL, not a measurement: the constants are profiles/r04/power_by_component_h2.txt's
+      # (bare MFMAs: 1490-1670 fp16-TFLOP/s at 1310-1320 W -> ~0.7 pJ per flop above idle)
+      roof['power_model_estimate'] = {
+          'mfma_share_of_power_above_idle': round(need * 0.7 / max(power_w - (idle_w or 280.0), 1.0), 2),
+          'assumes': '0.7 pJ per fp16 flop above idle (profiles/r04/power_by_component_h2.txt)'}
     if core_mhz:
       # sampled in extra steps after the timed region; peak stays the 2.4 GHz figure
       roof['core_clock_mhz_under_load'] = round(core_mhz, 0)
@@ -699,7 +767,7 @@ def main():
           'avg_launch_us': round(g_ms * 1e3 / max(nl, 1), 2) if g_ms > 0.02 else None,
           'achieved': round(gemm_gflop * B / g_ms, 2) if g_ms > 0.02 else None,
           'frac': round(gemm_gflop * B / g_ms / roof['peak'], 4) if g_ms > 0.02 else None,
-          'how': 'the same %d pipelined steps timed again with the GEMM (resp. depthwise) '
+          'how': 'the same %d x %d pipelined steps timed again with the GEMM (resp. depthwise) '
                  'launches removed from every plan\'s graph: step - that = the kernels\' '
                  'cost inside the timed regime; launches x avg_launch_us = gemm_ms_per_step '
                  '<= ms_per_step. The GEMM-less graphs also leave out the in-place softmax / '
@@ -707,7 +775,7 @@ def main():
                  'buffers keep valid probabilities and the correspondence / fitting stages do '
                  'their real work in those runs. roofline.achieved / avg_launch_us above are '
                  'per-launch figures from eager passes (launch gaps included, no overlap) '
-                 'and agree with the rocprofv3 kernel trace' % args.steps}
+                 'and agree with the rocprofv3 kernel trace' % (repeats, args.steps)}
     result['roofline'] = roof
     dwr = depthwise_roofline(pipe, max(2, min(args.steps, 5)))
     if dwr:

@@ -163,6 +163,7 @@ SYMBOLS = {
     'epos_separable_conv_fused_state': (ctypes.c_int, [vp]),
     'epos_set_h2_narrow_tile_limit': (ctypes.c_int, [ctypes.c_int]),
     'epos_set_h2_latency_tile_limit': (ctypes.c_int, [ctypes.c_int]),
+    'epos_set_h2_tall_tile_min': (ctypes.c_int, [ctypes.c_int]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),
     'epos_global_avg_pool_partial_f32': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),

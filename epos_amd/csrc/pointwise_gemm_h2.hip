@@ -88,16 +88,30 @@ constexpr int H2_EP_ROW = 132;                      // floats per staged epilogu
 // NW = 8 (with NB = 2): the 128 x 128 tile computed by EIGHT waves, 4 (rows) x 2 (column
 // halves) -- same stage, same bytes per MFMA as NB = 4 / NW = 4, but two waves per SIMD from
 // ONE workgroup: for launches that cannot give a CU a second workgroup ("latency mode").
+// NW = 8 with NB = 4 (round 5, "tall tile"): a 256 x 128 tile, EIGHT waves stacked along M
+// (8 x 1: every wave is exactly the wave of the 128 x 128 tile -- 32 rows x 128 columns, its
+// own two A pieces -- and the 8 KB W stage is shared by eight waves instead of four: THREE
+// LDS-DMA pieces per wave and K step instead of four, 24 KB through the CU's L1 -> LDS path
+// per 24 MFMAs per SIMD instead of 32 KB). One workgroup per CU (six 24 KB stages = 144 KB).
 template <int NB, int NW = 4> struct H2Geo {
-  static constexpr int BN = NB * 32 * (NW / 4);
+  static constexpr int WR = (NW == 8 && NB == 4) ? 8 : 4;   // waves along M
+  static constexpr int WC = NW / WR;                       // waves along N
+  static constexpr int BM = WR * 32;
+  static constexpr int BN = NB * 32 * WC;
+  static constexpr int A_LDS = BM * H2_BK * 4;             // A bytes per stage in LDS
   static constexpr int W_LDS = BN * 64;                    // W bytes per stage in LDS
-  static constexpr int STAGE = W_LDS + H2_A_BYTES;
-  static constexpr int LDS = H2_NST * STAGE;               // 81920 / 61440 (five stages)
-  static constexpr int NA = NW == 8 ? 1 : 2;               // A pieces per wave and stage
-  static constexpr int NWP = NW == 8 ? 1 : NB / 2;         // W pieces per wave and stage
+  static constexpr int STAGE = W_LDS + A_LDS;
+  static constexpr int NST = WR == 8 ? 6 : H2_NST;         // default ring depth
+  static constexpr int LDS = NST * STAGE;                  // 81920 / 61440 (five stages), 147456
+  static constexpr int NA = A_LDS / 1024 / NW;             // A pieces per wave and stage
+  static constexpr int NWP = W_LDS / 1024 / NW;            // W pieces per wave and stage
   static constexpr int NP = NA + NWP;                      // LDS-DMA pieces per wave and stage
   static constexpr int EP_ROW = NB * 32 + 4;               // a wave stages its own columns
 };
+static_assert(H2Geo<4>::NA == 2 && H2Geo<4>::NWP == 2 && H2Geo<2>::NA == 2 && H2Geo<2>::NWP == 1, "");
+static_assert(H2Geo<2, 8>::NA == 1 && H2Geo<2, 8>::NWP == 1 && H2Geo<2, 8>::BM == 128, "");
+static_assert(H2Geo<4, 8>::NA == 2 && H2Geo<4, 8>::NWP == 1 && H2Geo<4, 8>::BM == 256 &&
+              H2Geo<4, 8>::BN == 128 && H2Geo<4, 8>::STAGE == 24576, "");
 static_assert(H2Geo<4>::LDS == H2_LDS && H2Geo<4>::NP == H2_NP && H2Geo<4>::EP_ROW == H2_EP_ROW, "");
 static_assert(H2Geo<2, 8>::LDS == H2_LDS && H2Geo<2, 8>::BN == H2_BN, "");
 // Which MFMA of a K step (0..5 first half, 6..8 second half) each LDS-DMA piece of the
@@ -113,6 +127,7 @@ constexpr int h2_piece_at(int idx) {
        : idx == EPOS_H2_DS3 ? 3 : -1;
 }
 constexpr int H2_DS_FIRST = (EPOS_H2_DS0 < 6) + (EPOS_H2_DS1 < 6) + (EPOS_H2_DS2 < 6) + (EPOS_H2_DS3 < 6);
+constexpr int H2_DS_FIRST3 = (EPOS_H2_DS0 < 6) + (EPOS_H2_DS1 < 6) + (EPOS_H2_DS2 < 6);   // one W piece
 constexpr bool H2_DS_PAIRED = EPOS_H2_DS1 == EPOS_H2_DS0 + 1 && EPOS_H2_DS3 == EPOS_H2_DS2 + 1 &&
                               (EPOS_H2_DS0 < 6) == (EPOS_H2_DS1 < 6) && (EPOS_H2_DS2 < 6) == (EPOS_H2_DS3 < 6);
 static_assert(EPOS_H2_DS0 <= 8 && EPOS_H2_DS1 <= 8 && EPOS_H2_DS2 <= 8 && EPOS_H2_DS3 <= 8, "");
@@ -551,13 +566,15 @@ __device__ __forceinline__ float vec_epilogue_h2(float* ws, const f32x16* acc,
 // time) may take a deeper ring: with one wave per SIMD the K loop is bound by the bytes in
 // flight per CU (64 KB at look-ahead 4 -> ~50 B/ns of the 85-128 the load path sustains).
 template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, bool DW = false, int NB = 4,
-          int NW = 4, int NST = H2_NST>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2)
+          int NW = 4, int NST = H2Geo<NB, NW>::NST>
+__global__ __launch_bounds__(NW * 64, 2)
 void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
-  static_assert(NB == 4 || (NB == 2 && !DW), "tile = 128 x 128 or 128 x 64");
-  static_assert(NW == 4 || (NW == 8 && NB == 2 && !CONV), "eight waves: 4 x 2, plain 1x1 only");
-  static_assert(NST == H2_NST || (NB == 4 && !DW && !CONV), "deep ring: plain 128 x 128 only");
+  static_assert(NB == 4 || (NB == 2 && !DW), "tile = 128 x 128, 256 x 128 or 128 x 64");
+  static_assert(NW == 4 || (NW == 8 && !DW && (NB == 4 || !CONV)),
+                "eight waves: 8 x 1 (256 x 128), or 4 x 2 (128 x 128, plain 1x1 only)");
+  static_assert(NST == H2Geo<NB, NW>::NST || (NB == 4 && !DW && !CONV), "other ring depths: plain tiles only");
   using Geo = H2Geo<NB, NW>;
+  constexpr int BM = Geo::BM;
   constexpr int NP = Geo::NP;
   constexpr int NA = Geo::NA;
   constexpr int LA = NST - 1;                  // tiles issued ahead of the one computed
@@ -567,8 +584,8 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wrow = NW == 8 ? (wave & 3) : wave;          // the wave's 32-row group
-  const int wcol = NW == 8 ? (wave >> 2) : 0;           //            column half (NW = 8)
+  const int wrow = Geo::WC == 2 ? (wave & 3) : wave;     // the wave's 32-row group
+  const int wcol = Geo::WC == 2 ? (wave >> 2) : 0;      //            column half (4 x 2 waves)
   const int l31 = lane & 31, h = lane >> 5;
 
   (void)ga_;
@@ -639,7 +656,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
     tile_m = static_cast<int>(h2_div(static_cast<unsigned>(bid), dv));
     tile_n = bid - tile_m * tiles_n;
   } else {
-    const int tiles_m = (M + H2_BM - 1) / H2_BM;
+    const int tiles_m = (M + BM - 1) / BM;
     const int per_band = tiles_m * 8;
     const int band = bid / per_band;
     const int rem = bid - band * per_band;
@@ -648,7 +665,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
     tile_m = rem / bw;
     tile_n = band * 8 + (rem - tile_m * bw);
   }
-  const int m0 = tile_m * H2_BM, n0 = tile_n * Geo::BN;
+  const int m0 = tile_m * BM, n0 = tile_n * Geo::BN;
   const int tn128 = Geo::BN == 128 ? tiles_n : (tiles_n + 1) >> 1;   // packed W: 128-column images
   const int n0w = n0 + wcol * 64;                                       // this wave's first column
   const int nks = (K + H2_BK - 1) / H2_BK;
@@ -968,7 +985,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
 #else
       constexpr bool kIssue = true;
 #endif
-      if constexpr (kIssue && ISSUE && DMA >= 0 && DMA < H2_NP) {
+      if constexpr (kIssue && ISSUE && DMA >= 0 && DMA < H2_NP && (DMA < 3 || Geo::NWP == 2)) {
         __builtin_amdgcn_sched_barrier(0);
         issue_piece(kt + LA, s4, std::integral_constant<int, DMA>{},
                     std::integral_constant<bool, MODE == 1>{});
@@ -999,7 +1016,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
       // tile kt+1 have landed once at most the later tiles' pieces are outstanding
       // (of tile kt+LA: the H2_DS_FIRST pieces issued above)
 #ifndef EPOS_H2_ABL_NOBAR
-      if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_DS_FIRST>();
+      if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + (Geo::NWP == 2 ? H2_DS_FIRST : H2_DS_FIRST3)>();
       else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
       __builtin_amdgcn_s_barrier();
 #endif
@@ -1236,18 +1253,32 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
 }
 
 template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, bool DW = false,
-          int NB = 4, int NW = 4, int NST = H2_NST>
+          int NB = 4, int NW = 4, int NST = H2Geo<NB, NW>::NST>
 int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s,
                  const DwPhaseH2* dw = nullptr) {
   auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, DW, NB, NW, NST>;
   constexpr int lds = NST * H2Geo<NB, NW>::STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
+  static_assert(lds >= (NW * 32 * H2Geo<NB, NW>::EP_ROW + NW) * 4, "the epilogue stages through the ring");
+  // more than 64 KB of dynamic LDS needs the attribute, once per device (per instantiation)
+  static std::mutex mu;
+  static bool attr_set[RING_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RING_DEVICES) {
+    set_error("pointwise_gemm_h2_f32: no current device");
+    return EPOS_E_INVALID;
   }
-  // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!attr_set[dev]) {
+      const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                               "hipFuncSetAttribute(pointwise_gemm_h2_f32)");
+      if (rc) return rc;
+      attr_set[dev] = true;
+    }
+  }
+  // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD; the 256 x 128
+  // tile takes 144 KB: one eight-wave workgroup per CU = the same two waves per SIMD
   hipLaunchKernelGGL(kern, dim3(total), dim3(NW * 64), lds, s, g,
                      dw ? *dw : DwPhaseH2{});
   return launch_status("pointwise_gemm_h2_f32");
@@ -1317,7 +1348,11 @@ const float* zero_chunk_dev() {
   std::lock_guard<std::mutex> lock(mu);
   if (!z[dev]) {
     if (hipMalloc(reinterpret_cast<void**>(&z[dev]), 64) != hipSuccess) { z[dev] = nullptr; return nullptr; }
-    if (hipMemset(z[dev], 0, 64) != hipSuccess) return nullptr;
+    if (hipMemset(z[dev], 0, 64) != hipSuccess) {     // never hand out an unzeroed chunk
+      (void)hipFree(z[dev]);
+      z[dev] = nullptr;
+      return nullptr;
+    }
   }
   return z[dev];
 }
@@ -1400,6 +1435,15 @@ int& latency_limit() {
   return v;
 }
 
+// Launches of at least this many 128 x 128 tiles run as 256 x 128 tiles. 0 = never.
+int& tall_limit() {
+  static int v = [] {
+    const char* e = getenv("EPOS_H2_TALL_MIN_TILES");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                       const int* conv_cin, const int* conv_rate) {
   if (conv_cin && (count != 1 || args[0].R != nullptr)) {
@@ -1436,14 +1480,14 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
     g.conv_cin[i] = conv_cin ? conv_cin[i] : 0;
     g.conv_rate[i] = conv_rate ? conv_rate[i] : 1;
   }
-  auto lay_out = [&](int bn) {
+  auto lay_out = [&](int bn, int bm = H2_BM) {
     total = 0;
     for (int i = 0; i < count; ++i) {
       g.tile_start[i] = total;
       g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, bn));
       set_tn_div(g, i);
       g.npad[i] = static_cast<int>(ceil_div(args[i].N, H2_BN)) * H2_BN;
-      total += static_cast<int>(ceil_div(args[i].M, H2_BM)) * g.tiles_n[i];
+      total += static_cast<int>(ceil_div(args[i].M, bm)) * g.tiles_n[i];
     }
     for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
   };
@@ -1459,6 +1503,12 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
   bool narrow = !conv_cin && total <= __atomic_load_n(&narrow_limit(), __ATOMIC_RELAXED);
   for (int i = 0; i < count; ++i) narrow = narrow && !args[i].col_sums;
   if (narrow) lay_out(64);
+  // A launch of MANY tiles runs as 256 x 128 tiles (eight waves, one workgroup per CU): a
+  // quarter less L2 -> LDS traffic per MFMA. Same bits. EPOS_H2_TALL_MIN_TILES or
+  // epos_set_h2_tall_tile_min (0 = never).
+  const int tall_min = __atomic_load_n(&tall_limit(), __ATOMIC_RELAXED);
+  const bool tall = !narrow && tall_min > 0 && total >= tall_min;
+  if (tall) lay_out(H2_BN, 2 * H2_BM);
   g.zero_chunk = zero_chunk_dev();
   if (!g.zero_chunk) {
     set_error("launch_grouped_h2: cannot allocate the zero chunk");
@@ -1472,7 +1522,20 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
       set_error("launch_grouped_h2: the problems of a group must agree on a_presplit");
       return EPOS_E_INVALID;
     }
-  if (conv_cin) return launch_h2_tt<false, true, true>(g, total, s);
+  if (conv_cin) return tall ? launch_h2_tt<false, true, true, false, false, 4, 8>(g, total, s)
+                            : launch_h2_tt<false, true, true>(g, total, s);
+  if (tall) {
+    if (ps) {
+      if (res) return single ? launch_h2_tt<true, true, false, true, false, 4, 8>(g, total, s)
+                             : launch_h2_tt<true, false, false, true, false, 4, 8>(g, total, s);
+      return single ? launch_h2_tt<false, true, false, true, false, 4, 8>(g, total, s)
+                    : launch_h2_tt<false, false, false, true, false, 4, 8>(g, total, s);
+    }
+    if (res) return single ? launch_h2_tt<true, true, false, false, false, 4, 8>(g, total, s)
+                           : launch_h2_tt<true, false, false, false, false, 4, 8>(g, total, s);
+    return single ? launch_h2_tt<false, true, false, false, false, 4, 8>(g, total, s)
+                  : launch_h2_tt<false, false, false, false, false, 4, 8>(g, total, s);
+  }
   if (!narrow && total <= __atomic_load_n(&latency_limit(), __ATOMIC_RELAXED)) {
     bool ok = true;                       // block sums are laid out for four-wave tiles
     for (int i = 0; i < count; ++i) ok = ok && !args[i].col_sums;
@@ -1638,6 +1701,11 @@ extern "C" int epos_debug_set_gemm_trace(uint64_t* buf) {
 
 extern "C" int epos_set_h2_latency_tile_limit(int max_tiles) {
   return __atomic_exchange_n(&epos::latency_limit(), max_tiles < 0 ? 0 : max_tiles,
+                             __ATOMIC_RELAXED);
+}
+
+extern "C" int epos_set_h2_tall_tile_min(int min_tiles) {
+  return __atomic_exchange_n(&epos::tall_limit(), min_tiles < 0 ? 0 : min_tiles,
                              __ATOMIC_RELAXED);
 }
 

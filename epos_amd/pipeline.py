@@ -69,7 +69,16 @@ class EposPipeline(object):
     self.max_k = max_instances
     self._warned_cap = False
     self._warned_clamp = False
-    self.cap_hits, self.last_cap_hits = [], []   # (scene, image, obj, instances) at the cap
+    # (scene, image, obj, instances) at the cap: last_cap_hits = the batch just collected;
+    # cap_hits = the most recent CAP_HITS_KEPT of the run (bounded: a long-running service
+    # must not grow), cap_hit_count = how many there were. Requests that on_excess='clamp'
+    # cut down are recorded the same way: last_clamped / clamped / clamped_count hold
+    # (image index in the batch, obj, requested, fitted).
+    import collections
+    self.cap_hits = collections.deque(maxlen=self.CAP_HITS_KEPT)
+    self.last_cap_hits, self.cap_hit_count = [], 0
+    self.clamped = collections.deque(maxlen=self.CAP_HITS_KEPT)
+    self.last_clamped, self.clamped_count = [], 0
     centers, sizes = _corresp.pack_model_store(model_store, num_objs, num_frags)
     self.obj_ids = list(model_store.dp_model['obj_ids'])
     self.corr = _corresp.CorrExtractor(
@@ -147,11 +156,14 @@ class EposPipeline(object):
     return buf[off:off + n * sz].view(tdt)
 
   # --------------------------------------------------------------------
+  CAP_HITS_KEPT = 4096
+
   def make_slots(self, targets, task_type=LOCALIZATION):
     """targets: per image, dict obj_id -> number of instances (localization:
     the GT instance counts, infer.py:383-392,462-463). Detection: every object of
     the model store, unlimited instances (infer.py:464-465)."""
     slots, wants = [], []
+    self.last_clamped = []
     for im, t in enumerate(targets):
       for obj_id in self.obj_ids:                      # corresp.py:39 order
         if task_type == LOCALIZATION:
@@ -173,6 +185,10 @@ class EposPipeline(object):
               warnings.warn('object %d: %d instances requested, clamped to max_instances=%d'
                             % (obj_id, want, self.max_k))
               self._warned_clamp = True
+            rec = (im, obj_id, want, self.max_k)
+            self.last_clamped.append(rec)
+            self.clamped.append(rec)
+            self.clamped_count += 1
             want = self.max_k
           wants.append(want)
         else:
@@ -290,6 +306,7 @@ class EposPipeline(object):
           hit = (scene_ids[im] if scene_ids is not None else 0,
                  image_ids[im] if image_ids is not None else im, obj_id, int(nm[s]))
           self.cap_hits.append(hit)
+          self.cap_hit_count += 1
           self.last_cap_hits.append(hit)
           if not self._warned_cap:
             import warnings

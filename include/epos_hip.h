@@ -291,6 +291,12 @@ int epos_set_h2_narrow_tile_limit(int max_tiles);
  * four-wave workgroups per CU overlap better. Default 0 = never (environment
  * EPOS_H2_LATENCY_MAX_TILES). Same bits. Returns the previous limit. Process-wide. */
 int epos_set_h2_latency_tile_limit(int max_tiles);
+/* Tall tile of the fp16-pair GEMM (round 5): a launch with at least `min_tiles` 128 x 128
+ * tiles computes 256 x 128 tiles with eight waves (8 x 1: each wave is exactly the wave of
+ * the 128 x 128 tile; the W stage is shared by eight waves instead of four, so a quarter
+ * less data moves L2 -> LDS per MFMA; one workgroup per CU). 0 = never (environment
+ * EPOS_H2_TALL_MIN_TILES). Same bits. Returns the previous limit. Process-wide. */
+int epos_set_h2_tall_tile_min(int min_tiles);
 typedef struct EposSepConvArgs {
   EposDepthwiseArgs dw;
   EposPointwiseArgs pw;

@@ -69,6 +69,8 @@ def build_parser():
                                formatter_class=argparse.RawTextHelpFormatter)
   a = ap.add_argument
   # scripts/infer.py:37-120
+  a('--master', default='',
+    help='accepted and ignored (scripts/infer.py:38-40: BNS name of a TensorFlow master)')
   a('--model', required=True)
   a('--cpu_only', type=str2bool, default=False)
   a('--task_type', default=pipeline.LOCALIZATION)
@@ -110,6 +112,9 @@ def build_parser():
   a('--min_visib_fract', type=float, default=0.1)
   a('--corr_min_obj_conf', type=float, default=0.1)
   a('--corr_min_frag_rel_conf', type=float, default=0.5)
+  a('--corr_project_to_model', type=str2bool, default=False,
+    help='accepted and ignored, as in the reference: common.py:78-80 defines the flag and '
+         'nothing reads it (the projection switch that acts is --project_to_surface)')
   a('--model_variant', default='xception_65')
   a('--atrous_rates', default='12,24,36')
   a('--encoder_output_stride', type=int, default=8)
@@ -633,9 +638,11 @@ def main(argv=None):
     q, j0, ch = inflight.pop(0)
     finish(j0, ch, *q.collect())
   hits = sorted(set(h for q in pipes for h in q.cap_hits))
+  n_hits = sum(q.cap_hit_count for q in pipes)
   if hits:
     print('Instance cap (--detection_instance_cap={}) reached for {} (scene, image, object) '
-          'triples; more instances may exist there:'.format(max_inst, len(hits)))
+          'triples{}; more instances may exist there:'.format(
+              max_inst, n_hits, '' if n_hits == len(hits) else ' (the last {} listed)'.format(len(hits))))
     for sc_, im_, ob_, n_ in hits:
       print('  scene {} image {} object {}: {} instances'.format(sc_, im_, ob_, n_))
   # First-image time := mean time of the others (infer.py:741-749).

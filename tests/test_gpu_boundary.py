@@ -103,6 +103,9 @@ def test_pipeline_never_clamps_instance_counts_silently():
     slots, wants = pipe.make_slots([{1: 3, 2: 1}])
     pipe.make_slots([{1: 5}])
   assert wants == [2, 1] and len([w for w in rec if 'clamped' in str(w.message)]) == 1
+  # one warning for the whole run, but every clamped request is on record
+  assert pipe.last_clamped == [(0, 1, 5, 2)] and pipe.clamped_count == 2
+  assert list(pipe.clamped) == [(0, 1, 3, 2), (0, 1, 5, 2)]
   pipe.on_excess = 'raise'
   slots, wants = pipe.make_slots([{}], task_type='detection')
   assert wants == [-1, -1] and len(slots) == O

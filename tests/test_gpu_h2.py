@@ -20,17 +20,20 @@ def lib():
   return _lib.load()
 
 
-@pytest.fixture(autouse=True, params=['tile128', 'tile64', 'waves8'])
+@pytest.fixture(autouse=True, params=['tile128', 'tile64', 'waves8', 'tall256'])
 def tile(request, lib):
-  """Every test of this module runs with the three launch shapes of the fp16-pair kernel:
-  128 x 128 tiles on the five-stage ring only (both limits 0), 128 x 64 tiles wherever the
-  kernel offers them, and the eight-wave form wherever it is offered
-  (epos_set_h2_narrow_tile_limit / epos_set_h2_latency_tile_limit, include/epos_hip.h)."""
+  """Every test of this module runs with the launch shapes of the fp16-pair kernel:
+  128 x 128 tiles on the five-stage ring only (all limits 0), 128 x 64 tiles wherever the
+  kernel offers them, the eight-wave form wherever it is offered, and the 256 x 128 tile
+  (round 5) wherever it is offered (epos_set_h2_narrow_tile_limit /
+  epos_set_h2_latency_tile_limit / epos_set_h2_tall_tile_min, include/epos_hip.h)."""
   prev = (lib.epos_set_h2_narrow_tile_limit((1 << 30) if request.param == 'tile64' else 0),
-          lib.epos_set_h2_latency_tile_limit((1 << 30) if request.param == 'waves8' else 0))
+          lib.epos_set_h2_latency_tile_limit((1 << 30) if request.param == 'waves8' else 0),
+          lib.epos_set_h2_tall_tile_min(1 if request.param == 'tall256' else 0))
   yield request.param
   lib.epos_set_h2_narrow_tile_limit(prev[0])
   lib.epos_set_h2_latency_tile_limit(prev[1])
+  lib.epos_set_h2_tall_tile_min(prev[2])
 
 
 def _p(t, off=0):
@@ -236,11 +239,13 @@ def test_h2_bits_do_not_depend_on_the_tile(lib, m, k, n, res, relu):
   bias = rng.standard_normal(n).astype(np.float32)
   r = rng.standard_normal((m, n)).astype(np.float32) if res else None
   outs = []
-  prev = lib.epos_set_h2_narrow_tile_limit(0), lib.epos_set_h2_latency_tile_limit(0)
+  prev = (lib.epos_set_h2_narrow_tile_limit(0), lib.epos_set_h2_latency_tile_limit(0),
+          lib.epos_set_h2_tall_tile_min(0))
   try:
-    for limit, deep in ((0, 0), (1 << 30, 0), (0, 1 << 30)):
+    for limit, deep, tall in ((0, 0, 0), (1 << 30, 0, 0), (0, 1 << 30, 0), (0, 0, 1)):
       lib.epos_set_h2_narrow_tile_limit(limit)
       lib.epos_set_h2_latency_tile_limit(deep)
+      lib.epos_set_h2_tall_tile_min(tall)
       slot_a, slot_c = _slot(), _slot()
       A = torch.from_numpy(a).cuda()
       _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot_a), None))
@@ -249,6 +254,7 @@ def test_h2_bits_do_not_depend_on_the_tile(lib, m, k, n, res, relu):
   finally:
     lib.epos_set_h2_narrow_tile_limit(prev[0])
     lib.epos_set_h2_latency_tile_limit(prev[1])
+    lib.epos_set_h2_tall_tile_min(prev[2])
   for o in outs[1:]:
     assert np.array_equal(outs[0][0].view(np.uint32), o[0].view(np.uint32))
     assert o[1] == outs[0][1]

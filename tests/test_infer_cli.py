@@ -28,6 +28,31 @@ def test_params_yml_overrides_flag_defaults(tmp_path):
                        else None)
 
 
+def test_every_reference_flag_parses():
+  """Every flag the reference's entry point defines (scripts/infer.py:37-146 +
+  epos_lib/common.py:56-154; names and defaults in tests/golden/reference_flags.json, written
+  by tests/golden/make_flag_names.py from the DEFINE_* calls) is accepted by infer.py's parser,
+  with the reference's default wherever the default is a plain number / bool -- including the
+  two the reference defines and never reads (--master, --corr_project_to_model)."""
+  import json
+  import infer
+  with open(os.path.join(os.path.dirname(__file__), 'golden', 'reference_flags.json')) as f:
+    ref = json.load(f)
+  ap = infer.build_parser()
+  dests = {a.dest: a for a in ap._actions}
+  n = 0
+  for src, flags in ref.items():
+    for fl in flags:
+      assert fl['name'] in dests, '%s: --%s is not accepted' % (src, fl['name'])
+      ours = dests[fl['name']].default
+      if isinstance(fl['default'], (bool, int, float)) and not dests[fl['name']].required:
+        assert ours == fl['default'], (fl['name'], ours, fl['default'])
+      n += 1
+  assert n == 61
+  args = ap.parse_args(['--model', 'm', '--corr_project_to_model', 'True', '--master', 'x'])
+  assert args.corr_project_to_model is True and args.master == 'x'
+
+
 def test_unsupported_model_flags_raise(tmp_path):
   """A params.yml (or flag) that asks for a graph this build does not implement must
   stop the run, not be half-applied (common.py:96-154)."""

@@ -15,10 +15,13 @@ lib = _lib.load()
 PLAN = '--plan-args' in sys.argv     # bias, second absmax slot + gain, published output absmax (as the plan's layers)
 PS = '--presplit' in sys.argv          # A already as fp16 pairs (what the plan's depthwise layers write)
 argv = [a for a in sys.argv[1:] if not a.startswith('--')]
-MODES = argv[0].split(',') if argv else ['128x128', '128x64', '8 waves']
+MODES = argv[0].split(',') if argv else ['128x128', '128x64', '8 waves', '256x128']
 def p(t): return ctypes.c_void_p(t.data_ptr())
 # (M, N, K, residual)
-shapes = [(4800, 728, 728, 0), (4800, 728, 728, 1), (4800, 1024, 728, 0), (4800, 1536, 1024, 0),
+BIG = '--big' in sys.argv            # launches of many tiles (batches of four / eight, the heads, steady state)
+shapes = [(19200, 728, 728, 0), (19200, 728, 728, 1), (19200, 1024, 728, 0), (19200, 2048, 1536, 0), (19200, 256, 2048, 0),
+          (76800, 4032, 256, 0), (19200, 4032, 256, 0), (76800, 256, 304, 0), (38400, 728, 728, 1), (16384, 1024, 4096, 0),
+          (4800, 728, 728, 0), (4800, 2048, 1536, 0)] if BIG else [(4800, 728, 728, 0), (4800, 728, 728, 1), (4800, 1024, 728, 0), (4800, 1536, 1024, 0),
           (4800, 256, 2048, 0), (19200, 256, 304, 0), (19200, 256, 256, 0), (1200, 1024, 1536, 0)]
 NS = 4
 streams = [torch.cuda.Stream() for _ in range(NS)]
@@ -45,16 +48,17 @@ for (m, n, k, res) in shapes:
                              C=p(Cs[i]), ldc=n, M=m, N=n, K=k, relu=1, relu_in=0, sub=1, Wh=p(Wh),
                              a_amax=p(slot), a_presplit=1 if PS else 0) for i in range(NS)]
   tiles = -(-m // 128) * -(-n // 128)
-  for name, limit, deep in (('128x128', 0, 0), ('128x64', 1 << 30, 0), ('8 waves', 0, 1 << 30)):
+  for name, limit, deep, tall in (('128x128', 0, 0, 0), ('128x64', 1 << 30, 0, 0), ('8 waves', 0, 1 << 30, 0), ('256x128', 0, 0, 1)):
     if name not in MODES: continue
     lib.epos_set_h2_narrow_tile_limit(limit)
     lib.epos_set_h2_latency_tile_limit(deep)
+    lib.epos_set_h2_tall_tile_min(tall)
     cells = []
     for nstream in (1, 2, 4):
       def call(i):
         st = streams[i % nstream]
         _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args[i % NS]), ctypes.c_void_p(st.cuda_stream)))
-      reps = 120
+      reps = 120 if m * n * k < 2e11 else 40
       for i in range(reps): call(i)
       torch.cuda.synchronize()
       e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -66,5 +70,6 @@ for (m, n, k, res) in shapes:
       us = e0.elapsed_time(e1) / reps * 1e3
       cells.append('%6.1f (%3.0f)' % (us, 2.0 * m * n * k / us * 1e-6))
     print('%-26s %-9s %s' % ('%dx%dx%d%s [%d]' % (m, n, k, '+R' if res else '', tiles), name, '   '.join(cells)), flush=True)
-lib.epos_set_h2_narrow_tile_limit(256)
+lib.epos_set_h2_narrow_tile_limit(100)
 lib.epos_set_h2_latency_tile_limit(0)
+lib.epos_set_h2_tall_tile_min(0)

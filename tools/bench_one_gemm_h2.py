@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""ONE shape of the fp16-pair GEMM, a few launches (for rocprofv3 --pmc passes, tools/pmc_h2_gemm.sh):
+    python tools/bench_one_gemm_h2.py M N K iters [presplit] [tall]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from epos_amd import _lib
+lib = _lib.load()
+def p(t): return ctypes.c_void_p(t.data_ptr())
+m, n, k, it = [int(x) for x in sys.argv[1:5]]
+ps = 'presplit' in sys.argv; tall = 'tall' in sys.argv
+lib.epos_set_h2_narrow_tile_limit(0); lib.epos_set_h2_tall_tile_min(1 if tall else 0)
+A = torch.relu(torch.randn(m, k, device='cuda'))
+if ps: A = torch.randn(m, 2 * k, device='cuda').to(torch.float16).view(torch.float32)
+C = torch.empty(m, n, device='cuda')
+w = (np.random.randn(k, n) / np.sqrt(k)).astype(np.float32)
+tot = lib.epos_pack_pointwise_weights_h2(w.ctypes.data_as(ctypes.c_void_p), k, n, None)
+d8 = np.empty(tot, np.uint8)
+lib.epos_pack_pointwise_weights_h2(w.ctypes.data_as(ctypes.c_void_p), k, n, d8.ctypes.data_as(ctypes.c_void_p))
+Wh = torch.from_numpy(d8).cuda()
+slot = torch.zeros(64, dtype=torch.int32, device='cuda'); slot[0] = int(np.float32(8.0).view(np.int32))
+cs = torch.zeros(64, dtype=torch.int32, device='cuda')
+b = torch.zeros((n + 127) // 128 * 128, device='cuda')
+a = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Wh), bias=p(b), R=None, ldr=n, C=p(C), ldc=n, M=m, N=n, K=k, relu=1,
+                       relu_in=0, sub=1, Wh=p(Wh), a_amax=p(slot), a_presplit=1 if ps else 0, c_amax=p(cs))
+for _ in range(it): _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+torch.cuda.synchronize()

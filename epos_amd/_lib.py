@@ -164,6 +164,9 @@ SYMBOLS = {
     'epos_set_h2_narrow_tile_limit': (ctypes.c_int, [ctypes.c_int]),
     'epos_set_h2_latency_tile_limit': (ctypes.c_int, [ctypes.c_int]),
     'epos_set_h2_tall_tile_min': (ctypes.c_int, [ctypes.c_int]),
+    'epos_stream_create_cu_mask': (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int,
+                                                  ctypes.POINTER(ctypes.c_void_p)]),
+    'epos_stream_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),
     'epos_global_avg_pool_partial_f32': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),

@@ -38,6 +38,14 @@ extern "C" {
 
 int epos_abi_version(void);
 const char* epos_last_error(void);
+/* A HIP stream whose kernels run on a subset of the compute units (round 5: one partition of
+ * the chip per pipeline of images in flight). mask = `words` x 32 bits; on gfx950 bit i is CU
+ * number i / 8 of XCD i % 8, so `bits [64 p, 64 p + 64)` = eight CUs of every XCD. Workgroups
+ * are still dealt round robin over all eight XCDs, so every XCD must keep at least one CU
+ * (EPOS_E_INVALID otherwise: an XCD without a bit would run unmasked). hipGraph launches
+ * into the stream honour the mask. *stream is a hipStream_t; release with epos_stream_destroy. */
+int epos_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
+int epos_stream_destroy(void* stream);
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int epos_device_count(void);
 /* Measurement aid (bench.py): a one-wave kernel on `stream` that spins for

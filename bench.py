@@ -119,10 +119,6 @@ def parse_args():
                        '= 4 at one image per batch, 2 from four images per batch on (a batch '
                        'of four fills the chip by itself: 432 vs 421 images/s at depth 2 vs 4, '
                        'same box), 3 in between')
-  ap.add_argument('--cu-partitions', type=int, default=0,
-                  help='split the chip into this many equal CU partitions (CUs of every XCD) and '
-                       'run pipeline j on partition j %% n (CU-masked HIP streams); 0 = the '
-                       'pipelines share all CUs')
   ap.add_argument('--sparse-heads', action='store_true',
                   help='evaluate the fragment heads only for the target objects of '
                        'each image (identical poses, fewer FLOPs); default: dense '
@@ -467,8 +463,7 @@ def main():
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
       capacity=1 << 20, max_instances=max(1, args.instances), device=dev,
       use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads,
-      model_options=mo, fitting_method=args.fitting_method,
-      cu_partition=(j % args.cu_partitions, args.cu_partitions) if args.cu_partitions > 0 else None)
+      model_options=mo, fitting_method=args.fitting_method)
            for j in range(depth)]
   pipe = pipes[0]
   # Synthetic frames, resident in HBM before the timed region.
@@ -598,7 +593,6 @@ def main():
           'rccl_ranks_seen': (torch.distributed.get_world_size()
                               if torch.distributed.is_initialized() else 1),
           'hip_graph': not args.no_graph, 'pipeline_depth': depth,
-          'cu_partitions': args.cu_partitions or None,
           'heads': 'sparse (target objects only)' if args.sparse_heads else 'dense',
           'fitting_method': args.fitting_method,
           'corr_per_slot_last_step': [int(x) for x in totals[:, 1]],

@@ -38,9 +38,9 @@ class PointwiseArgs(ctypes.Structure):
       ('a_gain', ctypes.c_float), ('a_bias', ctypes.c_float),
       ('a_presplit', ctypes.c_int32),
       ('c_amax', vp),
-      # ABI 6: 32-row block sums; softmax over aligned groups of 64 output channels
+      # ABI 6: 32-row block sums, streaming stores (ABI 7: the fused softmax flag is reserved)
       ('col_sums', vp), ('col_ld', ctypes.c_int64),
-      ('c_stream', ctypes.c_int32), ('softmax64', ctypes.c_int32),
+      ('c_stream', ctypes.c_int32), ('reserved0', ctypes.c_int32),
   ]
 
 
@@ -60,8 +60,7 @@ class DepthwiseArgs(ctypes.Structure):
 
 
 class SepConvArgs(ctypes.Structure):
-  _fields_ = [('dw', DepthwiseArgs), ('pw', PointwiseArgs), ('sync', vp),
-              ('stats', vp)]
+  _fields_ = [('dw', DepthwiseArgs), ('pw', PointwiseArgs)]
 
 
 class Conv3x3Args(ctypes.Structure):
@@ -150,23 +149,11 @@ SYMBOLS = {
                                 [ctypes.POINTER(PointwiseArgs), vp]),
     'epos_pointwise_conv_grouped_f32': (ctypes.c_int, [
         ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp]),
-    'epos_pointwise_workspace_bytes': (ctypes.c_int64, []),
-    'epos_pointwise_conv_grouped_sk_f32': (ctypes.c_int, [
-        ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp, vp]),
-    'epos_pointwise_conv_grouped_ws_f32': (ctypes.c_int, [
-        ctypes.POINTER(PointwiseArgs), ctypes.c_int, vp, vp]),
     'epos_conv3x3_f32': (ctypes.c_int, [ctypes.POINTER(Conv3x3Args), ctypes.c_void_p]),
     'epos_depthwise3x3_f32': (ctypes.c_int,
                               [ctypes.POINTER(DepthwiseArgs), vp]),
-    'epos_separable_conv_sync_words': (ctypes.c_int64, [ctypes.c_int32]),
     'epos_separable_conv_f32': (ctypes.c_int, [ctypes.POINTER(SepConvArgs), vp]),
-    'epos_separable_conv_fused_state': (ctypes.c_int, [vp]),
     'epos_set_h2_narrow_tile_limit': (ctypes.c_int, [ctypes.c_int]),
-    'epos_set_h2_latency_tile_limit': (ctypes.c_int, [ctypes.c_int]),
-    'epos_set_h2_tall_tile_min': (ctypes.c_int, [ctypes.c_int]),
-    'epos_stream_create_cu_mask': (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int,
-                                                  ctypes.POINTER(ctypes.c_void_p)]),
-    'epos_stream_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'epos_im2col3x3_f32': (ctypes.c_int, [ctypes.POINTER(Im2colArgs), vp]),
     'epos_global_avg_pool_partial_f32': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
@@ -253,7 +240,7 @@ def load():
     fn.restype = restype
     if argtypes is not None:
       fn.argtypes = argtypes
-  if lib.epos_abi_version() != 6:
+  if lib.epos_abi_version() != 7:
     raise EposError('libepos_hip.so ABI version mismatch')
   _lib = lib
   return lib

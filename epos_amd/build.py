@@ -33,13 +33,30 @@ def _stale():
   return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(name, defines):
+def build_variant(name, defines, only=None):
   """A copy of the library with extra -D flags (tools/: same-box A/B runs, selected with
-  EPOS_HIP_LIB=<returned path>)."""
+  EPOS_HIP_LIB=<returned path>). only = basenames of the translation units the flags matter
+  for: the others are taken from the default build's object cache (build() first)."""
   out = os.path.join(LIB_DIR, 'libepos_hip_%s.so' % name)
   os.makedirs(LIB_DIR, exist_ok=True)
-  subprocess.check_call([HIPCC] + FLAGS + ['-Wno-inline-asm'] + list(defines) + ['-o', out] +
-                        sources())
+  if not only:
+    subprocess.check_call([HIPCC] + FLAGS + ['-Wno-inline-asm'] + list(defines) + ['-o', out] +
+                          sources())
+    return out
+  build()
+  obj_dir = os.path.join(LIB_DIR, 'obj')
+  cflags = [f for f in FLAGS if f != '-shared'] + ['-c', '-Wno-inline-asm']
+  objs = []
+  for src in sources():
+    base = os.path.basename(src)
+    if base in only:
+      obj = os.path.join(obj_dir, '%s.%s.o' % (base, name))
+      subprocess.check_call([HIPCC] + cflags + list(defines) + ['-o', obj, src])
+    else:
+      obj = os.path.join(obj_dir, base + '.o')
+    objs.append(obj)
+  link = [f for f in FLAGS if f.startswith('--offload-arch') or f in ('-shared', '-fPIC')]
+  subprocess.check_call([HIPCC] + link + ['-o', out] + objs)
   return out
 
 

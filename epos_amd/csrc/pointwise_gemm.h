@@ -10,36 +10,24 @@
 
 namespace epos {
 
-// Launchers defined in pointwise_gemm_dma.hip (the default data path for every GEMM
-// without a pre-activation ReLU, and the opt-in persistent stream-K variant).
+// Launcher defined in pointwise_gemm_dma.hip (the fp32-MFMA data path for every GEMM
+// without a pre-activation ReLU).
 // conv_cin != nullptr: implicit 3x3 conv, problem i has conv_cin[i] input channels and
 // dilation conv_rate[i] (K = 9 * conv_cin[i], A = the NHWC input of Hi x Wi pixels,
 // `sub` = stride, M = B * Ho * Wo output pixels).
 int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s,
                        const int* conv_cin = nullptr, const int* conv_rate = nullptr);
-int launch_grouped_sk(const EposPointwiseArgs* args, int count, void* workspace,
-                      hipStream_t s);
-int64_t sk_workspace_bytes();
 // pointwise_gemm_split.hip: fp32 GEMM on the bf16 matrix pipe (exact three-way operand
 // split, six piece products); every problem carries split-packed weights (p.Ws).
 int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s,
                          const int* conv_cin = nullptr, const int* conv_rate = nullptr);
 bool split_eligible(const EposPointwiseArgs* args, int count);
-// pointwise_gemm_split.hip: the fused separable conv (depthwise producer phase inside
-// the split GEMM's workgroups).
-int launch_sepconv_split(const EposSepConvArgs* a, hipStream_t s);
 // pointwise_gemm_h2.hip: fp32 GEMM on the fp16 matrix pipe (two fp16 pieces per operand,
 // three piece products); every problem carries fp16-pair weights (p.Wh). A problem
 // without an absmax slot (p.a_amax) gets one from the library's ring, measured first.
 int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                       const int* conv_cin = nullptr, const int* conv_rate = nullptr);
 bool h2_eligible(const EposPointwiseArgs* args, int count);
-int64_t sepconv_sync_words(int M);
-// pointwise_gemm_h2.hip: the fused separable conv on the fp16-pair kernel (LDS-staged
-// depthwise producer phase writing fp16 pairs, pre-split K loop); taken when the caller
-// opted into fp16-pair intermediates (dw.y_h2 and pw.a_presplit).
-bool sepconv_h2_eligible(const EposSepConvArgs* a);
-int launch_sepconv_h2(const EposSepConvArgs* a, hipStream_t s);
 
 namespace {
 

@@ -674,9 +674,9 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
                                                int count, void* stream) {
   using namespace epos;
   EPOS_REQUIRE(args && count >= 1 && count <= MAX_GROUP, "1..8 problems per group");
-  bool any_sm = false;
   for (int i = 0; i < count; ++i) {
     const EposPointwiseArgs& a = args[i];
+    EPOS_REQUIRE(a.reserved0 == 0, "EposPointwiseArgs.reserved0 must be 0 (ABI 7)");
     if (a.col_sums)
       EPOS_REQUIRE(!a.R && a.N % 4 == 0 && a.col_ld % 4 == 0 && a.col_ld >= a.N &&
                        (reinterpret_cast<uintptr_t>(a.col_sums) & 15) == 0 &&
@@ -684,24 +684,8 @@ extern "C" int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args,
                        h2_eligible(args, count),
                    "col_sums needs the fp16-pair kernel (Wh, a bound for A), no residual, "
                    "N, ldc, col_ld multiples of 4 and 16-byte aligned C / col_sums");
-    if (!a.softmax64) continue;
-    any_sm = true;
-    EPOS_REQUIRE(a.N % 64 == 0 && a.ldc == a.N && !a.R && !a.relu && a.M > 8 &&
-                     (reinterpret_cast<uintptr_t>(a.C) & 15) == 0,
-                 "softmax64 needs N % 64 == 0, dense rows (ldc == N), no residual, no ReLU, "
-                 "M > 8 and a 16-byte aligned C");
   }
-  // the fp16-pair kernel applies the softmax in its epilogue; for any other kernel the
-  // stand-alone kernel runs on the output afterwards (same arithmetic, same bits)
-  if (!any_sm || h2_eligible(args, count)) return grouped_impl(args, count, stream);
-  EposPointwiseArgs plain[MAX_GROUP];
-  for (int i = 0; i < count; ++i) { plain[i] = args[i]; plain[i].softmax64 = 0; }
-  int rc = grouped_impl(plain, count, stream);
-  for (int i = 0; i < count && !rc; ++i)
-    if (args[i].softmax64)
-      rc = epos_softmax_groups_f32(args[i].C, static_cast<int64_t>(args[i].M) * (args[i].N / 64),
-                                   64, stream);
-  return rc;
+  return grouped_impl(args, count, stream);
 }
 
 static int grouped_impl(const EposPointwiseArgs* args, int count, void* stream) {
@@ -802,10 +786,6 @@ extern "C" int epos_conv3x3_f32(const EposConv3x3Args* a, void* stream) {
   return launch_grouped_dma(&p, 1, static_cast<hipStream_t>(stream), &cin, &rate);
 }
 
-extern "C" int64_t epos_separable_conv_sync_words(int32_t M) {
-  return epos::sepconv_sync_words(M);
-}
-
 extern "C" int epos_separable_conv_f32(const EposSepConvArgs* a, void* stream) {
   using namespace epos;
   EPOS_REQUIRE(a && a->dw.X && a->dw.w9c && a->dw.bias && a->dw.Y, "null pointer");
@@ -815,23 +795,12 @@ extern "C" int epos_separable_conv_f32(const EposSepConvArgs* a, void* stream) {
                "the pointwise conv must read the depthwise output");
   EPOS_REQUIRE(static_cast<int64_t>(p.M) == static_cast<int64_t>(d.B) * d.Ho * d.Wo,
                "pw.M must be the number of depthwise output pixels");
+  EPOS_REQUIRE((d.y_h2 != 0) == (p.a_presplit != 0),
+               "dw.y_h2 and pw.a_presplit describe the same intermediate");
   const int rc = validate(&p);
   if (rc) return rc;
-  static const int fused = [] {
-    const char* e = getenv("EPOS_SEPCONV_FUSED");
-    return e ? atoi(e) : 1;
-  }();
-  const bool shape_ok = fused != 0 && a->sync && d.stride == 1 && d.Hi == d.Ho &&
-                        d.Wi == d.Wo && d.C % 4 == 0 && d.ldx % 4 == 0 && d.ldy % 4 == 0 &&
-                        p.sub == 1 && p.M > 8 &&
-                        (reinterpret_cast<uintptr_t>(d.X) & 15) == 0 &&
-                        (reinterpret_cast<uintptr_t>(d.Y) & 127) == 0;
-  // fp16-pair intermediates (dw.y_h2 + pw.a_presplit): the fused fp16-pair kernel
-  if (shape_ok && sepconv_h2_eligible(a))
-    return launch_sepconv_h2(a, static_cast<hipStream_t>(stream));
-  const bool ok = shape_ok && !d.y_h2 && !p.a_presplit && split_eligible(&p, 1) &&
-                  static_cast<int64_t>(d.Hi) * d.Wi * d.ldx < (1LL << 29);
-  if (ok) return launch_sepconv_split(a, static_cast<hipStream_t>(stream));
+  // the two launches (the single-launch forms of rounds 2 and 4 measured slower and were
+  // removed in round 5: include/epos_hip.h)
   const int rd = epos_depthwise3x3_f32(&d, stream);
   if (rd) return rd;
   return epos_pointwise_conv_f32(&p, stream);
@@ -841,64 +810,3 @@ extern "C" int epos_pointwise_conv_f32(const EposPointwiseArgs* a, void* stream)
   return epos_pointwise_conv_grouped_f32(a, 1, stream);
 }
 
-extern "C" int64_t epos_pointwise_workspace_bytes(void) {
-  return epos::sk_workspace_bytes();
-}
-
-extern "C" int epos_pointwise_conv_grouped_ws_f32(const EposPointwiseArgs* args,
-                                                  int count, void* workspace,
-                                                  void* stream) {
-  using namespace epos;
-  EPOS_REQUIRE(args && count >= 1 && count <= MAX_GROUP, "1..8 problems per group");
-  static const int use_sk = [] {
-    const char* e = getenv("EPOS_GEMM_SK");
-    return e ? atoi(e) : -1;
-  }();
-  int64_t units = 0;
-  for (int i = 0; i < count; ++i) {
-    const int rc = validate(&args[i]);
-    if (rc) return rc;
-    EPOS_REQUIRE((args[i].relu_in != 0) == (args[0].relu_in != 0) &&
-                 (args[i].R != nullptr) == (args[0].R != nullptr),
-                 "problems of one group must agree on relu_in / residual");
-    units += ceil_div(args[i].M, 64) * ceil_div(args[i].N, BN) * ceil_div(args[i].K, BK);
-  }
-  // Round-1 measurements: the persistent stream-K kernel ties or wins on
-  // under-filled grids with long K (N = 1024: 69.8 -> 67.7 us, ASPP: 63.6 -> 58.6 us) but
-  // loses on the 48 middle-flow layers (47.9 -> 55 us) and end to end (213 -> 177
-  // images/s: its fixed 512-workgroup grid leaves no slots for the other streams'
-  // kernels). It therefore stays opt-in (EPOS_GEMM_SK=1).
-  // The stream-K kernel has its own inline epilogue: it neither publishes c_amax nor reads
-  // fp16-pair weights / a pre-split A, so a problem that carries any of those takes the
-  // data-parallel path (the consumers of an absmax slot would otherwise read zeros).
-  bool abi5 = false;
-  for (int i = 0; i < count; ++i)
-    abi5 = abi5 || args[i].c_amax || args[i].Wh || args[i].a_presplit || args[i].softmax64 ||
-           args[i].col_sums;
-  const bool sk = workspace && use_sk == 1 && args[0].relu_in == 0 && !abi5;
-  if (sk && units < (1LL << 31))
-    return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
-  return epos_pointwise_conv_grouped_f32(args, count, stream);
-}
-
-extern "C" int epos_pointwise_conv_grouped_sk_f32(const EposPointwiseArgs* args,
-                                                  int count, void* workspace,
-                                                  void* stream) {
-  using namespace epos;
-  EPOS_REQUIRE(args && workspace && count >= 1 && count <= MAX_GROUP,
-               "1..8 problems per group and a workspace");
-  for (int i = 0; i < count; ++i) {
-    const int rc = validate(&args[i]);
-    if (rc) return rc;
-    EPOS_REQUIRE((args[i].relu_in != 0) == (args[0].relu_in != 0) &&
-                 (args[i].R != nullptr) == (args[0].R != nullptr),
-                 "problems of one group must agree on relu_in / residual");
-  }
-  if (args[0].relu_in != 0)   // the LDS-DMA ring cannot apply the pre-activation
-    return epos_pointwise_conv_grouped_f32(args, count, stream);
-  for (int i = 0; i < count; ++i)     // ABI-5 fields the stream-K epilogue does not serve
-    if (args[i].c_amax || args[i].Wh || args[i].a_presplit || args[i].softmax64 ||
-        args[i].col_sums)
-      return epos_pointwise_conv_grouped_f32(args, count, stream);
-  return launch_grouped_sk(args, count, workspace, static_cast<hipStream_t>(stream));
-}

@@ -42,11 +42,14 @@
 // Round 4: the activation may arrive already split by its producer (PRESPLIT: no conversion in
 // the loop); the epilogue publishes the output's absmax with ONE atomic per workgroup (912
 // same-line atomics kept a middle-flow launch alive 2 us after its last store), can write
-// streaming stores, 32-row block sums and a softmax over groups of 64 columns; the fused
-// separable conv's producer phase (DW) lives here too. Launch shapes besides the default
-// (template parameters NB, NW, NST; same bits in all of them): 128 x 64 tiles for launches of
-// few tiles (default: up to 100), eight waves per tile ("latency mode", opt-in), any ring
-// depth. What they measure, and why the default shape wins: DESIGN.md (e) "Round 4".
+// streaming stores and 32-row block sums. Launch shapes (template parameter NB; same bits in
+// both): 128 x 128 tiles, and 128 x 64 tiles for launches of few tiles (up to 100).
+//
+// Round 5 (diet): what was built on this kernel, measured slower or no better, and REMOVED
+// from the product again -- the fused separable conv's producer phase, the fragment softmax
+// in the epilogue, eight waves per 128 x 128 tile, the 256 x 128 eight-wave tile, deeper
+// rings, other LDS-DMA placements -- is described with its measurements in DESIGN.md (e) and
+// profiles/r04, profiles/r05; the code is in the history (last full version: commit 1b05025).
 #include <string.h>
 
 #include <mutex>
@@ -60,10 +63,7 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// where the always-issued output stores of the fused depthwise producer go for lanes that
-// have no output (rows past M, channel groups past the slice)
-__device__ __attribute__((aligned(16))) float g_dw_dump_h2[4 * THREADS];
+typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef EPOS_GEMM_TRACE      // tools/gemm_h2_trace.py: 100 MHz stamps per workgroup
 __device__ uint64_t* g_h2_trace = nullptr;
@@ -81,56 +81,22 @@ constexpr int H2_LDS = H2_NST * H2_STAGE;           // 81920: two workgroups per
 constexpr int H2_NP = 4;                            // LDS-DMA pieces per wave and stage
 constexpr int H2_EP_ROW = 132;                      // floats per staged epilogue row
 // Tile geometry by column blocks per wave: NB = 4 is the 128 x 128 tile above; NB = 2 a
-// 128 x 64 tile (round 4: launches with fewer 128-wide tiles than CUs -- the 48 middle-flow
-// layers of one image make 228 -- leave every SIMD with ONE wave; at 64 columns the same
-// launch has 456 workgroups, two per CU). A 64-column tile reads one half of the packed
-// 8 KB W stage image of its 128-column tile; the A stage is the same.
-// NW = 8 (with NB = 2): the 128 x 128 tile computed by EIGHT waves, 4 (rows) x 2 (column
-// halves) -- same stage, same bytes per MFMA as NB = 4 / NW = 4, but two waves per SIMD from
-// ONE workgroup: for launches that cannot give a CU a second workgroup ("latency mode").
-// NW = 8 with NB = 4 (round 5, "tall tile"): a 256 x 128 tile, EIGHT waves stacked along M
-// (8 x 1: every wave is exactly the wave of the 128 x 128 tile -- 32 rows x 128 columns, its
-// own two A pieces -- and the 8 KB W stage is shared by eight waves instead of four: THREE
-// LDS-DMA pieces per wave and K step instead of four, 24 KB through the CU's L1 -> LDS path
-// per 24 MFMAs per SIMD instead of 32 KB). One workgroup per CU (six 24 KB stages = 144 KB).
-template <int NB, int NW = 4> struct H2Geo {
-  static constexpr int WR = (NW == 8 && NB == 4) ? 8 : 4;   // waves along M
-  static constexpr int WC = NW / WR;                       // waves along N
-  static constexpr int BM = WR * 32;
-  static constexpr int BN = NB * 32 * WC;
-  static constexpr int A_LDS = BM * H2_BK * 4;             // A bytes per stage in LDS
+// 128 x 64 tile (round 4: launches of few tiles -- ASPP 1x1, concat projection: ~80 wide
+// tiles for 256 CUs -- get twice the workgroups). A 64-column tile reads one half of the packed
+// 8 KB W stage image of its 128-column tile; the A stage is the same. (Other launch shapes --
+// eight waves on a 128 x 128 tile, a 256 x 128 tile with eight waves, deeper rings -- were
+// built, bit-identical, and measured no better: DESIGN.md (e), profiles/r04, profiles/r05.)
+template <int NB> struct H2Geo {
+  static constexpr int BN = NB * 32;
   static constexpr int W_LDS = BN * 64;                    // W bytes per stage in LDS
-  static constexpr int STAGE = W_LDS + A_LDS;
-  static constexpr int NST = WR == 8 ? 6 : H2_NST;         // default ring depth
-  static constexpr int LDS = NST * STAGE;                  // 81920 / 61440 (five stages), 147456
-  static constexpr int NA = A_LDS / 1024 / NW;             // A pieces per wave and stage
-  static constexpr int NWP = W_LDS / 1024 / NW;            // W pieces per wave and stage
+  static constexpr int STAGE = W_LDS + H2_A_BYTES;
+  static constexpr int LDS = H2_NST * STAGE;               // 81920 / 61440 (five stages)
+  static constexpr int NA = 2;                             // A pieces per wave and stage
+  static constexpr int NWP = NB / 2;                       // W pieces per wave and stage
   static constexpr int NP = NA + NWP;                      // LDS-DMA pieces per wave and stage
   static constexpr int EP_ROW = NB * 32 + 4;               // a wave stages its own columns
 };
-static_assert(H2Geo<4>::NA == 2 && H2Geo<4>::NWP == 2 && H2Geo<2>::NA == 2 && H2Geo<2>::NWP == 1, "");
-static_assert(H2Geo<2, 8>::NA == 1 && H2Geo<2, 8>::NWP == 1 && H2Geo<2, 8>::BM == 128, "");
-static_assert(H2Geo<4, 8>::NA == 2 && H2Geo<4, 8>::NWP == 1 && H2Geo<4, 8>::BM == 256 &&
-              H2Geo<4, 8>::BN == 128 && H2Geo<4, 8>::STAGE == 24576, "");
 static_assert(H2Geo<4>::LDS == H2_LDS && H2Geo<4>::NP == H2_NP && H2Geo<4>::EP_ROW == H2_EP_ROW, "");
-static_assert(H2Geo<2, 8>::LDS == H2_LDS && H2Geo<2, 8>::BN == H2_BN, "");
-// Which MFMA of a K step (0..5 first half, 6..8 second half) each LDS-DMA piece of the
-// 128 x 128 tile is issued behind. Default: the first four.
-#ifndef EPOS_H2_DS0
-#define EPOS_H2_DS0 0
-#define EPOS_H2_DS1 1
-#define EPOS_H2_DS2 2
-#define EPOS_H2_DS3 3
-#endif
-constexpr int h2_piece_at(int idx) {
-  return idx == EPOS_H2_DS0 ? 0 : idx == EPOS_H2_DS1 ? 1 : idx == EPOS_H2_DS2 ? 2
-       : idx == EPOS_H2_DS3 ? 3 : -1;
-}
-constexpr int H2_DS_FIRST = (EPOS_H2_DS0 < 6) + (EPOS_H2_DS1 < 6) + (EPOS_H2_DS2 < 6) + (EPOS_H2_DS3 < 6);
-constexpr int H2_DS_FIRST3 = (EPOS_H2_DS0 < 6) + (EPOS_H2_DS1 < 6) + (EPOS_H2_DS2 < 6);   // one W piece
-constexpr bool H2_DS_PAIRED = EPOS_H2_DS1 == EPOS_H2_DS0 + 1 && EPOS_H2_DS3 == EPOS_H2_DS2 + 1 &&
-                              (EPOS_H2_DS0 < 6) == (EPOS_H2_DS1 < 6) && (EPOS_H2_DS2 < 6) == (EPOS_H2_DS3 < 6);
-static_assert(EPOS_H2_DS0 <= 8 && EPOS_H2_DS1 <= 8 && EPOS_H2_DS2 <= 8 && EPOS_H2_DS3 <= 8, "");
 template <int... I, class F>
 __device__ __forceinline__ void h2_static_for(std::integer_sequence<int, I...>, F&& f) {
   (f(std::integral_constant<int, I>{}), ...);
@@ -156,281 +122,10 @@ __device__ __forceinline__ void a_scale(const EposPointwiseArgs& p, int lane, fl
   h2_scale(p.a_amax, p.a_amax2, p.a_gain, p.a_bias, lane, s, inv);
 }
 
-// ---------------------------------------------------------------------------------
-// Fused separable conv on the fp16-pair kernel (round 4; epos_separable_conv_f32 when the
-// caller opted into fp16-pair intermediates: dw.y_h2 and pw.a_presplit): the depthwise 3x3
-// runs as a PRODUCER PHASE of the pointwise GEMM's own workgroups, as in round 2's
-// bf16 x 6 version (pointwise_gemm_split.hip) -- the tiles_n workgroups that share a row
-// tile each compute 1 / tiles_n of the channels of the tile's 128 rows, hand them over
-// through global memory (write-through stores, one arrival counter, one agent-scope
-// acquire per workgroup), and the K loop reads the intermediate as its A operand -- but
-//   * the producer stages its input through LDS by LDS-DMA: per chunk of 16 channels the
-//     three dilated input rows of the tile (128 + 2 * 4 raster-contiguous pixels each,
-//     64 B per pixel: 26 KB) land in one of three ring buffers that the GEMM's 80 KB ring
-//     leaves unused at that point; a thread computes 2 pixels x 4 channels per chunk from
-//     18 conflict-free ds_read_b128 (the register-direct version of round 2 issued 9
-//     global loads per output from 4 waves: 14.6 us per workgroup, TA-issue bound);
-//   * it writes fp16 PAIRS (the y_h2 arithmetic of layers.hip, same scale as the GEMM's
-//     a_scale), so every activation is split once instead of once per column tile and the
-//     K loop is the PRESPLIT instantiation -- no conversion in the loop (the split costs
-//     11-18 % of the loop, profiles/r04/power_by_component_h2.txt);
-//   * same fmaf chain per output as depthwise3x3_s1_kernel: intermediate and result are
-//     bit-identical to the two launches (tests/test_gpu_layers.py).
-// Progress never depends on co-scheduling: a workgroup that has waited `timeout` for its
-// siblings computes their slices itself (identical values; duplicate stores are benign).
-// ---------------------------------------------------------------------------------
 struct H2Div { unsigned mul, sh1, sh2; };          // n / d by multiply-shift (32-bit n)
-struct DwPhaseH2 {
-  const float* X; int64_t ldx;                     // depthwise input, NHWC
-  const float* w9c; const float* bias;             // [9][C] (BN folded), [C]
-  float* T; int64_t ldt;                           // depthwise output (fp16 pairs) = A
-  unsigned* sync;                                  // [tiles_m][2] arrivals, departures
-  unsigned* stats;                                 // [2] time-outs (diagnostics) or null
-  int Hi, Wi, rate, relu_in, relu_out, C;
-  unsigned timeout;                                // 100 MHz ticks
-  H2Div dw, dh;                                    // / Wi, / Hi
-};
-typedef __attribute__((address_space(1))) unsigned h2_gu32;
-typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int DWP_RUN = 136;                       // staged pixels per input row of a chunk
-constexpr int DWP_PADL = 4;                        // = the largest dilation served
-constexpr int DWP_RUN_BYTES = DWP_RUN * 64;        // 16 channels fp32 per pixel
-constexpr int DWP_DATA = 3 * DWP_RUN_BYTES;        // 26112: one ring buffer
-constexpr int DWP_NBUF = 3;
-constexpr int DWP_WOFF = DWP_NBUF * DWP_DATA;      // 78336: three 1 KB weight areas
-constexpr int DWP_FLAG = DWP_WOFF + DWP_NBUF * 1024;   // 81408: the time-out flag
-constexpr int DWP_NI = 7;                          // LDS-DMA instructions per wave and chunk
-static_assert(DWP_FLAG + 16 <= H2_LDS, "producer buffers must fit the GEMM's ring");
-
 __device__ __forceinline__ unsigned h2_div(unsigned n, const H2Div& f) {
   const unsigned t = __umulhi(f.mul, n);
   return (t + ((n - t) >> f.sh1)) >> f.sh2;
-}
-__device__ __forceinline__ float relu_1op_h2(float x) {          // as layers.hip
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-// Plain 16-byte store (lands in L2). A C++ store, NOT inline asm: a store of more than 64
-// bits reads its data VGPRs a cycle or two after issue, and the compiler only keeps the next
-// VALU write away from them (s_nop) for stores it knows about -- an asm store had its first
-// two data registers overwritten by the address computation of the next one.
-__device__ __forceinline__ void st4_l2_h2(float* p, u32x4 v) {
-  *reinterpret_cast<u32x4*>(p) = v;
-}
-
-// Depthwise 3x3 (stride 1, dilation d.rate <= 4, TF 'SAME') of rows [m0, m0 + 128) for the
-// channel groups (float4) [g_lo, g_lo + wc), written as fp16 pairs under the scale `sa`.
-__device__ __forceinline__ void dw_produce_h2(const DwPhaseH2& d, float* smem, unsigned lds0,
-                                              int M, int m0, int g_lo, int wc, float sa,
-                                              int t) {
-  const int lane = t & 63;
-  const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int g = t & 3;
-  const int c4n = d.C >> 2;
-  const int Wi = d.Wi, Hi = d.Hi, r = d.rate;
-  const int nq = (wc + 3) >> 2;                    // chunks of 4 groups (16 channels)
-  if (nq <= 0) return;                             // uniform
-  const float* xb = uniform_ptr(d.X);
-  // ---- L2 prefetch: the tile's input (3 rows x 136 pixels x this slice's channels) was
-  //      written by the previous launch and sits in the Infinity Cache / HBM; with ~52 KB of
-  //      LDS-DMA in flight per workgroup a chunk loop that pays that latency per chunk is
-  //      latency bound (16 us measured). One dword per 128-byte line, all issued at once,
-  //      pulls everything into this XCD's L2; they retire (in order) with the first chunk.
-  //      The loads are LDS-DMA dwords into a dump area (the third weight area, unused
-  //      until chunk 2 is issued): no destination VGPRs, so nothing the compiler allocates
-  //      can be overwritten by a load that returns late.
-  {
-    const int nl = ((wc * 16 + 127) >> 7) + 1;           // lines per pixel (unaligned rows)
-    const int fmax = (g_lo + wc) * 4 - 1;
-    const unsigned dump = __builtin_amdgcn_readfirstlane(lds0 + DWP_WOFF + 2 * 1024 + (wave_u & 1) * 256);
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2) {
-      int px = t + i2 * 256;
-      px = px < 3 * DWP_RUN ? px : 3 * DWP_RUN - 1;
-      const int run = px / DWP_RUN, pr = px - run * DWP_RUN;
-      int mm = m0 + pr - DWP_PADL + (run - 1) * r * Wi;
-      mm = mm < 0 ? 0 : (mm >= M ? M - 1 : mm);
-      const float* row = d.X + static_cast<int64_t>(mm) * d.ldx;
-#pragma unroll
-      for (int l = 0; l < 5; ++l) {
-        int fo = g_lo * 4 + (l < nl ? l : nl - 1) * 32;
-        fo = fo < fmax ? fo : fmax;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                     : : "v"(row + fo), "s"(dump) : "memory", "m0");
-      }
-    }
-  }
-  // ---- my 7 LDS-DMA instructions of a chunk: 27 = 3 input rows x 9 pieces of 16 pixels
-  //      (the ninth overlaps the eighth: 136 = 8 * 16 + 8) + 1 = the nine weight vectors
-  //      and the bias of the chunk's 16 channels
-  unsigned pixoff[DWP_NI], dsto[DWP_NI];
-  const float* wsrc = d.bias;
-#pragma unroll
-  for (int u = 0; u < DWP_NI; ++u) {
-    const int j = wave_u * DWP_NI + u;             // uniform
-    pixoff[u] = 0; dsto[u] = 0;
-    if (j < 27) {
-      const int run = j / 9, i = j - run * 9;
-      const int ps = i < 8 ? 16 * i : DWP_RUN - 16;
-      int mm = m0 + ps + (lane >> 2) - DWP_PADL + (run - 1) * r * Wi;
-      mm = mm < 0 ? 0 : (mm >= M ? M - 1 : mm);    // masked at compute time
-      pixoff[u] = static_cast<unsigned>(mm) * static_cast<unsigned>(d.ldx * 4);
-      dsto[u] = static_cast<unsigned>(run * DWP_RUN_BYTES + ps * 64);
-    } else {
-      const int tap = lane >> 2;
-      if (tap < 9) wsrc = d.w9c + static_cast<int64_t>(tap) * d.C;
-    }
-  }
-  auto issue = [&](int q, int b) {
-    const int gq = g_lo + 4 * q + (lane & 3);
-    const int gcl = gq < c4n ? gq : c4n - 1;       // a lane past the tensor's channels
-#pragma unroll
-    for (int u = 0; u < DWP_NI; ++u) {
-      const int j = wave_u * DWP_NI + u;
-      if (j < 27) {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(
-            lds0 + static_cast<unsigned>(b) * DWP_DATA + dsto[u]);
-        glds16_s_m0(pixoff[u] + static_cast<unsigned>(gcl) * 16u, xb, dst);
-      } else {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(
-            lds0 + DWP_WOFF + static_cast<unsigned>(b) * 1024u);
-        glds16_v_m0(wsrc + gcl * 4, dst);
-      }
-    }
-  };
-  // ---- my two pixels: validity of the nine taps, output row
-  unsigned okm[2];
-  bool valid[2];
-  unsigned toff[2];
-#pragma unroll
-  for (int pp = 0; pp < 2; ++pp) {
-    const int pl = (t >> 2) + 64 * pp;
-    int m = m0 + pl;
-    valid[pp] = m < M;
-    m = m < M ? m : M - 1;
-    const unsigned row = h2_div(static_cast<unsigned>(m), d.dw);
-    const int x = m - static_cast<int>(row) * Wi;
-    const int y = static_cast<int>(row - h2_div(row, d.dh) * Hi);
-    unsigned ok = 0;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int yi = y + (ky - 1) * r, xi = x + (kx - 1) * r;
-        const bool in = static_cast<unsigned>(yi) < static_cast<unsigned>(Hi) &&
-                        static_cast<unsigned>(xi) < static_cast<unsigned>(Wi);
-        ok |= in ? 1u << (ky * 3 + kx) : 0u;
-      }
-    okm[pp] = ok;
-    toff[pp] = static_cast<unsigned>(m) * static_cast<unsigned>(d.ldt);
-  }
-  const bool relu_in = d.relu_in != 0, relu_out = d.relu_out != 0;
-  const int ro = r * 16;                           // floats between taps kx, kx + 1
-  // every tap of both pixels of every lane of this wave inside the image: no selects
-  const bool interior = __builtin_amdgcn_ballot_w64(okm[0] != 0x1ffu || okm[1] != 0x1ffu) == 0;
-  // One chunk for both pixels of the thread: ALL LDS reads first (28 ds_read_b128, nothing
-  // between them -- a run-time flag tested per tap made the compiler wait for every read on
-  // the spot, ~2 us per chunk), then the select / ReLU / fmaf chain.
-  auto compute = [&](int b, auto masked_tag, auto relu_tag, u32x4& o0, u32x4& o1) {
-    constexpr bool MASKED = decltype(masked_tag)::value;
-    constexpr bool RELU_IN = decltype(relu_tag)::value;
-    const float* sb = smem + b * (DWP_DATA / 4);
-    const float* wsm = smem + (DWP_WOFF + b * 1024) / 4;
-    h2_f32x4 w[9], xv[2][9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-      w[i] = *reinterpret_cast<const h2_f32x4*>(wsm + (i * 4 + g) * 4);
-    const h2_f32x4 bias = *reinterpret_cast<const h2_f32x4*>(wsm + (36 + g) * 4);
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-      const float* px = sb + ((t >> 2) + 64 * pp + DWP_PADL) * 16 + g * 4;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-          xv[pp][ky * 3 + kx] =
-              *reinterpret_cast<const h2_f32x4*>(px + ky * (DWP_RUN * 16) + (kx - 1) * ro);
-    }
-    u32x4 o[2];
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-      h2_f32x4 acc = bias;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        h2_f32x4 x = xv[pp][i];
-        if constexpr (MASKED) {
-          const bool in = (okm[pp] >> i) & 1u;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = in ? x[e] : 0.f;
-        }
-        if constexpr (RELU_IN) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = relu_1op_h2(x[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaf(x[e], w[i][e], acc[e]);
-      }
-      if (relu_out) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = relu_1op_h2(acc[e]);
-      }
-      unsigned h0, h1, mm0, mm1;
-      h2_split_pair(acc[0], acc[1], sa, h0, mm0);
-      h2_split_pair(acc[2], acc[3], sa, h1, mm1);
-      o[pp][0] = h0; o[pp][1] = h1; o[pp][2] = mm0; o[pp][3] = mm1;
-    }
-    o0 = o[0]; o1 = o[1];
-  };
-  // ---- the chunk loop: COMPACT code (a first version, unrolled over eight chunks with the
-  //      outputs held in registers, was ~50 KB of straight-line code executed once per
-  //      workgroup -- 17 us per tile, instruction-fetch bound). Chunk q + 2 is issued while
-  //      chunk q is computed; the two output stores of a chunk are ALWAYS issued (lanes
-  //      without an output store to a dump word), so the counted waits know exactly what is
-  //      in flight: vector memory operations retire in order on gfx9-family parts.
-#ifdef EPOS_SEPCONV_TRACE
-  if (t == 0 && d.stats) (reinterpret_cast<uint64_t*>(d.stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x))[6] = wall_clock64();
-#endif
-  issue(0, 0);
-  if (nq > 1) issue(1, 1);
-  int b = 0;
-#pragma unroll 1
-  for (int q = 0; q < nq; ++q) {
-    // younger than chunk q's pieces: the stores of up to two earlier chunks (2 each) and
-    // chunk q + 1's seven pieces
-    const int younger = (q + 1 < nq ? DWP_NI : 0) + 2 * (q < 2 ? q : 2);
-    switch (younger) {
-      case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); break;
-      case 7: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); break;
-      case 9: asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory"); break;
-    }
-    __builtin_amdgcn_s_barrier();       // chunk q visible; everyone is past chunk q - 1
-    asm volatile("" ::: "memory");
-#ifdef EPOS_SEPCONV_TRACE
-    if (t == 0 && d.stats && q == 0) (reinterpret_cast<uint64_t*>(d.stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x))[7] = wall_clock64();
-#endif
-    const int b2 = b >= 1 ? b - 1 : b + 2;        // (q + 2) % 3
-    if (q + 2 < nq) issue(q + 2, b2);
-    u32x4 o0, o1;
-    if (relu_in) {
-      if (interior) compute(b, std::false_type{}, std::true_type{}, o0, o1);
-      else compute(b, std::true_type{}, std::true_type{}, o0, o1);
-    } else {
-      if (interior) compute(b, std::false_type{}, std::false_type{}, o0, o1);
-      else compute(b, std::true_type{}, std::false_type{}, o0, o1);
-    }
-    const int gq = g_lo + 4 * q + g;
-    const bool gok = gq < g_lo + wc;
-    float* dump = g_dw_dump_h2 + t * 4;
-    st4_l2_h2(valid[0] && gok ? d.T + (static_cast<size_t>(toff[0]) + gq * 4) : dump, o0);
-    st4_l2_h2(valid[1] && gok ? d.T + (static_cast<size_t>(toff[1]) + gq * 4) : dump, o1);
-    b = b == DWP_NBUF - 1 ? 0 : b + 1;
-  }
-  static_assert(DWP_NI == 7, "the counted waits assume 7 pieces per wave and chunk");
 }
 
 // Epilogue of the h2 kernel: value = (acc + corr * 2^-11) * 2^-e_n * 2^-e_a + bias
@@ -448,24 +143,35 @@ __device__ __forceinline__ float vec_epilogue_h2(float* ws, const f32x16* acc,
   constexpr int C4 = NB * 8;                 // float4 per staged row (128 / 64 columns)
   constexpr int RPI = 64 / C4;               // rows per wave instruction
   constexpr int NI = 32 / RPI;
-  const int c4 = lane & (C4 - 1), r0 = lane / C4;
+  const int c4 = lane & (C4 - 1);
+  int r0 = lane / C4;
+  // opaque, and behind the K loop's own asm statements: otherwise the sixteen 64-bit row
+  // addresses of the residual / the output (loop invariant) are computed BEFORE the K loop
+  // and live through it -- the residual variants sat at 256 VGPRs with a spill because of it
+  asm volatile("" : "+v"(r0));
   const int n = n0w + c4 * 4;
+  // The residual rows are requested in TWO halves: the first before anything is staged, the
+  // second once the first half of the column blocks has been staged -- their accumulators
+  // are dead by then, so the second half's 32 registers do not come on top of all 128
+  // accumulator registers (requested all at once, the residual + pre-split variant sat at
+  // 256 VGPRs with a spill; round 5).
   float4 rv[HAS_RES ? NI : 1];
-  if (HAS_RES) {
-    const int ncl = n < N ? n : 0;
+  const int ncl = n < N ? n : 0;
+  auto request_res = [&](int i_lo, int i_hi) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
+    for (int i = i_lo; i < i_hi; ++i) {
       int m = m0w + r0 + i * RPI;
       m = m < M ? m : M - 1;
       rv[i] = *reinterpret_cast<const float4*>(p.R + static_cast<int64_t>(m) * p.ldr + ncl);
     }
-  }
+  };
+  if (HAS_RES) request_res(0, NI / 2);
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
+    if (HAS_RES && j == NB / 2) request_res(NI / 2, NI);
     // residual variants (bias4 == nullptr): the bias is added in the row phase below -- a
-    // bias load issued here sits behind the sixteen residual rows in the in-order memory
-    // queue and made this step wait for all of them (3.1 instead of 1.0 us in the trace),
-    // and the registers to request it ahead of them are not there (256 VGPRs)
+    // bias load issued here sits behind the residual rows in the in-order memory queue and
+    // made this step wait for all of them (3.1 instead of 1.0 us in the trace)
     const float bias = bias4 ? bias4[j] : 0.f;
     const float c = cn[j];
     // two rows at a time (v_pk_fma / v_pk_mul / v_pk_add: the same operations per element)
@@ -510,13 +216,6 @@ __device__ __forceinline__ float vec_epilogue_h2(float* ws, const f32x16* acc,
 #pragma unroll
     for (int i = 0; i < NI; ++i) v[i] = relu4(v[i]);
   }
-  if (!HAS_RES && p.softmax64) {
-    // the fragment-confidence head: softmax over each aligned group of 64 columns = the 16
-    // lanes x float4 that hold it in a staged row (the arithmetic of the stand-alone
-    // kernel, h2_scale.h). Uniform per problem; every lane takes part in the shuffles.
-#pragma unroll
-    for (int i = 0; i < NI; ++i) v[i] = softmax64_lane16(v[i]);
-  }
   if (!HAS_RES && p.col_sums) {
     // column sums of this wave's 32 stored rows (image pooling, model.py:220): rows in the
     // order the lane holds them, then the two half-waves (even / odd rows); lanes 0..31 write
@@ -560,21 +259,14 @@ __device__ __forceinline__ float vec_epilogue_h2(float* ws, const f32x16* acc,
 
 // PRESPLIT: every problem of the launch has its A operand already as fp16 pairs
 // (EposPointwiseArgs.a_presplit; the plan does not mix the two kinds in one group).
-// DW: fused separable conv (the producer phase above; SINGLE, PRESPLIT, not CONV).
-// NST: stages of the LDS-DMA ring. Five = 80 KB = two workgroups per CU. A launch that cannot
-// give a CU a second workgroup anyway (a single image's 228-tile layers, one launch at a
-// time) may take a deeper ring: with one wave per SIMD the K loop is bound by the bytes in
-// flight per CU (64 KB at look-ahead 4 -> ~50 B/ns of the 85-128 the load path sustains).
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, bool DW = false, int NB = 4,
-          int NW = 4, int NST = H2Geo<NB, NW>::NST>
-__global__ __launch_bounds__(NW * 64, 2)
-void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
-  static_assert(NB == 4 || (NB == 2 && !DW), "tile = 128 x 128, 256 x 128 or 128 x 64");
-  static_assert(NW == 4 || (NW == 8 && !DW && (NB == 4 || !CONV)),
-                "eight waves: 8 x 1 (256 x 128), or 4 x 2 (128 x 128, plain 1x1 only)");
-  static_assert(NST == H2Geo<NB, NW>::NST || (NB == 4 && !DW && !CONV), "other ring depths: plain tiles only");
-  using Geo = H2Geo<NB, NW>;
-  constexpr int BM = Geo::BM;
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, int NB = 4>
+__global__ __launch_bounds__(256, 2)
+void pointwise_gemm_h2_f32(GroupedArgs ga_) {
+  static_assert(NB == 4 || NB == 2, "tile = 128 x 128 or 128 x 64");
+  using Geo = H2Geo<NB>;
+  constexpr int NW = 4;                        // waves 4 x 1: a wave owns 32 rows
+  constexpr int NST = H2_NST;
+  constexpr int BM = H2_BM;
   constexpr int NP = Geo::NP;
   constexpr int NA = Geo::NA;
   constexpr int LA = NST - 1;                  // tiles issued ahead of the one computed
@@ -584,12 +276,10 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wrow = Geo::WC == 2 ? (wave & 3) : wave;     // the wave's 32-row group
-  const int wcol = Geo::WC == 2 ? (wave >> 2) : 0;      //            column half (4 x 2 waves)
+  const int wrow = wave;                       // the wave's 32-row group
   const int l31 = lane & 31, h = lane >> 5;
 
   (void)ga_;
-  (void)dw_;
   H2_STAMP(0);
   const GroupedArgs* __restrict__ gp =
       (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -607,7 +297,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
              l1 = static_cast<uint64_t>(q.ldc), l2 = static_cast<uint64_t>(q.ldr);
     int i0 = q.M, i1 = q.N, i2 = q.K, i3 = q.relu, i4 = q.sub, i5 = gp->tiles_n[0],
         i6 = gp->tile_start[MAX_GROUP], i7 = q.Ho, i8 = q.Wo, i9 = q.Hi, i10 = q.Wi,
-        i11 = q.c_stream, i12 = q.softmax64;
+        i11 = q.c_stream;
     uint64_t a9 = reinterpret_cast<uint64_t>(q.col_sums), l3 = static_cast<uint64_t>(q.col_ld);
     unsigned u0 = gp->tn_mul[0], u1 = gp->tn_sh1[0], u2 = gp->tn_sh2[0];
     float f0 = q.a_gain, f1 = q.a_bias;
@@ -615,22 +305,9 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
                  "s"(a8), "s"(l0), "s"(l1), "s"(l2));
     asm volatile("" : : "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5), "s"(i6), "s"(u0),
                  "s"(u1), "s"(u2), "s"(f0), "s"(f1));
-    asm volatile("" : : "s"(i7), "s"(i8), "s"(i9), "s"(i10), "s"(i11), "s"(i12), "s"(a9), "s"(l3));
+    asm volatile("" : : "s"(i7), "s"(i8), "s"(i9), "s"(i10), "s"(i11), "s"(a9), "s"(l3));
   }
   int bid;
-  if constexpr (DW) {
-    // Fused separable conv: an XCD (blockIdx % 8) owns WHOLE row tiles, so that the
-    // workgroups that share a row tile -- and hand the depthwise slices to each other --
-    // sit behind the same L2: the hand-off then needs neither write-through stores nor an
-    // L2 invalidate (plain stores are in L2 once vmcnt says so, the siblings' LDS-DMA reads
-    // hit them there). Surplus workgroups of XCDs with one row tile less leave at once.
-    const int tn = gp->tiles_n[0];
-    const int tiles_m = (gp->p[0].M + H2_BM - 1) / H2_BM;
-    const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int rt_lo = x * tiles_m / 8, rt_n = (x + 1) * tiles_m / 8 - rt_lo;
-    if (idx >= rt_n * tn) return;
-    bid = rt_lo * tn + idx;
-  } else
   {   // workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles
     const int total = gp->tile_start[MAX_GROUP];
     const int raw = blockIdx.x, x = raw & 7, idx = raw >> 3;
@@ -651,7 +328,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
   // tile order inside an XCD's range: column fastest; wide problems in bands of 8 column
   // tiles (all row tiles of a band before the next band), as in the split kernel
   int tile_m, tile_n;
-  if (DW || tiles_n <= 8) {       // DW: the siblings of a row tile must be neighbours
+  if (tiles_n <= 8) {
     const H2Div dv = {gp->tn_mul[pi], gp->tn_sh1[pi], gp->tn_sh2[pi]};
     tile_m = static_cast<int>(h2_div(static_cast<unsigned>(bid), dv));
     tile_n = bid - tile_m * tiles_n;
@@ -667,16 +344,16 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
   }
   const int m0 = tile_m * BM, n0 = tile_n * Geo::BN;
   const int tn128 = Geo::BN == 128 ? tiles_n : (tiles_n + 1) >> 1;   // packed W: 128-column images
-  const int n0w = n0 + wcol * 64;                                       // this wave's first column
+  const int n0w = n0;                                                   // this wave's first column
   const int nks = (K + H2_BK - 1) / H2_BK;
   const int cblocks = CONV ? gp->conv_cin[pi] / H2_BK : 1;   // channel blocks per tap
   const int crate = CONV ? gp->conv_rate[pi] : 1;
 
   // The scale of A comes from a global load (the absmax slot) + a wave reduction: ~2 us of
   // latency that the first LDS-DMA stages can hide -- so it is computed AFTER the prologue's
-  // DMA issue (below), except in the fused form, whose producer phase needs it first.
+  // DMA issue (below).
   // (Only in the variants with registers to spare: the residual ones sit at 256 VGPRs.)
-  constexpr bool LATE_SCALE = !DW && !HAS_RES;
+  constexpr bool LATE_SCALE = !HAS_RES;
   constexpr bool EARLY_EPI = !HAS_RES;
   float sa_v = 0.f, inv_a = 0.f, sa = 0.f;
   unsigned am_raw = 0, am_raw2 = 0;
@@ -706,72 +383,6 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
 
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(
       (__attribute__((address_space(3))) float*)smem));
-
-  if constexpr (DW) {
-    // ---- producer phase: my channel slice of this row tile's depthwise output ----
-    const DwPhaseH2* __restrict__ dp = reinterpret_cast<const DwPhaseH2*>(
-        reinterpret_cast<const char*>(gp) + ((sizeof(GroupedArgs) + 7) & ~size_t(7)));
-    const DwPhaseH2 d = *dp;
-    const int c4n = K >> 2;
-    int* flag = reinterpret_cast<int*>(smem + DWP_FLAG / 4);
-    h2_gu32* cnt = (h2_gu32*)(d.sync + 2 * tile_m);
-    int late = 0;
-#ifdef EPOS_SEPCONV_TRACE      // tools/sepconv_h2_trace.py: 100 MHz stamps per workgroup
-    uint64_t* trc = reinterpret_cast<uint64_t*>(d.stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x);
-    if (t == 0) trc[0] = wall_clock64();
-#endif
-#pragma unroll 1
-    for (int pass = 0; pass < tiles_n; ++pass) {
-      // pass 0: my slice; further passes (only after a time-out): the siblings' slices
-      const int sl = pass == 0 ? tile_n : (pass <= tile_n ? pass - 1 : pass);
-      const int g_lo = sl * c4n / tiles_n;
-      const int wc = (sl + 1) * c4n / tiles_n - g_lo;
-      dw_produce_h2(d, smem, lds0, M, m0, g_lo, wc, sa, t);
-#ifdef EPOS_SEPCONV_TRACE
-      if (t == 0 && pass == 0) trc[1] = wall_clock64();
-#endif
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // every storing wave drains
-      __syncthreads();
-#ifdef EPOS_SEPCONV_TRACE
-      if (t == 0 && pass == 0) trc[2] = wall_clock64();
-#endif
-      if (pass == 0) {
-        if (t == 0) {
-          __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint64_t t0 = wall_clock64();
-          int lt = 0;
-          while (__hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                 static_cast<unsigned>(tiles_n)) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > d.timeout) { lt = 1; break; }
-          }
-          *flag = lt;
-#ifdef EPOS_SEPCONV_TRACE
-          trc[3] = wall_clock64();
-#endif
-        }
-        __syncthreads();
-        late = *flag;
-        if (!late) break;          // uniform: every slice of the row tile is in memory
-      }
-    }
-    if (t == 0) {
-      if (late && d.stats)
-        __hip_atomic_fetch_add((h2_gu32*)d.stats, 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-      // no acquire: the siblings are behind this XCD's L2 (see the tile mapping above)
-      // departures: the last sibling re-arms the pair for the next launch of this layer
-      if (__hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-          static_cast<unsigned>(tiles_n - 1)) {
-        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#ifdef EPOS_SEPCONV_TRACE
-      trc[4] = wall_clock64();
-#endif
-    }
-    __syncthreads();
-  }
 
   // ---- A pieces (1 KB = 16 rows x 64 B): piece = wave*2 + i, lane -> (row, slot);
   //      slot s of row r holds chunk s ^ ((r >> 2) & 3)
@@ -833,7 +444,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
         src = ok ? src : zero_chunk;
       } else if constexpr (!TAIL) {
         // full K step of a 1x1 conv: scalar base + 32-bit lane offset
-        if constexpr (PIECE == 0 || !(H2_DS_PAIRED || NB == 2)) {
+        if constexpr (PIECE == 0) {
           glds16_s_m0(avoff[PIECE], abase + kt * H2_BK, a_dst[PIECE] + so);
         } else {
           const float* ab = abase + (kt * H2_BK - PIECE * 256);      // uniform
@@ -844,13 +455,12 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
         src = asrc[PIECE] + kt * H2_BK;
         src = (kt * H2_BK + achunk[PIECE] < K) ? src : zero_chunk;
       }
-      if constexpr (PIECE == 0 || !(H2_DS_PAIRED || NB == 2)) glds16_v_m0(src, a_dst[PIECE] + so);
+      if constexpr (PIECE == 0) glds16_v_m0(src, a_dst[PIECE] + so);
       else glds16_v_off<PIECE * 1024>(src - PIECE * 256);
     } else {
       const float* wb = wsb + static_cast<int64_t>(kt) * (H2_W_BYTES / 4);
       if constexpr (PIECE == 2) glds16_s_m0(wvoff, wb, w_dst + so);
-      else if constexpr (H2_DS_PAIRED) glds16_s_off<1024>(wvoff, wb);
-      else glds16_s_m0(wvoff, wb + 256, w_dst + so + 1024);
+      else glds16_s_off<1024>(wvoff, wb);        // shares the M0 write of piece 2
     }
   };
   auto issue = [&](int kt, int stage) {
@@ -868,7 +478,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
     for (int j = 0; j < 2; ++j)
       a_off[j] = Geo::W_LDS / 4 + (wrow * 32 + l31) * H2_BK + (((2 * h + j) ^ sw) << 2);
   }
-  const int b_off = lane * 4 + wcol * 1024;   // + (cb*2 + piece) * 256 floats
+  const int b_off = lane * 4;   // + (cb*2 + piece) * 256 floats
 
   float4 xa[2];             // raw fp32 A fragments of the NEXT stage to compute
   u32x4 bp[4][2];           // W fragments {hi, mid} per column block (NB of them live)
@@ -985,7 +595,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
 #else
       constexpr bool kIssue = true;
 #endif
-      if constexpr (kIssue && ISSUE && DMA >= 0 && DMA < H2_NP && (DMA < 3 || Geo::NWP == 2)) {
+      if constexpr (kIssue && ISSUE && DMA >= 0 && DMA < H2_NP) {
         __builtin_amdgcn_sched_barrier(0);
         issue_piece(kt + LA, s4, std::integral_constant<int, DMA>{},
                     std::integral_constant<bool, MODE == 1>{});
@@ -1004,7 +614,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
     using I3 = std::integral_constant<int, 3>;
     // first half: column blocks 0 and 1 interleaved (consecutive MFMAs never on the same
     // accumulator), small terms first per accumulator; the four DMA pieces ride along
-#define H2_D(i) std::integral_constant<int, h2_piece_at(i)>{}
+#define H2_D(i) std::integral_constant<int, ((i) < H2_NP ? (i) : -1)>{}   // the four pieces behind the first four MFMAs
     step(ah, bp[0][1], corr[0], H2_D(0), N_{});
     step(ah, bp[1][1], corr[1], H2_D(1), N_{});
     step(am, bp[0][0], corr[0], H2_D(2), N_{});
@@ -1014,9 +624,9 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
     if constexpr (MODE != LAST) {
       // my reads of this stage are complete (fragments are in registers); my pieces of
       // tile kt+1 have landed once at most the later tiles' pieces are outstanding
-      // (of tile kt+LA: the H2_DS_FIRST pieces issued above)
+      // (of tile kt+LA: the four pieces issued above)
 #ifndef EPOS_H2_ABL_NOBAR
-      if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + (Geo::NWP == 2 ? H2_DS_FIRST : H2_DS_FIRST3)>();
+      if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_NP>();
       else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
       __builtin_amdgcn_s_barrier();
 #endif
@@ -1166,13 +776,6 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
   }
 
   H2_STAMP(3);
-#ifdef EPOS_SEPCONV_TRACE
-  if constexpr (DW) {
-    const DwPhaseH2* dq = reinterpret_cast<const DwPhaseH2*>(
-        reinterpret_cast<const char*>(gp) + ((sizeof(GroupedArgs) + 7) & ~size_t(7)));
-    if (t == 0) (reinterpret_cast<uint64_t*>(dq->stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x))[5] = wall_clock64();
-  }
-#endif
   // ---- epilogue --------------------------------------------------------------
 #ifdef EPOS_H2_ABL_NOEPI            // ablation (tools/power_components_h2.py): no epilogue
   if (p.ldr != 0x7fffffff) return;  // (always taken; the compiler cannot know)
@@ -1198,15 +801,24 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
       // ONE atomic per workgroup: the workgroups of a launch finish together, and their
       // atomics all land on the slot's two cache lines -- one per wave (912 for a middle-flow
       // launch) kept the launch alive ~2 us after its last store (profiles/r04).
+      // (shuffles through an OPAQUE copy of the lane id: __shfl_xor's six permute indices are
+      // otherwise shared with the scale reduction of the prologue and kept in registers
+      // through the whole K loop -- the residual variants spilled one of them)
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      auto xor_max = [&](float x, int o) {
+        return fmaxf(x, __int_as_float(__builtin_amdgcn_ds_bpermute((lane_e ^ o) << 2,
+                                                                    __float_as_int(x))));
+      };
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      for (int o = 32; o > 0; o >>= 1) amax = xor_max(amax, o);
       float* red = smem + NW * 32 * Geo::EP_ROW;           // behind every wave's staged rows
       if (lane == 0) red[wave] = amax;
       __syncthreads();
       if (wave == 0) {
         float v = lane < NW ? red[lane] : 0.f;
 #pragma unroll
-        for (int o = NW / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+        for (int o = NW / 2; o > 0; o >>= 1) v = xor_max(v, o);
         if (lane == 0)
           __hip_atomic_fetch_max(p.c_amax + (blockIdx.x & (EPOS_AMAX_WORDS - 1)),
                                  __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1252,13 +864,11 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_, DwPhaseH2 dw_) {
   }
 }
 
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, bool DW = false,
-          int NB = 4, int NW = 4, int NST = H2Geo<NB, NW>::NST>
-int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s,
-                 const DwPhaseH2* dw = nullptr) {
-  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, DW, NB, NW, NST>;
-  constexpr int lds = NST * H2Geo<NB, NW>::STAGE;
-  static_assert(lds >= (NW * 32 * H2Geo<NB, NW>::EP_ROW + NW) * 4, "the epilogue stages through the ring");
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, int NB = 4>
+int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
+  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, NB>;
+  constexpr int lds = H2Geo<NB>::LDS;
+  static_assert(lds >= (4 * 32 * H2Geo<NB>::EP_ROW + 4) * 4, "the epilogue stages through the ring");
   // more than 64 KB of dynamic LDS needs the attribute, once per device (per instantiation)
   static std::mutex mu;
   static bool attr_set[RING_DEVICES] = {};
@@ -1277,10 +887,8 @@ int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s,
       attr_set[dev] = true;
     }
   }
-  // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD; the 256 x 128
-  // tile takes 144 KB: one eight-wave workgroup per CU = the same two waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(NW * 64), lds, s, g,
-                     dw ? *dw : DwPhaseH2{});
+  // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD
+  hipLaunchKernelGGL(kern, dim3(total), dim3(256), lds, s, g);
   return launch_status("pointwise_gemm_h2_f32");
 }
 
@@ -1425,31 +1033,29 @@ int& narrow_limit() {
   return v;
 }
 
-// "Latency mode": launches of at most this many 128 x 128 tiles (and more than the narrow
-// limit) run the eight-wave form of the tile. 0 = never.
-int& latency_limit() {
-  static int v = [] {
-    const char* e = getenv("EPOS_H2_LATENCY_MAX_TILES");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
-// Launches of at least this many 128 x 128 tiles run as 256 x 128 tiles. 0 = never.
-int& tall_limit() {
-  static int v = [] {
-    const char* e = getenv("EPOS_H2_TALL_MIN_TILES");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
 int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                       const int* conv_cin, const int* conv_rate) {
   if (conv_cin && (count != 1 || args[0].R != nullptr)) {
     set_error("launch_grouped_h2: implicit conv = one problem without residual");
     return EPOS_E_INVALID;
   }
+  // one launch = one kind of problem: a group that mixes pre-split and fp32 A operands is
+  // refused (the plan never builds one); a group with a residual goes out problem by problem
+  // (same bits: an element's value does not depend on the launch it is computed in)
+  for (int i = 1; i < count; ++i)
+    if ((args[i].a_presplit != 0) != (args[0].a_presplit != 0)) {
+      set_error("launch_grouped_h2: the problems of a group must agree on a_presplit");
+      return EPOS_E_INVALID;
+    }
+  if (count > 1)
+    for (int i = 0; i < count; ++i)
+      if (args[i].R) {
+        for (int j = 0; j < count; ++j) {
+          const int rc = launch_grouped_h2(args + j, 1, s, nullptr, nullptr);
+          if (rc) return rc;
+        }
+        return EPOS_OK;
+      }
   GroupedArgs g = {};
   g.count = count;
   int total = 0;
@@ -1480,14 +1086,14 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
     g.conv_cin[i] = conv_cin ? conv_cin[i] : 0;
     g.conv_rate[i] = conv_rate ? conv_rate[i] : 1;
   }
-  auto lay_out = [&](int bn, int bm = H2_BM) {
+  auto lay_out = [&](int bn) {
     total = 0;
     for (int i = 0; i < count; ++i) {
       g.tile_start[i] = total;
       g.tiles_n[i] = static_cast<int>(ceil_div(args[i].N, bn));
       set_tn_div(g, i);
       g.npad[i] = static_cast<int>(ceil_div(args[i].N, H2_BN)) * H2_BN;
-      total += static_cast<int>(ceil_div(args[i].M, bm)) * g.tiles_n[i];
+      total += static_cast<int>(ceil_div(args[i].M, H2_BM)) * g.tiles_n[i];
     }
     for (int i = count; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
   };
@@ -1497,18 +1103,11 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
   // (ASPP 1x1, concat projection: two thirds of the CUs idle otherwise), a LOSS from ~150
   // tiles on -- at 228 tiles (a single image's middle-flow layers) two narrow workgroups per
   // CU are slower than one wide one, because a narrow tile moves 1.5x the LDS-DMA bytes per
-  // MFMA and the DMA issue is what the loop waits for. Hence the default limit of 100. Same
-  // bits either way (an element's K sum does not depend on the tile). EPOS_H2_BN64_MAX_TILES
-  // or epos_set_h2_narrow_tile_limit (0 = never).
+  // MFMA. Hence the default limit of 100. Same bits either way (an element's K sum does not
+  // depend on the tile). EPOS_H2_BN64_MAX_TILES or epos_set_h2_narrow_tile_limit (0 = never).
   bool narrow = !conv_cin && total <= __atomic_load_n(&narrow_limit(), __ATOMIC_RELAXED);
   for (int i = 0; i < count; ++i) narrow = narrow && !args[i].col_sums;
   if (narrow) lay_out(64);
-  // A launch of MANY tiles runs as 256 x 128 tiles (eight waves, one workgroup per CU): a
-  // quarter less L2 -> LDS traffic per MFMA. Same bits. EPOS_H2_TALL_MIN_TILES or
-  // epos_set_h2_tall_tile_min (0 = never).
-  const int tall_min = __atomic_load_n(&tall_limit(), __ATOMIC_RELAXED);
-  const bool tall = !narrow && tall_min > 0 && total >= tall_min;
-  if (tall) lay_out(H2_BN, 2 * H2_BM);
   g.zero_chunk = zero_chunk_dev();
   if (!g.zero_chunk) {
     set_error("launch_grouped_h2: cannot allocate the zero chunk");
@@ -1517,177 +1116,24 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
   const bool res = args[0].R != nullptr;
   const bool single = count == 1;
   const bool ps = args[0].a_presplit != 0;
-  for (int i = 1; i < count; ++i)
-    if ((args[i].a_presplit != 0) != ps) {
-      set_error("launch_grouped_h2: the problems of a group must agree on a_presplit");
-      return EPOS_E_INVALID;
-    }
-  if (conv_cin) return tall ? launch_h2_tt<false, true, true, false, false, 4, 8>(g, total, s)
-                            : launch_h2_tt<false, true, true>(g, total, s);
-  if (tall) {
-    if (ps) {
-      if (res) return single ? launch_h2_tt<true, true, false, true, false, 4, 8>(g, total, s)
-                             : launch_h2_tt<true, false, false, true, false, 4, 8>(g, total, s);
-      return single ? launch_h2_tt<false, true, false, true, false, 4, 8>(g, total, s)
-                    : launch_h2_tt<false, false, false, true, false, 4, 8>(g, total, s);
-    }
-    if (res) return single ? launch_h2_tt<true, true, false, false, false, 4, 8>(g, total, s)
-                           : launch_h2_tt<true, false, false, false, false, 4, 8>(g, total, s);
-    return single ? launch_h2_tt<false, true, false, false, false, 4, 8>(g, total, s)
-                  : launch_h2_tt<false, false, false, false, false, 4, 8>(g, total, s);
-  }
-  if (!narrow && total <= __atomic_load_n(&latency_limit(), __ATOMIC_RELAXED)) {
-    bool ok = true;                       // block sums are laid out for four-wave tiles
-    for (int i = 0; i < count; ++i) ok = ok && !args[i].col_sums;
-    if (ok) {
-      if (ps) {
-        if (res) return single ? launch_h2_tt<true, true, false, true, false, 2, 8>(g, total, s)
-                               : launch_h2_tt<true, false, false, true, false, 2, 8>(g, total, s);
-        return single ? launch_h2_tt<false, true, false, true, false, 2, 8>(g, total, s)
-                      : launch_h2_tt<false, false, false, true, false, 2, 8>(g, total, s);
-      }
-      if (res) return single ? launch_h2_tt<true, true, false, false, false, 2, 8>(g, total, s)
-                             : launch_h2_tt<true, false, false, false, false, 2, 8>(g, total, s);
-      return single ? launch_h2_tt<false, true, false, false, false, 2, 8>(g, total, s)
-                    : launch_h2_tt<false, false, false, false, false, 2, 8>(g, total, s);
-    }
-  }
+  // Kernel instantiations (11): 128 x 128 tiles -- single problem {residual} x {pre-split A},
+  // group {pre-split A}, implicit 3x3 conv; 128 x 64 tiles (always the group form, which also
+  // serves one problem) {residual} x {pre-split A}.
+  if (conv_cin) return launch_h2_tt<false, true, true>(g, total, s);
   if (narrow) {
-    if (ps) {
-      if (res) return single ? launch_h2_tt<true, true, false, true, false, 2>(g, total, s)
-                             : launch_h2_tt<true, false, false, true, false, 2>(g, total, s);
-      return single ? launch_h2_tt<false, true, false, true, false, 2>(g, total, s)
-                    : launch_h2_tt<false, false, false, true, false, 2>(g, total, s);
-    }
-    if (res) return single ? launch_h2_tt<true, true, false, false, false, 2>(g, total, s)
-                           : launch_h2_tt<true, false, false, false, false, 2>(g, total, s);
-    return single ? launch_h2_tt<false, true, false, false, false, 2>(g, total, s)
-                  : launch_h2_tt<false, false, false, false, false, 2>(g, total, s);
+    if (ps) return res ? launch_h2_tt<true, false, false, true, 2>(g, total, s)
+                       : launch_h2_tt<false, false, false, true, 2>(g, total, s);
+    return res ? launch_h2_tt<true, false, false, false, 2>(g, total, s)
+               : launch_h2_tt<false, false, false, false, 2>(g, total, s);
   }
-  if (ps) {
-    if (res) return single ? launch_h2_tt<true, true, false, true>(g, total, s)
-                           : launch_h2_tt<true, false, false, true>(g, total, s);
-    return single ? launch_h2_tt<false, true, false, true>(g, total, s)
-                  : launch_h2_tt<false, false, false, true>(g, total, s);
+  if (single) {
+    if (ps) return res ? launch_h2_tt<true, true, false, true>(g, total, s)
+                       : launch_h2_tt<false, true, false, true>(g, total, s);
+    return res ? launch_h2_tt<true, true, false>(g, total, s)
+               : launch_h2_tt<false, true, false>(g, total, s);
   }
-  if (res) return single ? launch_h2_tt<true, true, false>(g, total, s)
-                         : launch_h2_tt<true, false, false>(g, total, s);
-  return single ? launch_h2_tt<false, true, false>(g, total, s)
-                : launch_h2_tt<false, false, false>(g, total, s);
-}
-
-// The fused kernel's hand-off assumes that workgroups whose block indices agree modulo 8
-// run on the same XCD (the dispatcher deals workgroups round robin over the XCDs). That is
-// probed ONCE per device (64 workgroups report HW_REG_XCC_ID; blocking, so never during a
-// stream capture): if it does not hold -- or cannot be probed yet -- the fused path is not
-// taken and epos_separable_conv_f32 issues the two launches.
-__global__ void xcc_probe_kernel(unsigned* out) {
-  unsigned x;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-  if (threadIdx.x == 0) out[blockIdx.x] = x & 15u;
-}
-int xcd_mapping_state(hipStream_t s) {      // 1 ok, 0 not ok, -1 unknown (capturing)
-  static std::mutex mu;
-  static int state[RING_DEVICES];
-  static bool init = false;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!init) {
-    for (int i = 0; i < RING_DEVICES; ++i) state[i] = -1;
-    init = true;
-  }
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RING_DEVICES) return 0;
-  if (state[dev] >= 0) return state[dev];
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
-    return -1;
-  constexpr int NB = 256;
-  unsigned* dbuf = nullptr;
-  unsigned host[NB];
-  int ok = 0;
-  if (hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(host)) == hipSuccess) {
-    hipLaunchKernelGGL(xcc_probe_kernel, dim3(NB), dim3(64), 0, s, dbuf);
-    if (hipMemcpyAsync(host, dbuf, sizeof(host), hipMemcpyDeviceToHost, s) == hipSuccess &&
-        hipStreamSynchronize(s) == hipSuccess) {
-      ok = 1;
-      for (int b = 8; b < NB; ++b) ok = ok && host[b] == host[b & 7];
-    }
-    (void)hipFree(dbuf);
-  }
-  state[dev] = ok;
-  return ok;
-}
-
-// Fused separable conv on the fp16-pair kernel (epos_separable_conv_f32). The caller has
-// checked eligibility (sepconv_h2_eligible).
-bool sepconv_h2_eligible(const EposSepConvArgs* a) {
-  const EposDepthwiseArgs& d = a->dw;
-  const EposPointwiseArgs& p = a->pw;
-  if (!(p.Wh && p.a_amax && p.a_presplit && d.y_h2)) return false;
-  if (!h2_eligible(&p, 1)) return false;
-  // the GEMM derives the scale of its A operand from its own fields: they must be the
-  // ones the depthwise output was described with
-  if (d.x_amax != p.a_amax || d.x_amax2 != p.a_amax2 || d.gain != p.a_gain ||
-      d.bias0 != p.a_bias)
-    return false;
-  if (d.rate < 1 || d.rate > DWP_PADL) return false;
-  const int64_t xbytes = static_cast<int64_t>(d.B) * d.Hi * d.Wi * d.ldx * 4;
-  return xbytes < (1LL << 32) && (reinterpret_cast<uintptr_t>(d.w9c) & 15) == 0 &&
-         (reinterpret_cast<uintptr_t>(d.bias) & 15) == 0;
-}
-
-int launch_sepconv_h2(const EposSepConvArgs* a, hipStream_t s) {
-  if (xcd_mapping_state(s) != 1) {          // not proven: the two launches (same bits)
-    const int rd = epos_depthwise3x3_f32(&a->dw, s);
-    if (rd) return rd;
-    return epos_pointwise_conv_f32(&a->pw, s);
-  }
-  const EposPointwiseArgs& pw = a->pw;
-  const EposDepthwiseArgs& dwa = a->dw;
-  GroupedArgs g = {};
-  g.count = 1;
-  g.p[0] = pw;
-  g.tile_start[0] = 0;
-  g.tiles_n[0] = static_cast<int>(ceil_div(pw.N, H2_BN));
-  set_tn_div(g, 0);
-  g.npad[0] = g.tiles_n[0] * H2_BN;
-  g.conv_rate[0] = 1;
-  const int total = static_cast<int>(ceil_div(pw.M, H2_BM)) * g.tiles_n[0];
-  for (int i = 1; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
-  g.zero_chunk = zero_chunk_dev();
-  if (!g.zero_chunk) {
-    set_error("launch_sepconv_h2: cannot allocate the zero chunk");
-    return EPOS_E_INVALID;
-  }
-  auto sp = [](unsigned d) {
-    H2Div f;
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    f.mul = static_cast<unsigned>(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.sh1 = l > 0 ? 1 : 0;
-    f.sh2 = l > 0 ? l - 1 : 0;
-    return f;
-  };
-  static const unsigned timeout = [] {      // EPOS_SEPCONV_TIMEOUT_US (default 200)
-    const char* e = getenv("EPOS_SEPCONV_TIMEOUT_US");
-    return static_cast<unsigned>((e ? atoi(e) : 200) * 100);
-  }();
-  DwPhaseH2 d = {};
-  d.X = dwa.X; d.ldx = dwa.ldx;
-  d.w9c = dwa.w9c; d.bias = dwa.bias;
-  d.T = dwa.Y; d.ldt = dwa.ldy;
-  d.sync = a->sync;
-  d.stats = a->stats;
-  d.Hi = dwa.Hi; d.Wi = dwa.Wi; d.rate = dwa.rate; d.C = dwa.C;
-  d.relu_in = dwa.relu_in; d.relu_out = dwa.relu_out;
-  d.timeout = timeout;
-  d.dw = sp(static_cast<unsigned>(dwa.Wi));
-  d.dh = sp(static_cast<unsigned>(dwa.Hi));
-  // XCD-aligned grid: 8 x (row tiles of the fullest XCD) x column tiles (surplus exits)
-  const int tiles_m = static_cast<int>(ceil_div(pw.M, H2_BM));
-  const int grid = 8 * static_cast<int>(ceil_div(tiles_m, 8)) * g.tiles_n[0];
-  return pw.R != nullptr ? launch_h2_tt<true, true, false, true, true>(g, grid, s, &d)
-                         : launch_h2_tt<false, true, false, true, true>(g, grid, s, &d);
+  return ps ? launch_h2_tt<false, false, false, true>(g, total, s)
+            : launch_h2_tt<false, false, false>(g, total, s);
 }
 
 }  // namespace epos
@@ -1699,23 +1145,9 @@ extern "C" int epos_debug_set_gemm_trace(uint64_t* buf) {
 }
 #endif
 
-extern "C" int epos_set_h2_latency_tile_limit(int max_tiles) {
-  return __atomic_exchange_n(&epos::latency_limit(), max_tiles < 0 ? 0 : max_tiles,
-                             __ATOMIC_RELAXED);
-}
-
-extern "C" int epos_set_h2_tall_tile_min(int min_tiles) {
-  return __atomic_exchange_n(&epos::tall_limit(), min_tiles < 0 ? 0 : min_tiles,
-                             __ATOMIC_RELAXED);
-}
-
 extern "C" int epos_set_h2_narrow_tile_limit(int max_tiles) {
   return __atomic_exchange_n(&epos::narrow_limit(), max_tiles < 0 ? 0 : max_tiles,
                              __ATOMIC_RELAXED);
-}
-
-extern "C" int epos_separable_conv_fused_state(void* stream) {
-  return epos::xcd_mapping_state(static_cast<hipStream_t>(stream));
 }
 
 extern "C" int epos_amax_clear(uint32_t* slots, int64_t n_slots, void* stream) {

@@ -28,6 +28,8 @@
 // per stage as in pointwise_gemm_dma_f32.
 #include <string.h>
 
+#include <mutex>
+
 #include "pointwise_gemm.h"
 
 namespace epos {
@@ -78,142 +80,12 @@ __device__ __forceinline__ void mfma_bf16(const u32x4& a, const u32x4& b, f32x16
                                               __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// ---------------------------------------------------------------------------------
-// Fused separable conv (DW): the depthwise 3x3 of a sep-conv runs as a PRODUCER PHASE
-// of the pointwise GEMM's own workgroups instead of as a launch of its own. The
-// tiles_n workgroups that share a row tile (the "siblings": consecutive tile indices,
-// column fastest) each compute the depthwise output of the tile's rows for 1/tiles_n of
-// the channels, store it write-through (sc1) to the intermediate tensor T, and hand it
-// to each other through an arrival counter (placement-independent agent-scope protocol
-// of cdna_hip_programming.md, Guideline 16 R1: every storing wave drains its stores,
-// ONE lane bumps the counter, ONE lane polls it relaxed, ONE agent acquire, barrier,
-// plain loads). Every depthwise value is computed exactly once (same fmaf chain as
-// depthwise3x3_s1_kernel: the fused and the two-launch paths give the same bits).
-//
-// Why: a depthwise launch is latency bound (8.8 us for 28 MB, 2x a plain copy) and, with
-// several images in flight, cannot start while two GEMM workgroups per CU hold all of
-// its LDS and registers -- its time was purely additive (0.65 of 3.0 ms per image). As
-// a phase of a GEMM workgroup it owns a slot by construction, and the CU's OTHER GEMM
-// workgroup (usually another image's) keeps the matrix pipe busy meanwhile.
-//
-// Progress does not depend on co-scheduling: a workgroup that has waited `timeout`
-// (100 MHz ticks) for its siblings computes their slices itself (identical values, so
-// concurrent duplicate stores are benign) and goes on.
-// ---------------------------------------------------------------------------------
-struct SpDiv { unsigned mul, sh1, sh2; };          // n / d by multiply-shift (32-bit n)
-struct DwPhase {
-  const float* X; int64_t ldx;                     // depthwise input, NHWC
-  const float* w9c; const float* bias;             // [9][C] (BN folded), [C]
-  float* T; int64_t ldt;                           // depthwise output = the GEMM's A
-  unsigned* sync;                                  // [tiles_m][2] arrivals, departures
-  unsigned* stats;                                 // [2] time-outs (diagnostics) or null
-  int Hi, Wi, rate, relu_in, relu_out;
-  unsigned timeout;                                // 100 MHz ticks
-  SpDiv dw, dh;                                    // / Wi, / Hi
-};
-typedef __attribute__((address_space(1))) unsigned gu32;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned sp_div(unsigned n, const SpDiv& f) {
-  const unsigned t = __umulhi(f.mul, n);
-  return (t + ((n - t) >> f.sh1)) >> f.sh2;
-}
-__device__ __forceinline__ void st4_wt(float* p, f32x4 v) {      // write-through store
-  // s_nop: a store of more than 64 bits reads its data VGPRs after issue; the compiler does
-  // not know this asm is one and would not keep the next VALU write away from them
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ float relu_1op_sp(float x) {          // as layers.hip
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-
-// Depthwise 3x3 (stride 1, dilation `rate`, TF 'SAME') of rows [m0, m0 + BM) for channel
-// slice `slice` of `nslices`: lanes walk the channel axis (float4 each, LW lanes per
-// pixel), 256 / LW pixels per pass, two pixels (18 independent loads) in flight per
-// thread. Loads are unconditional from clamped addresses, zero padding is a select.
-template <int BM>
-__device__ __forceinline__ void dw_slice(const DwPhase& d, int M, int c4n, int m0,
-                                         int slice, int nslices, int t) {
-  const int c_lo = slice * c4n / nslices;
-  const int wc = (slice + 1) * c4n / nslices - c_lo;
-  const int lw_log = wc <= 16 ? 4 : wc <= 32 ? 5 : 6;
-  const int LW = 1 << lw_log, PPP = 256 >> lw_log;
-  const int Hi = d.Hi, Wi = d.Wi, r = d.rate;
-  const int ldx = static_cast<int>(d.ldx);
-  const bool relu_in = d.relu_in != 0, relu_out = d.relu_out != 0;
-  constexpr int U = 2;
-  for (int cc = 0; cc < wc; cc += LW) {
-    const int cl = (t & (LW - 1)) + cc;
-    const bool act = cl < wc;
-    const int c = (c_lo + (act ? cl : 0)) * 4;
-    f32x4 w[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-      w[i] = *reinterpret_cast<const f32x4*>(d.w9c + static_cast<int64_t>(i) * (c4n * 4) + c);
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(d.bias + c);
-    for (int pp = t >> lw_log; pp < BM; pp += U * PPP) {
-      f32x4 v[U][9];
-      unsigned okm[U];
-      bool valid[U];
-      int mrow[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int pq = pp + u * PPP;
-        int m = m0 + pq;
-        valid[u] = act && pq < BM && m < M;
-        m = m < M ? m : M - 1;
-        mrow[u] = m;
-        const unsigned row = sp_div(static_cast<unsigned>(m), d.dw);
-        const int x = m - static_cast<int>(row) * Wi;
-        const int y = static_cast<int>(row - sp_div(row, d.dh) * Hi);
-        const float* px = d.X + static_cast<int64_t>(m) * d.ldx + c;
-        unsigned ok = 0;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int yi = y + (ky - 1) * r, xi = x + (kx - 1) * r;
-            const bool in = static_cast<unsigned>(yi) < static_cast<unsigned>(Hi) &&
-                            static_cast<unsigned>(xi) < static_cast<unsigned>(Wi);
-            ok |= in ? 1u << (ky * 3 + kx) : 0u;
-            const int off = in ? ((ky - 1) * Wi + (kx - 1)) * r * ldx : 0;
-            v[u][ky * 3 + kx] = *reinterpret_cast<const f32x4*>(px + off);
-          }
-        okm[u] = ok;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        f32x4 acc = bias;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          f32x4 x = v[u][i];
-          if (!((okm[u] >> i) & 1u)) x = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (relu_in) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = relu_1op_sp(x[e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = fmaf(x[e], w[i][e], acc[e]);
-        }
-        if (relu_out) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = relu_1op_sp(acc[e]);
-        }
-        if (valid[u]) st4_wt(d.T + static_cast<int64_t>(mrow[u]) * d.ldt + c, acc);
-      }
-    }
-  }
-}
-
 // CONV: implicit GEMM of a dense 3x3 conv with Cin % 16 == 0, as in
 // pointwise_gemm_dma_f32: K step kt is channel block kt % (Cin/16) of tap kt / (Cin/16),
 // the A rows are the input pixels (y*stride + dy*rate, x*stride + dx*rate), taps outside
 // the image come from a zero block (a per-lane source select).
-template <bool HAS_RES, bool SINGLE, bool TWO_ACC, int CB, bool CONV, bool DW = false>
-__global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedArgs ga_,
-                                                                       DwPhase dw_) {
+template <bool HAS_RES, bool SINGLE, bool TWO_ACC, int CB, bool CONV>
+__global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedArgs ga_) {
   constexpr int WN = 4 / CB;                 // waves along N (1 or 2); CB along M
   constexpr int SP_BM = 32 * CB;
   constexpr int SP_STAGE = sp_stage_bytes(CB);
@@ -228,7 +100,6 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   const int l31 = lane & 31, h = lane >> 5;
 
   (void)ga_;
-  (void)dw_;
   const GroupedArgs* __restrict__ gp =
       (const GroupedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   int bid;
@@ -254,7 +125,7 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   // flight on an XCD share 8 tiles' weights (K = 256: 1.5 MB, L2-resident) instead of
   // sweeping all of them (6 MB for the 4032-channel head) once per row tile.
   int tile_m, tile_n;
-  if (DW || tiles_n <= 8) {       // DW: the siblings of a row tile must be neighbours
+  if (tiles_n <= 8) {
     tile_n = bid % tiles_n;
     tile_m = bid / tiles_n;
   } else {
@@ -269,65 +140,6 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
   }
   const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
   const int nks = (K + SP_BK - 1) / SP_BK;
-  if constexpr (DW) {
-    // ---- producer phase: my channel slice of this row tile's depthwise output ----
-    const DwPhase* __restrict__ dp = reinterpret_cast<const DwPhase*>(
-        reinterpret_cast<const char*>(gp) + ((sizeof(GroupedArgs) + 7) & ~size_t(7)));
-    const DwPhase d = *dp;
-    const int c4n = K >> 2;
-#ifdef EPOS_SEPCONV_TRACE      // tools/sepconv_trace.py: 100 MHz stamps per workgroup
-    uint64_t* trc = reinterpret_cast<uint64_t*>(d.stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x);
-    if (t == 0) trc[0] = wall_clock64();
-#endif
-    dw_slice<SP_BM>(d, M, c4n, m0, tile_n, tiles_n, t);
-#ifdef EPOS_SEPCONV_TRACE
-    if (t == 0) trc[1] = wall_clock64();
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains
-    __syncthreads();
-#ifdef EPOS_SEPCONV_TRACE
-    if (t == 0) trc[2] = wall_clock64();
-#endif
-    int* flag = reinterpret_cast<int*>(smem);
-    gu32* cnt = (gu32*)(d.sync + 2 * tile_m);
-    if (t == 0) {
-      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint64_t t0 = wall_clock64();
-      int late = 0;
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-             static_cast<unsigned>(tiles_n)) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > d.timeout) { late = 1; break; }
-      }
-      *flag = late;
-#ifdef EPOS_SEPCONV_TRACE
-      trc[3] = wall_clock64();
-#endif
-    }
-    __syncthreads();
-    if (*flag) {          // uniform: siblings not in sight -- do their slices myself
-      for (int sl = 0; sl < tiles_n; ++sl)
-        if (sl != tile_n) dw_slice<SP_BM>(d, M, c4n, m0, sl, tiles_n, t);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (t == 0 && d.stats)
-        __hip_atomic_fetch_add((gu32*)d.stats, 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // ONE acquire for the workgroup
-      // departures: the last sibling re-arms the pair for the next launch of this layer
-      if (__hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-          static_cast<unsigned>(tiles_n - 1)) {
-        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#ifdef EPOS_SEPCONV_TRACE
-      trc[4] = wall_clock64();
-#endif
-    }
-    __syncthreads();
-  }
   const int cblocks = CONV ? gp->conv_cin[pi] / SP_BK : 1;   // channel blocks per tap
   const int crate = CONV ? gp->conv_rate[pi] : 1;
 
@@ -733,13 +545,6 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
       for (int r = 0; r < 16; ++r) acc[j][r] += acc2[j][r];
   }
 
-#ifdef EPOS_SEPCONV_TRACE
-  if constexpr (DW) {
-    const DwPhase* dq = reinterpret_cast<const DwPhase*>(
-        reinterpret_cast<const char*>(gp) + ((sizeof(GroupedArgs) + 7) & ~size_t(7)));
-    if (t == 0) (reinterpret_cast<uint64_t*>(dq->stats) + 8 + 8 * static_cast<uint64_t>(blockIdx.x))[5] = wall_clock64();
-  }
-#endif
   // ---- epilogue --------------------------------------------------------------
   if (vec_epilogue_ok(p, HAS_RES)) {
     __syncthreads();
@@ -776,21 +581,30 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
     }
 }
 
-template <bool HAS_RES, bool SINGLE, int CB, bool TWO_ACC, bool CONV = false,
-          bool DW = false>
-int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s,
-                    const DwPhase* dw = nullptr) {
-  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, TWO_ACC, CB, CONV, DW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              sp_lds_bytes(CB));
-    attr_set = true;
+template <bool HAS_RES, bool SINGLE, int CB, bool TWO_ACC, bool CONV = false>
+int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s) {
+  auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, TWO_ACC, CB, CONV>;
+  // more than 64 KB of dynamic LDS needs the attribute, once per device (per instantiation)
+  static std::mutex mu;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    set_error("pointwise_gemm_split_f32: no current device");
+    return EPOS_E_INVALID;
+  }
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!attr_set[dev]) {
+      const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   sp_lds_bytes(CB)),
+                               "hipFuncSetAttribute(pointwise_gemm_split_f32)");
+      if (rc) return rc;
+      attr_set[dev] = true;
+    }
   }
   // 80 / 64 KB per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), sp_lds_bytes(CB), s, g,
-                     dw ? *dw : DwPhase{});
+  hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), sp_lds_bytes(CB), s, g);
   return launch_status("pointwise_gemm_split_f32");
 }
 
@@ -882,62 +696,6 @@ int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s
   return big ? launch_split_rb<4>(args, count, s, conv_cin, conv_rate)
              : launch_split_rb<2>(args, count, s, conv_cin, conv_rate);
 }
-
-// Fused separable conv: depthwise producer phase + pointwise GEMM in one launch
-// (epos_separable_conv_f32). The caller has checked eligibility (sepconv_fusable).
-int launch_sepconv_split(const EposSepConvArgs* a, hipStream_t s) {
-  const EposPointwiseArgs& pw = a->pw;
-  const EposDepthwiseArgs& dwa = a->dw;
-  static const int forced = [] {
-    const char* e = getenv("EPOS_GEMM_SPLIT_ROWS");
-    return e ? atoi(e) : 0;
-  }();
-  const int64_t tiles128 = ceil_div(pw.M, 128) * ceil_div(pw.N, SP_BN);
-  const bool big = forced ? forced == 128 : tiles128 >= 200;
-  const int bm = big ? 128 : 64;
-  GroupedArgs g = {};
-  g.count = 1;
-  g.p[0] = pw;
-  g.tile_start[0] = 0;
-  g.tiles_n[0] = static_cast<int>(ceil_div(pw.N, SP_BN));
-  g.npad[0] = g.tiles_n[0] * SP_BN;
-  g.conv_rate[0] = 1;
-  const int total = static_cast<int>(ceil_div(pw.M, bm)) * g.tiles_n[0];
-  for (int i = 1; i <= MAX_GROUP; ++i) g.tile_start[i] = total;
-  auto sp = [](unsigned d) {
-    SpDiv f;
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    f.mul = static_cast<unsigned>(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.sh1 = l > 0 ? 1 : 0;
-    f.sh2 = l > 0 ? l - 1 : 0;
-    return f;
-  };
-  static const unsigned timeout = [] {      // EPOS_SEPCONV_TIMEOUT_US (default 200)
-    const char* e = getenv("EPOS_SEPCONV_TIMEOUT_US");
-    return static_cast<unsigned>((e ? atoi(e) : 200) * 100);
-  }();
-  DwPhase d = {};
-  d.X = dwa.X; d.ldx = dwa.ldx;
-  d.w9c = dwa.w9c; d.bias = dwa.bias;
-  d.T = dwa.Y; d.ldt = dwa.ldy;
-  d.sync = a->sync;
-  d.stats = a->stats;
-  d.Hi = dwa.Hi; d.Wi = dwa.Wi; d.rate = dwa.rate;
-  d.relu_in = dwa.relu_in; d.relu_out = dwa.relu_out;
-  d.timeout = timeout;
-  d.dw = sp(static_cast<unsigned>(dwa.Wi));
-  d.dh = sp(static_cast<unsigned>(dwa.Hi));
-  const bool res = pw.R != nullptr;
-  if (big) {
-    return res ? launch_split_tt<true, true, 4, true, false, true>(g, total, s, &d)
-               : launch_split_tt<false, true, 4, true, false, true>(g, total, s, &d);
-  }
-  return res ? launch_split_tt<true, true, 2, true, false, true>(g, total, s, &d)
-             : launch_split_tt<false, true, 2, true, false, true>(g, total, s, &d);
-}
-
-int64_t sepconv_sync_words(int M) { return 2 * ceil_div(M, 64); }
 
 }  // namespace epos
 

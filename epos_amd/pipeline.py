@@ -38,14 +38,8 @@ class EposPipeline(object):
                corr_min_frag_rel_conf=0.5, max_slots=None, capacity=1 << 20,
                max_instances=4, model_options=None, device='cuda:0',
                use_graph=True, instance=0, sparse_heads=False,
-               fitting_method='progressive_x', on_excess='raise', cu_partition=None):
-    """cu_partition: None, or (j, n): this pipeline's stream runs on partition j of n equal
-    partitions of the chip's compute units (eight / sixteen / ... CUs of EVERY XCD:
-    epos_stream_create_cu_mask, include/epos_hip.h) -- pipelines of images in flight then
-    share the chip in space instead of in time: one pipeline's memory-bound launches
-    (depthwise, resize, softmax, correspondences) run beside the other partitions' GEMMs
-    instead of taking their workgroup slots.
-    on_excess: what launch() does with a frame that asks for more instances of an object
+               fitting_method='progressive_x', on_excess='raise'):
+    """on_excess: what launch() does with a frame that asks for more instances of an object
     than `max_instances` (localization): 'raise' (default: EposError BEFORE anything of that
     batch is enqueued -- batches already in flight on other pipelines are unaffected and can
     still be collected) or 'clamp' (fit `max_instances` of them and warn once)."""
@@ -138,35 +132,10 @@ class EposPipeline(object):
     self.num_models = mv(self.res_dev, self._res_layout, 'num_models')
     self.corr.totals = mv(self.res_dev, self._res_layout, 'totals').view(S, 2)
     self.corr.overflow = mv(self.res_dev, self._res_layout, 'overflow')
-    self.cu_partition = cu_partition
-    self._raw_stream = None
-    if cu_partition is None:
-      self.stream = torch.cuda.Stream(self.dev)
-    else:
-      self.stream = self._masked_stream(*cu_partition)
+    self.stream = torch.cuda.Stream(self.dev)
     self._done = torch.cuda.Event()
     self._pending = None
     self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-
-  N_CUS = 256      # MI355X: 8 XCDs x 32 CUs; mask bit i = CU i // 8 of XCD i % 8
-
-  def _masked_stream(self, j, n):
-    if not (isinstance(n, int) and n >= 1 and self.N_CUS % (8 * n) == 0 and 0 <= j < n):
-      raise ValueError('cu_partition=(j, n): n must divide %d CUs per XCD, 0 <= j < n' % (self.N_CUS // 8))
-    per = self.N_CUS // n
-    words = (ctypes.c_uint32 * (self.N_CUS // 32))()
-    for i in range(j * per, (j + 1) * per):
-      words[i >> 5] |= 1 << (i & 31)
-    raw = ctypes.c_void_p()
-    with torch.cuda.device(self.dev):
-      _lib.check(self.lib.epos_stream_create_cu_mask(words, len(words), ctypes.byref(raw)),
-                 'epos_stream_create_cu_mask')
-    self._raw_stream = raw
-    return torch.cuda.ExternalStream(raw.value, device=self.dev)
-
-  # The masked stream lives as long as the process: the plan's captured graphs and torch's
-  # stream wrappers refer to it, and destroying it under them at interpreter exit crashed
-  # (a pipeline is a long-lived object; a service that rebuilds pipelines reuses partitions).
 
   _DT = {'f8': (torch.float64, 8), 'i8': (torch.int64, 8), 'i4': (torch.int32, 4)}
 
@@ -244,13 +213,7 @@ class EposPipeline(object):
     if self.fitting_method == 'opencv_ransac':
       max_k = 1                       # "can estimate pose of only one object instance"
     cur = torch.cuda.current_stream(self.dev)
-    # inputs produced on the caller's stream. A CU-masked stream is a BLOCKING stream
-    # (hipExtStreamCreateWithCUMask takes no flags): it already waits for everything issued
-    # to the legacy default stream before it, and an event RECORDED on the default stream
-    # would in turn wait for all blocking streams -- the partitions would run one after
-    # the other (measured: 111 instead of 423 images/s) -- so no event in that case.
-    if not (self.cu_partition is not None and cur == torch.cuda.default_stream(self.dev)):
-      self.stream.wait_stream(cur)
+    self.stream.wait_stream(cur)            # inputs produced on the caller's stream
     with torch.cuda.stream(self.stream):
       if timing:
         self._ev[0].record()

@@ -34,18 +34,10 @@ extern "C" {
 #define EPOS_E_INTERNAL (-4)  /* a device-side consistency check failed (see epos_last_error) */
 #define EPOS_E_HIP_BASE (-1000)
 
-#define EPOS_ABI_VERSION 6   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32; 4: epos_solve_pnp_ransac; 5: fp16-pair GEMM (Wh, a_amax, c_amax, epos_pack_pointwise_weights_h2, epos_absmax_f32); 6: epos_separable_conv_f32 with fp16-pair intermediates on the fp16-pair kernel, epos_separable_conv_fused_state */
+#define EPOS_ABI_VERSION 7   /* 2: EposPointwiseArgs.Ws, EposConv3x3Args.Ws, split weight packing; 3: epos_separable_conv_f32; 4: epos_solve_pnp_ransac; 5: fp16-pair GEMM (Wh, a_amax, c_amax, epos_pack_pointwise_weights_h2, epos_absmax_f32); 6: epos_separable_conv_f32 with fp16-pair intermediates on the fp16-pair kernel, epos_separable_conv_fused_state ; 7 (round 5, the diet): the measured-slower opt-ins left the library -- EposSepConvArgs lost sync / stats and epos_separable_conv_f32 issues the two launches, EposPointwiseArgs.softmax64 is reserved, removed: epos_separable_conv_sync_words, epos_separable_conv_fused_state, epos_set_h2_latency_tile_limit, epos_pointwise_workspace_bytes, epos_pointwise_conv_grouped_ws_f32, epos_pointwise_conv_grouped_sk_f32 */
 
 int epos_abi_version(void);
 const char* epos_last_error(void);
-/* A HIP stream whose kernels run on a subset of the compute units (round 5: one partition of
- * the chip per pipeline of images in flight). mask = `words` x 32 bits; on gfx950 bit i is CU
- * number i / 8 of XCD i % 8, so `bits [64 p, 64 p + 64)` = eight CUs of every XCD. Workgroups
- * are still dealt round robin over all eight XCDs, so every XCD must keep at least one CU
- * (EPOS_E_INVALID otherwise: an XCD without a bit would run unmasked). hipGraph launches
- * into the stream honour the mask. *stream is a hipStream_t; release with epos_stream_destroy. */
-int epos_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
-int epos_stream_destroy(void* stream);
 /* Number of visible HIP devices (>= 0) or a negative error. */
 int epos_device_count(void);
 /* Measurement aid (bench.py): a one-wave kernel on `stream` that spins for
@@ -170,12 +162,8 @@ typedef struct EposPointwiseArgs {
                        * are not re-read soon (the 413 MB of dense heads would otherwise sweep
                        * the 256 MB Infinity Cache clean of the other images' working sets);
                        * fp16-pair kernel's float4 epilogue only, ignored elsewhere */
-  int32_t softmax64;  /* != 0: softmax over every aligned group of 64 output channels
-                       * (model.py:678: the fragment confidences of one object) before the
-                       * store. Needs N % 64 == 0, ldc == N (dense rows), no residual, no
-                       * ReLU. On the fp16-pair kernel it is part of the epilogue (the same
-                       * arithmetic as epos_softmax_groups_f32 with G = 64: identical bits);
-                       * on the other kernels the library runs that kernel on C afterwards */
+  int32_t reserved0;  /* 0 (ABI 6 carried a fused fragment softmax here; measured slower than
+                       * its own launch, removed in ABI 7: profiles/r04/ab_head_softmax.txt) */
 } EposPointwiseArgs;
 int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
 
@@ -186,20 +174,10 @@ int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
 int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args, int count,
                                     void* stream);
 
-/* Persistent stream-K form of the grouped GEMM (experimental in round 1, opt-in):
- * a fixed grid of two workgroups per CU, the (tile, K-tile) units of the group cut
- * into equal contiguous ranges, tiles split between workgroups combined through
- * partial-sum slabs in a deterministic order. `workspace` [device]:
- * epos_pointwise_workspace_bytes() bytes, zero-initialised once by the caller;
- * launches sharing a workspace must be ordered on one stream.
- * epos_pointwise_conv_grouped_ws_f32 is what the network plan calls: it uses the
- * stream-K kernel only when EPOS_GEMM_SK=1 is set and the data-parallel kernels
- * otherwise (see DESIGN.md for the measurements behind that default). */
-int64_t epos_pointwise_workspace_bytes(void);
-int epos_pointwise_conv_grouped_sk_f32(const EposPointwiseArgs* args, int count,
-                                       void* workspace, void* stream);
-int epos_pointwise_conv_grouped_ws_f32(const EposPointwiseArgs* args, int count,
-                                       void* workspace, void* stream);
+/* (ABI <= 6 also had a persistent stream-K form of the grouped GEMM on the fp32-MFMA ring,
+ * epos_pointwise_conv_grouped_sk_f32 / _ws_f32 + a workspace: correct, tested, and slower
+ * than the data-parallel kernels end to end (177 vs 213 images/s in round 1); removed in
+ * ABI 7 -- DESIGN.md "Stream-K", history up to commit 1b05025.) */
 
 /* Dense 3x3 conv + folded BatchNorm (+ ReLU) as an IMPLICIT GEMM: the im2col matrix
  * only exists as LDS tiles filled by LDS-DMA from the shifted input pixels. Semantics =
@@ -256,62 +234,27 @@ typedef struct EposDepthwiseArgs {
 } EposDepthwiseArgs;
 int epos_depthwise3x3_f32(const EposDepthwiseArgs* args, void* stream);
 
-/* Separable conv in ONE launch: depthwise 3x3 (+BN, ReLU before/after) followed by
- * the pointwise 1x1 (+BN, +residual, +ReLU) -- slim.separable_conv2d as
- * net_xception.py:96-194 (separable_conv2d_same, stride 1) and model.py:58-97
- * (split_separable_conv2d) build it. Result and intermediate are bit-identical to
- * epos_depthwise3x3_f32(&dw) followed by epos_pointwise_conv_f32(&pw): the depthwise
- * runs as a producer phase of the GEMM's own workgroups (the workgroups that share a
- * row tile each compute a channel slice of it and hand it over through `sync`), so it
- * needs no launch and no workgroup slots of its own.
- * Requirements: dw.stride == 1 (Ho == Hi, Wo == Wi); pw.A == dw.Y, pw.lda == dw.ldy,
- * pw.K == dw.C, pw.M == dw.B * dw.Ho * dw.Wo, pw.sub == 1, pw.relu_in == 0, pw.Ws given
- * (split-packed weights). When a requirement of the fused kernel is not met (or
- * EPOS_SEPCONV_FUSED=0) the two launches are issued instead.
- * dw.Y [device] keeps the depthwise output (the GEMM reads it; callers may too).
- * sync [device]: epos_separable_conv_sync_words(pw.M) uint32 words, zero-initialised
- * ONCE by the caller, private to this layer and stream (the kernel re-arms them);
- * stats [device, optional]: one uint32 counting workgroups that stopped waiting for
- * their siblings and computed the siblings' slices themselves (diagnostics). */
-/* Round 4: with fp16-pair intermediates (dw.y_h2 != 0 and pw.a_presplit != 0, pw.Wh and
- * pw.a_amax given, dw.x_amax / x_amax2 / gain / bias0 equal to pw.a_amax / a_amax2 / a_gain /
- * a_bias, dw.rate <= 4) the fused launch runs on the fp16-pair kernel: the producer phase
- * stages its input through LDS by LDS-DMA and writes fp16 pairs, the K loop carries no
- * operand split. dw.Y then holds the fp16 pairs (the y_h2 format). Bit-identical to
- * epos_depthwise3x3_f32 (y_h2) + epos_pointwise_conv_f32 (a_presplit). Its hand-off between
- * the workgroups of a row tile goes through ONE XCD's L2 and relies on workgroups with equal
- * block index modulo 8 sharing an XCD; epos_separable_conv_fused_state() reports whether
- * that was verified on the current device (1), refuted (0) or not probed yet because the
- * first call came during a stream capture (-1) -- unless it is 1 the two launches are
- * issued instead. */
-int epos_separable_conv_fused_state(void* stream);
+/* Separable conv as ONE call: depthwise 3x3 (+BN, ReLU before/after) followed by the
+ * pointwise 1x1 (+BN, +residual, +ReLU) -- slim.separable_conv2d as net_xception.py:96-194
+ * (separable_conv2d_same, stride 1) and model.py:58-97 (split_separable_conv2d) build it.
+ * Requirements: pw.A == dw.Y, pw.lda == dw.ldy, pw.K == dw.C, pw.M == dw.B * dw.Ho * dw.Wo.
+ * dw.Y [device] keeps the depthwise output (fp32, or fp16 pairs with dw.y_h2 +
+ * pw.a_presplit). Since ABI 7 this is exactly epos_depthwise3x3_f32(&dw) followed by
+ * epos_pointwise_conv_f32(&pw) on the stream: the single-launch forms of rounds 2 and 4
+ * (depthwise as a producer phase of the GEMM's workgroups, on the bf16 x 6 and on the
+ * fp16-pair kernel; both bit-identical to the two launches) measured slower on every
+ * configuration (C2 351 vs 420, C3 359 vs 425 images/s; profiles/r02, r04, r05) and left the
+ * product library in round 5 -- DESIGN.md (e), git history up to commit 1b05025. */
 /* The fp16-pair GEMM takes 128 x 64 instead of 128 x 128 output tiles for a launch with at
  * most `max_tiles` 128 x 128 tiles (default 100; environment EPOS_H2_BN64_MAX_TILES; 0 =
  * never): launches that would leave most CUs idle (ASPP 1x1 of one image: 76 tiles) get
  * twice the workgroups. Results do not depend on the tile. Returns the previous limit.
  * Process-wide; meant for tuning and for the tests that run both tiles. */
 int epos_set_h2_narrow_tile_limit(int max_tiles);
-/* Latency mode of the fp16-pair GEMM: a launch with at most `max_tiles` 128 x 128 tiles
- * (and more than the narrow-tile limit) computes each tile with EIGHT waves (4 row groups x
- * 2 column halves, 512 threads, one workgroup per CU) instead of four: two waves on every
- * SIMD from a launch that cannot give a CU a second workgroup. For callers that run ONE
- * launch at a time (a single image, pipeline depth 1); with several launches in flight two
- * four-wave workgroups per CU overlap better. Default 0 = never (environment
- * EPOS_H2_LATENCY_MAX_TILES). Same bits. Returns the previous limit. Process-wide. */
-int epos_set_h2_latency_tile_limit(int max_tiles);
-/* Tall tile of the fp16-pair GEMM (round 5): a launch with at least `min_tiles` 128 x 128
- * tiles computes 256 x 128 tiles with eight waves (8 x 1: each wave is exactly the wave of
- * the 128 x 128 tile; the W stage is shared by eight waves instead of four, so a quarter
- * less data moves L2 -> LDS per MFMA; one workgroup per CU). 0 = never (environment
- * EPOS_H2_TALL_MIN_TILES). Same bits. Returns the previous limit. Process-wide. */
-int epos_set_h2_tall_tile_min(int min_tiles);
 typedef struct EposSepConvArgs {
   EposDepthwiseArgs dw;
   EposPointwiseArgs pw;
-  uint32_t* sync;
-  uint32_t* stats;
 } EposSepConvArgs;
-int64_t epos_separable_conv_sync_words(int32_t M);
 int epos_separable_conv_f32(const EposSepConvArgs* args, void* stream);
 
 /* im2col for a dense 3x3 conv (slim resnet_utils.conv2d_same,

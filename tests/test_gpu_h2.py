@@ -20,20 +20,14 @@ def lib():
   return _lib.load()
 
 
-@pytest.fixture(autouse=True, params=['tile128', 'tile64', 'waves8', 'tall256'])
+@pytest.fixture(autouse=True, params=['tile128', 'tile64'])
 def tile(request, lib):
-  """Every test of this module runs with the launch shapes of the fp16-pair kernel:
-  128 x 128 tiles on the five-stage ring only (all limits 0), 128 x 64 tiles wherever the
-  kernel offers them, the eight-wave form wherever it is offered, and the 256 x 128 tile
-  (round 5) wherever it is offered (epos_set_h2_narrow_tile_limit /
-  epos_set_h2_latency_tile_limit / epos_set_h2_tall_tile_min, include/epos_hip.h)."""
-  prev = (lib.epos_set_h2_narrow_tile_limit((1 << 30) if request.param == 'tile64' else 0),
-          lib.epos_set_h2_latency_tile_limit((1 << 30) if request.param == 'waves8' else 0),
-          lib.epos_set_h2_tall_tile_min(1 if request.param == 'tall256' else 0))
+  """Every test of this module runs with both launch shapes of the fp16-pair kernel: 128 x 128
+  tiles only (limit 0) and 128 x 64 tiles wherever the kernel offers them
+  (epos_set_h2_narrow_tile_limit, include/epos_hip.h)."""
+  prev = lib.epos_set_h2_narrow_tile_limit((1 << 30) if request.param == 'tile64' else 0)
   yield request.param
-  lib.epos_set_h2_narrow_tile_limit(prev[0])
-  lib.epos_set_h2_latency_tile_limit(prev[1])
-  lib.epos_set_h2_tall_tile_min(prev[2])
+  lib.epos_set_h2_narrow_tile_limit(prev)
 
 
 def _p(t, off=0):
@@ -229,9 +223,9 @@ def test_absmax_kernel(lib):
                                             (1200, 1024, 1536, 0, 1), (333, 40, 24, 0, 0),
                                             (19200, 256, 48, 0, 1), (130, 92, 200, 1, 0)])
 def test_h2_bits_do_not_depend_on_the_tile(lib, m, k, n, res, relu):
-  """128 x 64 tiles, 128 x 128 tiles and the eight-wave form (round 4) accumulate an element's
-  K sum in the same order: equal bits, equal published absmax -- with and without residual, ragged M / N / K, the
-  first and the second half of a packed 128-column weight image."""
+  """128 x 64 and 128 x 128 tiles accumulate an element's K sum in the same order: equal bits,
+  equal published absmax -- with and without residual, ragged M / N / K, the first and the
+  second half of a packed 128-column weight image."""
   from epos_amd import _lib
   rng = np.random.RandomState(m + k + n)
   a = rng.standard_normal((m, k)).astype(np.float32)
@@ -239,22 +233,17 @@ def test_h2_bits_do_not_depend_on_the_tile(lib, m, k, n, res, relu):
   bias = rng.standard_normal(n).astype(np.float32)
   r = rng.standard_normal((m, n)).astype(np.float32) if res else None
   outs = []
-  prev = (lib.epos_set_h2_narrow_tile_limit(0), lib.epos_set_h2_latency_tile_limit(0),
-          lib.epos_set_h2_tall_tile_min(0))
+  prev = lib.epos_set_h2_narrow_tile_limit(0)
   try:
-    for limit, deep, tall in ((0, 0, 0), (1 << 30, 0, 0), (0, 1 << 30, 0), (0, 0, 1)):
+    for limit in (0, 1 << 30):
       lib.epos_set_h2_narrow_tile_limit(limit)
-      lib.epos_set_h2_latency_tile_limit(deep)
-      lib.epos_set_h2_tall_tile_min(tall)
       slot_a, slot_c = _slot(), _slot()
       A = torch.from_numpy(a).cuda()
       _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot_a), None))
       c = _gemm(lib, a, w, 'h2', bias=bias, res=r, relu=relu, a_amax=slot_a, c_amax=slot_c)
       outs.append((c, _slot_value(slot_c)))
   finally:
-    lib.epos_set_h2_narrow_tile_limit(prev[0])
-    lib.epos_set_h2_latency_tile_limit(prev[1])
-    lib.epos_set_h2_tall_tile_min(prev[2])
+    lib.epos_set_h2_narrow_tile_limit(prev)
   for o in outs[1:]:
     assert np.array_equal(outs[0][0].view(np.uint32), o[0].view(np.uint32))
     assert o[1] == outs[0][1]
@@ -513,7 +502,7 @@ def test_presplit_needs_the_fp16_pair_kernel(lib):
 # ------------------------------- fused separable conv on the fp16-pair kernel (round 4) ---
 def _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res, seed=0):
   """A separable conv with fp16-pair intermediates: (dw args, pw args, SepConvArgs) for given
-  intermediate / output / sync buffers; the depthwise input's absmax slot is measured."""
+  intermediate / output buffers; the depthwise input's absmax slot is measured."""
   from epos_amd import _lib
   rng = np.random.RandomState(seed + h * 7 + cin)
   x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
@@ -534,7 +523,7 @@ def _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res, s
   gain = float(np.abs(w9c.astype(np.float64)).sum(0).max())
   bias0 = float(np.abs(dbias).max())
 
-  def make(T, C, sync, stats=None):
+  def make(T, C):
     dw = _lib.DepthwiseArgs(X=_p(t['X']), ldx=cin, w9c=_p(t['w9c']), bias=_p(t['dbias']),
                             Y=_p(T), ldy=cin, B=b, Hi=h, Wi=w, Ho=h, Wo=w, C=cin,
                             stride=1, rate=rate, relu_in=relu_in, relu_out=relu_out,
@@ -543,50 +532,37 @@ def _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res, s
                             R=_p(t['R']) if res else None, ldr=cout, C=_p(C), ldc=cout,
                             M=m, N=cout, K=cin, relu=1, relu_in=0, sub=1, Wh=_p(t['Wh']),
                             a_amax=_p(t['xs']), a_gain=gain, a_bias=bias0, a_presplit=1)
-    return dw, pw, _lib.SepConvArgs(dw=dw, pw=pw, sync=_p(sync) if sync is not None else None,
-                                    stats=_p(stats) if stats is not None else None)
+    return dw, pw, _lib.SepConvArgs(dw=dw, pw=pw)
   return t, m, make
 
 
 @pytest.mark.parametrize('b,h,w,cin,cout,rate', [
-    (1, 60, 80, 728, 728, 2),       # middle flow: 6 siblings, ragged slices (30 / 31 groups)
-    (1, 60, 80, 1024, 1536, 4),     # exit flow: 12 column tiles, rate 4 = the staging pad
-    (1, 30, 40, 304, 256, 1),       # decoder shape: slices of 38 groups = two super-blocks
-    (2, 13, 17, 64, 128, 1),        # one column tile, tiles straddle the two images
-    (1, 9, 11, 36, 200, 3),         # rate > a third of the image: every tap class at the border
-    (1, 120, 160, 256, 256, 1),     # 19200 rows
-    (1, 8, 8, 8, 384, 2)])          # fewer channel groups than column tiles: empty slices
+    (1, 60, 80, 728, 728, 2),       # middle flow
+    (2, 13, 17, 64, 128, 1),        # tiles straddle the two images
+    (1, 9, 11, 36, 200, 3)])        # rate > a third of the image: every tap class at the border
 @pytest.mark.parametrize('relu_in,relu_out,res', [(0, 1, 0), (1, 0, 1)])
-def test_fused_separable_conv_h2_equals_two_launches(lib, b, h, w, cin, cout, rate, relu_in,
-                                                     relu_out, res):
-  """epos_separable_conv_f32 with fp16-pair intermediates (dw.y_h2 + pw.a_presplit: the
-  LDS-staged depthwise producer phase inside pointwise_gemm_h2_f32) against
-  epos_depthwise3x3_f32 (y_h2) + epos_pointwise_conv_f32 (a_presplit): intermediate (the
-  fp16 pairs) and output bit for bit, over repeated launches (the counters re-arm)."""
+def test_separable_conv_one_call_form(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res):
+  """epos_separable_conv_f32 (slim.separable_conv2d as one C-ABI call, fp16-pair intermediate)
+  = epos_depthwise3x3_f32 (y_h2) + epos_pointwise_conv_f32 (a_presplit): intermediate and
+  output bit for bit, and the intermediate against an fp64 depthwise conv. (Rounds 2 and 4
+  ran it as ONE launch -- bit-identical, slower; since ABI 7 it issues the two launches.)"""
   from epos_amd import _lib
-  # the fused kernel really runs here (otherwise the entry point issues the two launches and
-  # this test would compare them with themselves): the XCD mapping its hand-off relies on
-  # has been verified on this device
-  assert lib.epos_separable_conv_fused_state(None) == 1
   t, m, make = _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res)
   assert t['Wh'] is not None
   T0 = torch.full((m, cin), 3.0, device='cuda'); C0 = torch.zeros(m, cout, device='cuda')
-  dw, pw, _ = make(T0, C0, None)
+  dw, pw, _ = make(T0, C0)
   _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))
   _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))
   torch.cuda.synchronize()
-  sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32,
-                     device='cuda')
-  stats = torch.zeros(2, dtype=torch.int32, device='cuda')
-  T1 = torch.empty(m, cin, device='cuda'); C1 = torch.empty(m, cout, device='cuda')
-  _, _, sa = make(T1, C1, sync, stats)
-  for it in range(4):
-    T1.fill_(float(it)); C1.fill_(-1.0)       # stale lines from the previous round
-    _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sa), None))
-    torch.cuda.synchronize()
-    assert torch.equal(T1.view(torch.int32), T0.view(torch.int32)), 'intermediate, launch %d' % it
-    assert torch.equal(C1, C0), 'output, launch %d' % it
-    assert int(sync.abs().sum()) == 0         # re-armed
+  T1 = torch.full((m, cin), 7.0, device='cuda'); C1 = torch.full((m, cout), -1.0, device='cuda')
+  _, _, sa = make(T1, C1)
+  _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sa), None))
+  torch.cuda.synchronize()
+  assert torch.equal(T1.view(torch.int32), T0.view(torch.int32))
+  assert torch.equal(C1, C0)
+  bad = _lib.SepConvArgs(dw=dw, pw=pw)
+  bad.pw.a_presplit = 0                  # the two halves must describe the same intermediate
+  assert lib.epos_separable_conv_f32(ctypes.byref(bad), None) != 0
   # the reference itself against fp64 (so that "equal" means "right")
   x = torch.from_numpy(t['x']).double().permute(0, 3, 1, 2)
   if relu_in:
@@ -605,123 +581,7 @@ def test_fused_separable_conv_h2_equals_two_launches(lib, b, h, w, cin, cout, ra
   np.testing.assert_allclose(dec, y, rtol=1e-5, atol=1e-5 * bound)
 
 
-def test_fused_separable_conv_h2_concurrent_streams_and_timeout(lib):
-  """Four fused layers in flight on four streams with other kernels competing for the
-  workgroup slots, many rounds, every word checked; then a zero time-out in a fresh process:
-  every workgroup gives up waiting at once and computes its siblings' slices itself --
-  same bits (the progress guarantee of the hand-off)."""
-  import os
-  import subprocess
-  import sys
-  from epos_amd import _lib
-  b, h, w, cin, cout, rate = 1, 60, 80, 728, 728, 2
-  t, m, make = _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, 1, 0, 1, seed=5)
-  T0 = torch.empty(m, cin, device='cuda'); C0 = torch.empty(m, cout, device='cuda')
-  dw, pw, _ = make(T0, C0, None)
-  _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))
-  torch.cuda.synchronize()
-  streams = [torch.cuda.Stream() for _ in range(4)]
-  bufs = []
-  for s in streams:
-    sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32,
-                       device='cuda')
-    T = torch.zeros(m, cin, device='cuda'); C = torch.zeros(m, cout, device='cuda')
-    bufs.append((T, C, sync, make(T, C, sync)[2]))
-  noise = torch.randn(1 << 22, device='cuda')
-  for rnd in range(25):
-    for i, s in enumerate(streams):
-      T, C, sync, sa = bufs[i]
-      with torch.cuda.stream(s):
-        if (rnd + i) % 3 == 0:
-          noise.mul_(1.0001)                      # uneven load between the launches
-        T.fill_(float(rnd)); C.fill_(-2.0)
-        _lib.check(lib.epos_separable_conv_f32(
-            ctypes.byref(sa), ctypes.c_void_p(s.cuda_stream)))
-    torch.cuda.synchronize()
-    for T, C, sync, _ in bufs:
-      assert torch.equal(T.view(torch.int32), T0.view(torch.int32)) and torch.equal(C, C0), \
-          'round %d' % rnd
-      assert int(sync.abs().sum()) == 0
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  script = (
-      "import sys, ctypes, numpy as np, torch\n"
-      "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-      "from epos_amd import _lib\n"
-      "import test_gpu_h2 as th\n"
-      "lib = _lib.load()\n"
-      "t, m, make = th._sepconv_h2_problem(lib, 1, 60, 80, 728, 728, 2, 1, 0, 1, seed=5)\n"
-      "T0 = torch.empty(m, 728, device='cuda'); C0 = torch.empty(m, 728, device='cuda')\n"
-      "dw, pw, _ = make(T0, C0, None)\n"
-      "_lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))\n"
-      "_lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))\n"
-      "sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32, device='cuda')\n"
-      "stats = torch.zeros(2, dtype=torch.int32, device='cuda')\n"
-      "T = torch.zeros(m, 728, device='cuda'); C = torch.zeros(m, 728, device='cuda')\n"
-      "sa = make(T, C, sync, stats)[2]\n"
-      "for it in range(3):\n"
-      "  _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sa), None)); torch.cuda.synchronize()\n"
-      "  assert torch.equal(T.view(torch.int32), T0.view(torch.int32)) and torch.equal(C, C0), it\n"
-      "  assert int(sync.abs().sum()) == 0\n"
-      "print('TIMEOUTS', int(stats[0]))\n" % (root, os.path.join(root, 'tests')))
-  r = subprocess.run([sys.executable, '-c', script],
-                     env=dict(os.environ, EPOS_SEPCONV_TIMEOUT_US='0'),
-                     capture_output=True, text=True, timeout=600)
-  assert r.returncode == 0, r.stdout + r.stderr
-  assert int(r.stdout.split('TIMEOUTS')[1]) > 0, r.stdout     # the path was taken
-
-
 # ------------------------------------------ softmax over 64-groups in the epilogue (round 4) ---
-@pytest.mark.parametrize('m,k,n_conf', [(4800, 256, 1344), (300, 64, 64), (19200, 256, 192)])
-def test_softmax64_in_the_epilogue_equals_the_stand_alone_kernel(lib, m, k, n_conf):
-  """EposPointwiseArgs.softmax64: the fragment-confidence head's softmax (model.py:678) as part
-  of the fp16-pair GEMM's epilogue, in a grouped launch with two other heads as in the plan,
-  against the same launch without it followed by epos_softmax_groups_f32 -- bit for bit (one
-  definition of the 16-lane softmax); the other problems of the group are untouched; a call
-  without fp16-pair weights takes the library's fall-back (GEMM, then the stand-alone kernel)
-  and equals ITS two-step form bit for bit; rows sum to one."""
-  from epos_amd import _lib
-  rng = np.random.RandomState(m + n_conf)
-  a = np.maximum(rng.standard_normal((m, k)), 0).astype(np.float32)
-  A = torch.from_numpy(a).cuda()
-  slot = _slot()
-  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
-  ns = [22, n_conf, 3 * n_conf]
-  ws = [(rng.standard_normal((k, n)) * (2.0 / np.sqrt(k))).astype(np.float32) for n in ns]
-  bs = [torch.from_numpy(np.pad(rng.standard_normal(n).astype(np.float32),
-                                (0, (-n) % 128))).cuda() for n in ns]
-  Wp = [_pack(lib, w) for w in ws]
-  Wh = [_pack(lib, w, 'h2') for w in ws]
-
-  def run(use_h2, fused):
-    Cs = [torch.zeros(m, n, device='cuda') for n in ns]
-    args = [_lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp[i]), bias=_p(bs[i]), R=None, ldr=0,
-                               C=_p(Cs[i]), ldc=ns[i], M=m, N=ns[i], K=k, relu=0, relu_in=0,
-                               sub=1, Wh=_p(Wh[i]) if use_h2 else None,
-                               a_amax=_p(slot) if use_h2 else None,
-                               softmax64=int(fused and i == 1)) for i in range(3)]
-    arr = (_lib.PointwiseArgs * 3)(*args)
-    _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
-    if not fused:
-      _lib.check(lib.epos_softmax_groups_f32(_p(Cs[1]), m * (n_conf // 64), 64, None))
-    torch.cuda.synchronize()
-    return Cs
-  for use_h2 in (True, False):
-    two, one = run(use_h2, False), run(use_h2, True)
-    for i in range(3):
-      assert torch.equal(two[i], one[i]), (use_h2, i)
-    p = one[1].cpu().numpy().reshape(m, n_conf // 64, 64).astype(np.float64)
-    assert np.abs(p.sum(-1) - 1.0).max() < 1e-5 and p.min() >= 0.0
-
-
-def test_softmax64_rejects_what_it_cannot_do(lib):
-  from epos_amd import _lib
-  A = torch.zeros(64, 32, device='cuda'); C = torch.zeros(64, 96, device='cuda')
-  Wp = _pack(lib, np.zeros((32, 96), np.float32))
-  a = _lib.PointwiseArgs(A=_p(A), lda=32, Wp=_p(Wp), bias=None, R=None, ldr=0, C=_p(C), ldc=96,
-                         M=64, N=96, K=32, relu=0, relu_in=0, sub=1, softmax64=1)
-  with pytest.raises(_lib.EposError):          # 96 is not a multiple of 64
-    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
 
 
 @pytest.mark.parametrize('b,hw,k,n,relu', [(1, 4800, 1536, 2048, 1), (2, 96, 64, 260, 0),

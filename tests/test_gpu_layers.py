@@ -453,46 +453,6 @@ def test_softmax_and_argmax(lib, g):
   assert lab[5].item() == 0
 
 
-@pytest.mark.parametrize('m,k,n,res', [(4800, 728, 728, 1), (4800, 2048, 256, 0),
-                                       (19200, 256, 1344, 0), (700, 736, 300, 0),
-                                       (5000, 64, 128, 0), (64, 4096, 128, 1),
-                                       (3000, 40, 136, 1), (9000, 100, 260, 0)])
-def test_stream_k_gemm_matches_reference(lib, m, k, n, res, monkeypatch):
-  """Persistent stream-K kernel (opt-in in round 1) through its explicit entry
-  point: shapes with many / few units per worker, more workers than units, split
-  tiles with residual + ReLU; repeated launches reuse the self-resetting flags and
-  must be bit-identical (deterministic combine order)."""
-  from epos_amd import _lib
-  rng = np.random.RandomState(m + n)
-  a = rng.standard_normal((m, k)).astype(np.float32)
-  w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
-  bias = rng.standard_normal(n).astype(np.float32)
-  r = rng.standard_normal((m, n)).astype(np.float32)
-  npad = (n + 127) // 128 * 128
-  bpad = np.zeros(npad, np.float32); bpad[:n] = bias
-  A, Wp, Bd, R = (torch.from_numpy(a).cuda(), _pack(lib, w),
-                  torch.from_numpy(bpad).cuda(), torch.from_numpy(r).cuda())
-  ws = torch.zeros(int(lib.epos_pointwise_workspace_bytes()), dtype=torch.uint8,
-                   device='cuda')
-  ref = a.astype(np.float64) @ w.astype(np.float64) + bias
-  if res:
-    ref = np.maximum(ref + r, 0)
-  outs = []
-  for it in range(3):
-    C = torch.full((m, n), -7.0, device='cuda')
-    args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=_p(Bd),
-                              R=_p(R) if res else None, ldr=n, C=_p(C), ldc=n, M=m,
-                              N=n, K=k, relu=res, relu_in=0, sub=1)
-    _lib.check(lib.epos_pointwise_conv_grouped_sk_f32(ctypes.byref(args), 1, _p(ws),
-                                                      None))
-    torch.cuda.synchronize()
-    outs.append(C.cpu().numpy())
-    np.testing.assert_allclose(outs[-1], ref, rtol=1e-4, atol=1e-4)
-  assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
-  flags = ws.cpu().numpy()[-4096:].view(np.int32)
-  assert not flags.any()              # flags self-reset, no error word
-
-
 def test_clock_probe_reports_a_plausible_core_clock(lib):
   """epos_clock_probe: shader cycles per 100 MHz tick while a wave spins for 200 us."""
   from epos_amd import _lib
@@ -546,142 +506,6 @@ print('ok')
 
 
 # ------------------------------------------------------- fused separable conv ---
-def _sepconv_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res, seed=0):
-  from epos_amd import _lib
-  rng = np.random.RandomState(seed + h * 7 + cin)
-  x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
-  w9c = (rng.standard_normal((9, cin)) / 3).astype(np.float32)
-  dbias = rng.standard_normal(cin).astype(np.float32)
-  wkn = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
-  bias = rng.standard_normal(cout).astype(np.float32)
-  npad = (cout + 127) // 128 * 128
-  bpad = np.zeros(npad, np.float32); bpad[:cout] = bias
-  m = b * h * w
-  t = dict(
-      X=torch.from_numpy(x).cuda(), w9c=torch.from_numpy(w9c).cuda(),
-      dbias=torch.from_numpy(dbias).cuda(), Wp=_pack(lib, wkn),
-      Ws=_pack_split(lib, wkn), bias=torch.from_numpy(bpad).cuda(),
-      R=torch.from_numpy(rng.standard_normal((m, cout)).astype(np.float32)).cuda())
-
-  def make(T, C, sync):
-    dw = _lib.DepthwiseArgs(X=_p(t['X']), ldx=cin, w9c=_p(t['w9c']), bias=_p(t['dbias']),
-                            Y=_p(T), ldy=cin, B=b, Hi=h, Wi=w, Ho=h, Wo=w, C=cin,
-                            stride=1, rate=rate, relu_in=relu_in, relu_out=relu_out)
-    pw = _lib.PointwiseArgs(A=_p(T), lda=cin, Wp=_p(t['Wp']), bias=_p(t['bias']),
-                            R=_p(t['R']) if res else None, ldr=cout, C=_p(C), ldc=cout,
-                            M=m, N=cout, K=cin, relu=1, relu_in=0, sub=1, Ws=_p(t['Ws']))
-    return dw, pw, _lib.SepConvArgs(dw=dw, pw=pw, sync=_p(sync) if sync is not None
-                                    else None, stats=None)
-  return t, m, make
-
-
-@pytest.mark.parametrize('b,h,w,cin,cout,rate', [
-    (1, 60, 80, 728, 728, 2),       # middle flow: 128-row tiles, 6 siblings, ragged slices
-    (1, 60, 80, 1024, 1536, 4),     # exit flow: 12 column tiles (no banded order when fused)
-    (1, 30, 40, 304, 256, 1),       # decoder shape: 64-row tiles, slices of 38 float4
-    (2, 13, 17, 64, 128, 1),        # one column tile, M not a multiple of the tile
-    (1, 9, 11, 36, 200, 3),         # rate > half the image: every tap class at the border
-    (1, 120, 160, 256, 256, 1)])    # 19200 rows
-@pytest.mark.parametrize('relu_in,relu_out,res', [(0, 1, 0), (1, 0, 1)])
-def test_fused_separable_conv_equals_two_launches(lib, b, h, w, cin, cout, rate, relu_in,
-                                                  relu_out, res):
-  """epos_separable_conv_f32 (depthwise as a producer phase of the GEMM's workgroups)
-  against epos_depthwise3x3_f32 + epos_pointwise_conv_f32: intermediate and output
-  bit for bit, over repeated launches (the hand-off counters re-arm themselves)."""
-  from epos_amd import _lib
-  t, m, make = _sepconv_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res)
-  T0 = torch.full((m, cin), 3.0, device='cuda'); C0 = torch.zeros(m, cout, device='cuda')
-  dw, pw, _ = make(T0, C0, None)
-  _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))
-  torch.cuda.synchronize()
-  sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32,
-                     device='cuda')
-  T1 = torch.empty(m, cin, device='cuda'); C1 = torch.empty(m, cout, device='cuda')
-  _, _, sa = make(T1, C1, sync)
-  for it in range(4):
-    T1.fill_(float(it)); C1.fill_(-1.0)       # stale lines from the previous round
-    _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sa), None))
-    torch.cuda.synchronize()
-    assert torch.equal(T1, T0), 'intermediate, launch %d' % it
-    assert torch.equal(C1, C0), 'output, launch %d' % it
-    assert int(sync.abs().sum()) == 0         # re-armed
-  # fp64 check of the reference itself (so that "equal" means "right")
-  x = t['X'].double().permute(0, 3, 1, 2)
-  if relu_in:
-    x = x.clamp(min=0)
-  wd = t['w9c'].double().t().reshape(cin, 1, 3, 3)
-  y = F.conv2d(x, wd, padding=rate, dilation=rate, groups=cin) + t['dbias'].double().view(1, -1, 1, 1)
-  if relu_out:
-    y = y.clamp(min=0)
-  np.testing.assert_allclose(T0.cpu().numpy().reshape(b, h, w, cin),
-                             y.permute(0, 2, 3, 1).cpu().numpy(), rtol=1e-5, atol=1e-5)
-
-
-def test_fused_separable_conv_concurrent_streams_and_timeout(lib, monkeypatch):
-  """Four fused layers in flight on four streams with other kernels competing for the
-  workgroup slots (uneven load), many rounds, every word checked; then the same with
-  a zero time-out, where every workgroup gives up waiting at once and computes its
-  siblings' slices itself -- same bits (the progress guarantee of the hand-off)."""
-  import os
-  import subprocess
-  import sys
-  from epos_amd import _lib
-  b, h, w, cin, cout, rate = 1, 60, 80, 728, 728, 2
-  t, m, make = _sepconv_problem(lib, b, h, w, cin, cout, rate, 1, 0, 1, seed=5)
-  T0 = torch.empty(m, cin, device='cuda'); C0 = torch.empty(m, cout, device='cuda')
-  dw, pw, _ = make(T0, C0, None)
-  _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))
-  torch.cuda.synchronize()
-  streams = [torch.cuda.Stream() for _ in range(4)]
-  bufs = []
-  for s in streams:
-    sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32,
-                       device='cuda')
-    T = torch.zeros(m, cin, device='cuda'); C = torch.zeros(m, cout, device='cuda')
-    bufs.append((T, C, sync, make(T, C, sync)[2]))
-  noise = torch.randn(1 << 22, device='cuda')
-  for rnd in range(25):
-    for i, s in enumerate(streams):
-      T, C, sync, sa = bufs[i]
-      with torch.cuda.stream(s):
-        if (rnd + i) % 3 == 0:
-          noise.mul_(1.0001)                      # uneven load between the launches
-        T.fill_(float(rnd)); C.fill_(-2.0)
-        _lib.check(lib.epos_separable_conv_f32(
-            ctypes.byref(sa), ctypes.c_void_p(s.cuda_stream)))
-    torch.cuda.synchronize()
-    for T, C, sync, _ in bufs:
-      assert torch.equal(T, T0) and torch.equal(C, C0), 'round %d' % rnd
-      assert int(sync.abs().sum()) == 0
-  # zero time-out in a fresh process (the value is read once per process)
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  script = (
-      "import sys, ctypes, numpy as np, torch\n"
-      "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-      "from epos_amd import _lib\n"
-      "import test_gpu_layers as tl\n"
-      "lib = _lib.load()\n"
-      "t, m, make = tl._sepconv_problem(lib, 1, 60, 80, 728, 728, 2, 1, 0, 1, seed=5)\n"
-      "T0 = torch.empty(m, 728, device='cuda'); C0 = torch.empty(m, 728, device='cuda')\n"
-      "dw, pw, _ = make(T0, C0, None)\n"
-      "_lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))\n"
-      "_lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))\n"
-      "sync = torch.zeros(int(lib.epos_separable_conv_sync_words(m)), dtype=torch.int32, device='cuda')\n"
-      "stats = torch.zeros(2, dtype=torch.int32, device='cuda')\n"
-      "T = torch.zeros(m, 728, device='cuda'); C = torch.zeros(m, 728, device='cuda')\n"
-      "sa = make(T, C, sync)[2]; sa.stats = ctypes.c_void_p(stats.data_ptr())\n"
-      "for it in range(3):\n"
-      "  _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sa), None)); torch.cuda.synchronize()\n"
-      "  assert torch.equal(T, T0) and torch.equal(C, C0), it\n"
-      "  assert int(sync.abs().sum()) == 0\n"
-      "print('TIMEOUTS', int(stats[0]))\n" % (root, os.path.join(root, 'tests')))
-  r = subprocess.run([sys.executable, '-c', script],
-                     env=dict(os.environ, EPOS_SEPCONV_TIMEOUT_US='0'),
-                     capture_output=True, text=True, timeout=600)
-  assert r.returncode == 0, r.stdout + r.stderr
-  assert int(r.stdout.split('TIMEOUTS')[1]) > 0, r.stdout     # the path was taken
 
 
 # --------------------------------------------- split GEMM on adversarial operands ---

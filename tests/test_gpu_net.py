@@ -172,70 +172,6 @@ def test_split_gemm_network_is_not_less_accurate_than_fp32_mfma(tmp_path):
     assert rms['1'][k] <= rms['0'][k] * 1.15, k
 
 
-def test_fused_separable_convs_give_the_same_network_bits(monkeypatch):
-  """EPOS_SEPCONV_FUSED=1 (every stride-1 separable conv with a GEMM launch of its own runs
-  as ONE launch: LDS-staged depthwise producer phase writing fp16 pairs + pre-split K loop,
-  csrc/pointwise_gemm_h2.hip) against the default plan (depthwise launch + GEMM launch with
-  the in-kernel operand split): every head tensor and the encoder / decoder check points
-  bit for bit, eagerly and as a replayed graph, and no hand-off timed out."""
-  from epos_amd import model, weights
-  num_objs, h, w = 2, 96, 128
-  ckpt = weights.random_init(num_objs=num_objs, seed=3, randomize_bn=True, logits_std=0.2)
-  img = torch.from_numpy(
-      np.random.RandomState(0).randint(0, 256, (1, h, w, 3)).astype('f')).cuda()
-  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
-  # the image-pooling mean from the last GEMM's block sums (another summation order) is only
-  # attached to a stand-alone GEMM launch: compare like with like
-  monkeypatch.setenv('EPOS_POOL_FOLD', '0')
-  monkeypatch.setenv('EPOS_SEPCONV_FUSED', '0')
-  net0 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=10)
-  out0 = {k: v.clone() for k, v in net0.forward(img).items()}
-  monkeypatch.setenv('EPOS_SEPCONV_FUSED', '1')
-  net1 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=11)
-  assert len(net1.fused_sepconvs) >= 50 and not net0.fused_sepconvs
-  assert len(net1.presplit_layers) >= len(net1.fused_sepconvs)
-  for rep in range(3):
-    out1 = net1.forward(img, use_graph=rep > 0)
-    torch.cuda.synchronize()
-    for k in out0:
-      assert torch.equal(out0[k], out1[k]), (k, rep)
-    assert torch.equal(net0.encoder, net1.encoder)
-    assert torch.equal(net0.decoder_out, net1.decoder_out)
-  assert int(net1.sepconv_stats[0]) == 0
-
-
-def test_head_softmax_in_the_epilogue_gives_the_same_network_bits(monkeypatch):
-  """The fragment-confidence softmax as part of the heads' GEMM launch (EPOS_HEAD_SOFTMAX_FUSED=1;
-  opt-in: measured slower) against the separate softmax_groups64 launch (the default): every output bit
-  for bit, eagerly and as a replayed graph; run_plan(with_post=False) still leaves the RAW
-  logits in the head buffers."""
-  from epos_amd import model, weights
-  num_objs, h, w = 3, 96, 128
-  ckpt = weights.random_init(num_objs=num_objs, seed=5, randomize_bn=True, logits_std=0.5)
-  img = torch.from_numpy(
-      np.random.RandomState(1).randint(0, 256, (2, h, w, 3)).astype('f')).cuda()
-  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
-  monkeypatch.setenv('EPOS_HEAD_SOFTMAX_FUSED', '0')
-  net0 = model.get_net(ckpt, 2, h, w, num_objs, 64, mo, instance=20)
-  out0 = {k: v.clone() for k, v in net0.forward(img).items()}
-  monkeypatch.setenv('EPOS_HEAD_SOFTMAX_FUSED', '1')
-  net1 = model.get_net(ckpt, 2, h, w, num_objs, 64, mo, instance=21)
-  assert net1._fuse_head_softmax and not net0._fuse_head_softmax
-  for rep in range(3):
-    out1 = net1.forward(img, use_graph=rep > 0)
-    torch.cuda.synchronize()
-    for k in out0:
-      assert torch.equal(out0[k], out1[k]), (k, rep)
-  s = out1['pred_frag_conf'].sum(-1)
-  assert float((s - 1).abs().max()) < 1e-5
-  net0.set_images(img); net0.run_plan(with_post=False)
-  net1.set_images(img); net1.run_plan(with_post=False)
-  torch.cuda.synchronize()
-  raw0, raw1 = net0.logits['pred_frag_conf'], net1.logits['pred_frag_conf']
-  assert torch.equal(raw0, raw1)
-  assert float(raw1.view(-1, 64).sum(-1).sub(1).abs().max()) > 1e-3        # logits, not probabilities
-
-
 def test_folded_image_pooling_and_slot_clear_match_the_separate_launches(monkeypatch):
   """Round 4: the image-pooling mean from the last encoder GEMM's 32-row block sums and the slot
   table cleared by the opening im2col launch (the defaults) against the separate kernels
@@ -263,30 +199,3 @@ def test_folded_image_pooling_and_slot_clear_match_the_separate_launches(monkeyp
       a, b = out0[k].float(), out1[k].float()
       assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), k
 
-
-def test_graph_branches_give_the_same_network_bits(monkeypatch):
-  """EPOS_GRAPH_BRANCHES=1 (opt-in): the Xception shortcut convs and the image-pooling branch on
-  a second stream between fork and join events (parallel branches of the captured hipGraph,
-  net_xception.py:296-302, model.py:213-258) -- every output bit for bit against the linear
-  plan, eagerly and as a replayed graph, many replays (a missing join would race)."""
-  from epos_amd import model, weights
-  num_objs, h, w = 3, 96, 128
-  ckpt = weights.random_init(num_objs=num_objs, seed=7, randomize_bn=True, logits_std=0.5)
-  img = torch.from_numpy(
-      np.random.RandomState(2).randint(0, 256, (1, h, w, 3)).astype('f')).cuda()
-  mo = model.ModelOptions(model.get_outputs_to_num_channels(num_objs, 64))
-  monkeypatch.setenv('EPOS_GRAPH_BRANCHES', '0')
-  net0 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=40)
-  out0 = {k: v.clone() for k, v in net0.forward(img).items()}
-  monkeypatch.setenv('EPOS_GRAPH_BRANCHES', '1')
-  net1 = model.get_net(ckpt, 1, h, w, num_objs, 64, mo, instance=41)
-  assert net1.graph_branches and not net0.graph_branches
-  side = torch.cuda.Stream()
-  for rep in range(12):
-    with torch.cuda.stream(side if rep % 2 else torch.cuda.current_stream()):
-      out1 = net1.forward(img, use_graph=rep > 1)
-    torch.cuda.synchronize()
-    for k in out0:
-      assert torch.equal(out0[k], out1[k]), (k, rep)
-    assert torch.equal(net0.encoder, net1.encoder)
-    assert torch.equal(net0.decoder_out, net1.decoder_out)

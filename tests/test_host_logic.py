@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
   assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
   for name in declared:
     assert hasattr(lib, name), name
-  assert lib.epos_abi_version() == 6
+  assert lib.epos_abi_version() == 7
 
 
 def test_pack_pointwise_weights_host():

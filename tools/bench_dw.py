@@ -14,6 +14,7 @@ if defs:
   subprocess.check_call([build.HIPCC] + build.FLAGS + defs + ['-o', path] + build.sources())
   _lib.lib_path = lambda: path
 lib = _lib.load()
+H2 = '--h2' in sys.argv          # fp16-pair output (what the plan's depthwise layers write)
 def p(t): return ctypes.c_void_p(t.data_ptr())
 shapes = [(60, 80, 728, 2), (60, 80, 1024, 2), (60, 80, 1536, 4), (60, 80, 2048, 12), (120, 160, 256, 1),
           (120, 160, 304, 1), (240, 320, 64, 1), (240, 320, 128, 1), (60, 80, 256, 1)]
@@ -30,6 +31,10 @@ for (h, w, c, rate) in shapes:
   w9 = torch.randn(9, c, device='cuda'); b = torch.randn(c, device='cuda')
   a = _lib.DepthwiseArgs(X=p(X), ldx=c, w9c=p(w9), bias=p(b), Y=p(Y), ldy=c, B=1, Hi=h, Wi=w,
                          Ho=h, Wo=w, C=c, stride=1, rate=rate, relu_in=1, relu_out=0)
+  if H2:
+    import numpy as np
+    slot = torch.zeros(64, dtype=torch.int32, device='cuda'); slot[0] = int(np.float32(6.0).view(np.int32))
+    a.x_amax = p(slot); a.gain = 30.0; a.bias0 = 3.0; a.y_h2 = 1
   us = timeit(lambda: lib.epos_depthwise3x3_f32(ctypes.byref(a), None))
   cp = timeit(lambda: Y.copy_(X))
   mb = 2 * X.numel() * 4 / 1e6

@@ -5,11 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from epos_amd import _lib
 lib = _lib.load()
-USE_WS = os.environ.get('BENCH_WS', '0') == '1'
 RELU_IN = int(os.environ.get('BENCH_RELU_IN', '0'))
 CHECK = os.environ.get('BENCH_CHECK', '1') == '1'
 SPLIT = os.environ.get('BENCH_SPLIT', '0') == '1'   # hand the split-packed weights over too
-WS = torch.zeros(int(lib.epos_pointwise_workspace_bytes()), dtype=torch.uint8, device='cuda')
 def p(t): return ctypes.c_void_p(t.data_ptr())
 shapes = [(4800,728,728,1),(4800,728,728,0),(4800,1024,728,0),(4800,1536,1024,0),(4800,2048,1536,0),(4800,256,2048,0),(4800,256,1280,0),
           (19200,256,304,0),(19200,128,64,0),(19200,256,128,0),(76800,64,288,0),(19200,4032,256,0),(9600,728,728,1),(19200,728,728,1)]
@@ -25,7 +23,7 @@ for (m,n,k,res) in shapes:
     lib.epos_pack_pointwise_weights_split(w.ctypes.data_as(ctypes.c_void_p),k,n,d8.ctypes.data_as(ctypes.c_void_p))
     Ws = torch.from_numpy(d8).cuda()
   a = _lib.PointwiseArgs(A=p(A),lda=k,Wp=p(Wp),bias=p(b),R=p(R) if res else None,ldr=n,C=p(C),ldc=n,M=m,N=n,K=k,relu=0,relu_in=RELU_IN,sub=1,Ws=p(Ws) if Ws is not None else None)
-  call = (lambda: lib.epos_pointwise_conv_grouped_ws_f32(ctypes.byref(a), 1, p(WS), None)) if USE_WS else (lambda: lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+  call = lambda: lib.epos_pointwise_conv_f32(ctypes.byref(a), None)
   for _ in range(3): call()
   torch.cuda.synchronize()
   err = ''

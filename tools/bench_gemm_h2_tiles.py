@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""128 x 128 against 128 x 64 output tiles and the eight-wave form of the fp16-pair GEMM (round 4, judge's item 3:
+"""128 x 128 against 128 x 64 output tiles of the fp16-pair GEMM (the eight-wave form of round 4 and the
+256 x 128 tile of round 5 were measured with this script at commits 0698228 / 1b05025 -- profiles/r04/gemm_h2_tile_shapes.txt,
+profiles/r05/gemm_h2_tall_tile_shapes*.txt -- and left the library again). Round 4, judge's item 3:
 "a 64-row tile (456 tiles)" for a single image's M = 4800 layers), per shape: one launch at
 a time on one stream, and 2 / 4 streams round robin (what a pipeline of images looks like).
 With and without pre-split A, residual epilogue for the middle-flow shape.
@@ -15,7 +17,7 @@ lib = _lib.load()
 PLAN = '--plan-args' in sys.argv     # bias, second absmax slot + gain, published output absmax (as the plan's layers)
 PS = '--presplit' in sys.argv          # A already as fp16 pairs (what the plan's depthwise layers write)
 argv = [a for a in sys.argv[1:] if not a.startswith('--')]
-MODES = argv[0].split(',') if argv else ['128x128', '128x64', '8 waves', '256x128']
+MODES = argv[0].split(',') if argv else ['128x128', '128x64']
 def p(t): return ctypes.c_void_p(t.data_ptr())
 # (M, N, K, residual)
 BIG = '--big' in sys.argv            # launches of many tiles (batches of four / eight, the heads, steady state)
@@ -48,11 +50,9 @@ for (m, n, k, res) in shapes:
                              C=p(Cs[i]), ldc=n, M=m, N=n, K=k, relu=1, relu_in=0, sub=1, Wh=p(Wh),
                              a_amax=p(slot), a_presplit=1 if PS else 0) for i in range(NS)]
   tiles = -(-m // 128) * -(-n // 128)
-  for name, limit, deep, tall in (('128x128', 0, 0, 0), ('128x64', 1 << 30, 0, 0), ('8 waves', 0, 1 << 30, 0), ('256x128', 0, 0, 1)):
+  for name, limit in (('128x128', 0), ('128x64', 1 << 30)):
     if name not in MODES: continue
     lib.epos_set_h2_narrow_tile_limit(limit)
-    lib.epos_set_h2_latency_tile_limit(deep)
-    lib.epos_set_h2_tall_tile_min(tall)
     cells = []
     for nstream in (1, 2, 4):
       def call(i):
@@ -71,5 +71,3 @@ for (m, n, k, res) in shapes:
       cells.append('%6.1f (%3.0f)' % (us, 2.0 * m * n * k / us * 1e-6))
     print('%-26s %-9s %s' % ('%dx%dx%d%s [%d]' % (m, n, k, '+R' if res else '', tiles), name, '   '.join(cells)), flush=True)
 lib.epos_set_h2_narrow_tile_limit(100)
-lib.epos_set_h2_latency_tile_limit(0)
-lib.epos_set_h2_tall_tile_min(0)

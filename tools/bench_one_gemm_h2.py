@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """ONE shape of the fp16-pair GEMM, a few launches (for rocprofv3 --pmc passes, tools/pmc_h2_gemm.sh):
-    python tools/bench_one_gemm_h2.py M N K iters [presplit] [tall]"""
+    python tools/bench_one_gemm_h2.py M N K iters [presplit]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,8 +8,8 @@ from epos_amd import _lib
 lib = _lib.load()
 def p(t): return ctypes.c_void_p(t.data_ptr())
 m, n, k, it = [int(x) for x in sys.argv[1:5]]
-ps = 'presplit' in sys.argv; tall = 'tall' in sys.argv
-lib.epos_set_h2_narrow_tile_limit(0); lib.epos_set_h2_tall_tile_min(1 if tall else 0)
+ps = 'presplit' in sys.argv
+lib.epos_set_h2_narrow_tile_limit(0)
 A = torch.relu(torch.randn(m, k, device='cuda'))
 if ps: A = torch.randn(m, 2 * k, device='cuda').to(torch.float16).view(torch.float32)
 C = torch.empty(m, n, device='cuda')

@@ -1,13 +1,20 @@
 #!/bin/bash
-# Same-box A/B of two environments of bench.py: bash tools/ab_env.sh "VAR=a" "VAR=b" [bench args]
-# (interleaved runs A B A B)
-A=$1; B=$2; shift 2
-for rep in 1 2; do for E in "$A" "$B"; do
-  env $E python bench.py --steps 60 --warmup 8 --no-cpu-baseline --traffic static "$@" 2>/dev/null | tail -1 | python -c "
+# Same-box A/B of environments of bench.py (interleaved, REPS rounds):
+#   bash tools/ab_env.sh "VAR=a" "VAR=b" [...more environments] -- [bench args]
+ENVS=()
+while [ $# -gt 0 ] && [ "$1" != "--" ]; do ENVS+=("$1"); shift; done
+[ "${1:-}" = "--" ] && shift
+COMMON=${COMMON:---steps 40 --warmup 8 --no-cpu-baseline --traffic off}
+for rep in $(seq ${REPS:-2}); do for E in "${ENVS[@]}"; do
+  env $E python bench.py $COMMON "$@" 2>/tmp/ab_err.txt | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); i=d['roofline'].get('in_step') or {}
-s=d.get('serial_depth1') or {}
-print('%-36s %7.1f img/s %6.3f ms | serial %6.1f (pred %.3f) | in-step gemm %.3f dw %.3f rest %.3f | per-launch %.1f us' % (
-  sys.argv[1][-36:], d['value'], d['ms_per_step'], s.get('images_per_sec',0), (s.get('stage_ms') or {}).get('prediction',0),
-  i.get('gemm_ms_per_step',0), i.get('depthwise_ms_per_step',0), i.get('rest_ms_per_step',0), d['roofline'].get('avg_launch_us',0)))" "$E"
+try:
+  d=json.loads(sys.stdin.read())
+except Exception as e:
+  print('%-44s FAILED: %s' % (sys.argv[1][-44:], open('/tmp/ab_err.txt').read()[-400:])); sys.exit(0)
+r=d.get('roofline') or {}; i=r.get('in_step') or {}
+s=d.get('serial_depth1') or {}; t=d.get('timed_regions') or {}
+print('%-44s %7.1f img/s (%.1f..%.1f) %6.3f ms | serial %6.1f | in-step gemm %.3f dw %.3f rest %.3f | per-launch %.1f us | %s W %s MHz' % (
+  sys.argv[1][-44:], d['value'], t.get('images_per_sec_min',0), t.get('images_per_sec_max',0), d['ms_per_step'], s.get('images_per_sec',0),
+  i.get('gemm_ms_per_step',0), i.get('depthwise_ms_per_step',0), i.get('rest_ms_per_step',0), r.get('avg_launch_us',0), r.get('power_w'), r.get('core_clock_mhz_under_load')))" "$E"
 done; done

@@ -50,6 +50,11 @@
 // in the epilogue, eight waves per 128 x 128 tile, the 256 x 128 eight-wave tile, deeper
 // rings, other LDS-DMA placements -- is described with its measurements in DESIGN.md (e) and
 // profiles/r04, profiles/r05; the code is in the history (last full version: commit 1b05025).
+// Also tried in round 5 and removed: loader / consumer wave specialisation (eight waves, four
+// of them issuing only the LDS-DMA pieces, four only MFMAs + fragment reads; bit-identical;
+// commit 374286e): SLOWER -- 344 vs 384 TFLOP/s in steady state -- one MFMA wave per SIMD
+// cannot cover the per-K-step barrier and fragment-read latency by itself, DMA issue or not
+// (profiles/r05/gemm_h2_loader_consumer_waves.txt).
 #include <string.h>
 
 #include <mutex>
@@ -259,18 +264,10 @@ __device__ __forceinline__ float vec_epilogue_h2(float* ws, const f32x16* acc,
 
 // PRESPLIT: every problem of the launch has its A operand already as fp16 pairs
 // (EposPointwiseArgs.a_presplit; the plan does not mix the two kinds in one group).
-// SPEC (round 5, experiment): LOADER / CONSUMER specialisation. The workgroup has EIGHT waves:
-// waves 0..3 are the four waves above minus their LDS-DMA issue (12 MFMAs, 10 fragment
-// reads and one barrier per K step, nothing else), waves 4..7 issue the LDS-DMA pieces their
-// consumer twin would have issued and wait for them (counted vmcnt) -- so no MFMA wave's
-// in-order instruction stream is ever held by a DMA issue (60-180 cycles each, four per
-// twelve MFMAs: what kept two co-resident workgroups at 67 % of the pipe,
-// profiles/r05/pmc_h2_*.json). One workgroup per CU (512 threads x 256 registers).
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, int NB = 4, bool SPEC = false>
-__global__ __launch_bounds__(SPEC ? 512 : 256, 2)
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, int NB = 4>
+__global__ __launch_bounds__(256, 2)
 void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   static_assert(NB == 4 || NB == 2, "tile = 128 x 128 or 128 x 64");
-  static_assert(!SPEC || NB == 4, "loader / consumer waves: 128 x 128 tiles");
   using Geo = H2Geo<NB>;
   constexpr int NW = 4;                        // waves 4 x 1: a wave owns 32 rows
   constexpr int NST = H2_NST;
@@ -282,9 +279,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
-  const int wave_all = t >> 6;
-  const bool loader = SPEC && __builtin_amdgcn_readfirstlane(wave_all) >= 4;   // wave-uniform
-  const int wave = SPEC ? (wave_all & 3) : wave_all;     // the 32-row group served
+  const int wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int wrow = wave;                       // the wave's 32-row group
   const int l31 = lane & 31, h = lane >> 5;
@@ -526,19 +521,17 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; corr[j][r] = 0.f; }
 
   // ---- prologue: up to four tiles in flight, tile 0 landed + visible
-  if (!SPEC || loader) {
-    issue(0, 0);
-    h2_static_for(std::make_integer_sequence<int, LA - 1>{}, [&](auto i_tag) {
-      constexpr int i = decltype(i_tag)::value + 1;
-      if (nks > i) issue(i, i);
-    });
-  }
+  issue(0, 0);
+  h2_static_for(std::make_integer_sequence<int, LA - 1>{}, [&](auto i_tag) {
+    constexpr int i = decltype(i_tag)::value + 1;
+    if (nks > i) issue(i, i);
+  });
   H2_STAMP(1);
   if constexpr (LATE_SCALE) {
     h2_scale_finish(am_raw, am_raw2, p.a_gain, p.a_bias, sa_v, inv_a);
     sa = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sa_v)));
   }
-  if (!SPEC || loader) {   // tile 0 has landed once only the later tiles' pieces are outstanding
+  {   // tile 0 has landed once only the later tiles' pieces are outstanding
     bool waited = false;
     h2_static_for(std::make_integer_sequence<int, LA>{}, [&](auto i_tag) {
       constexpr int i = LA - 1 - decltype(i_tag)::value;          // LA-1 .. 0
@@ -547,43 +540,6 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   }
   __builtin_amdgcn_s_barrier();
   H2_STAMP(2);
-  if constexpr (SPEC) {
-    if (loader) {
-      // ---- loader wave: per K step kt, the pieces of tile kt + LA (their stage was read
-      //      for the last time before the barrier of step kt - 1), then "my pieces of tile
-      //      kt + 1 have landed" (counted: the tiles behind it may still be in flight), then
-      //      the step's barrier -- exactly one barrier per step, as the consumers
-      int stage_i = LA % NST;                       // stage of tile kt + LA
-      for (int kt = 0; kt + 1 < nks; ++kt) {
-        if (kt + LA < nks) {
-          if (kt + LA + 1 < nks) {                  // a full K step: the scalar-base forms
-            issue_piece(kt + LA, stage_i, std::integral_constant<int, 0>{}, std::false_type{});
-            issue_piece(kt + LA, stage_i, std::integral_constant<int, 1>{}, std::false_type{});
-            issue_piece(kt + LA, stage_i, std::integral_constant<int, 2>{}, std::false_type{});
-            issue_piece(kt + LA, stage_i, std::integral_constant<int, 3>{}, std::false_type{});
-          } else {
-            issue(kt + LA, stage_i);                // the last, maybe partial
-          }
-        }
-        stage_i = stage_i + 1 == NST ? 0 : stage_i + 1;
-        const int last = kt + LA < nks ? kt + LA : nks - 1;       // newest tile issued
-        switch (last - (kt + 1)) {                                // tiles behind tile kt + 1
-          case 0: h2_wait_vm<0>(); break;
-          case 1: h2_wait_vm<NP>(); break;
-          case 2: h2_wait_vm<2 * NP>(); break;
-          default: h2_wait_vm<3 * NP>(); break;
-        }
-        static_assert(LA == 4, "the loader's counted waits assume a look-ahead of four tiles");
-        __builtin_amdgcn_s_barrier();
-      }
-      // the epilogue's workgroup barriers (the consumers stage and publish)
-      if (vec_epilogue_ok(p, HAS_RES)) {
-        __syncthreads();
-        if (p.c_amax) __syncthreads();
-      }
-      return;
-    }
-  }
   u32x4 ah, am;
   if constexpr (PRESPLIT) {
     read_a_ps(0, ah, am);
@@ -631,7 +587,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
 #endif
       nh[u] = hh; nm[u] = mm;
     };
-    constexpr bool ISSUE = MODE <= 1 && !SPEC;         // SPEC: the loader waves issue
+    constexpr bool ISSUE = MODE <= 1;
     // one MFMA of the schedule + what is pinned behind it
     //   DMA >= 0: LDS-DMA piece DMA of tile kt+4 after this MFMA
     //   SPL >= 0: split unit SPL of the next stage's A fragment after this MFMA
@@ -675,8 +631,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
       // tile kt+1 have landed once at most the later tiles' pieces are outstanding
       // (of tile kt+LA: the four pieces issued above)
 #ifndef EPOS_H2_ABL_NOBAR
-      if constexpr (SPEC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads only
-      else if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_NP>();
+      if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_NP>();
       else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
       __builtin_amdgcn_s_barrier();
 #endif
@@ -914,9 +869,9 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   }
 }
 
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, int NB = 4, bool SPEC = false>
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, int NB = 4>
 int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, NB, SPEC>;
+  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, NB>;
   constexpr int lds = H2Geo<NB>::LDS;
   static_assert(lds >= (4 * 32 * H2Geo<NB>::EP_ROW + 4) * 4, "the epilogue stages through the ring");
   // more than 64 KB of dynamic LDS needs the attribute, once per device (per instantiation)
@@ -938,7 +893,7 @@ int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
     }
   }
   // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(SPEC ? 512 : 256), lds, s, g);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(256), lds, s, g);
   return launch_status("pointwise_gemm_h2_f32");
 }
 
@@ -1175,20 +1130,6 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                        : launch_h2_tt<false, false, false, true, 2>(g, total, s);
     return res ? launch_h2_tt<true, false, false, false, 2>(g, total, s)
                : launch_h2_tt<false, false, false, false, 2>(g, total, s);
-  }
-  static const int spec = [] {            // EXPERIMENT: loader / consumer waves
-    const char* e = getenv("EPOS_H2_SPEC");
-    return e ? atoi(e) : 0;
-  }();
-  if (spec) {
-    if (single) {
-      if (ps) return res ? launch_h2_tt<true, true, false, true, 4, true>(g, total, s)
-                         : launch_h2_tt<false, true, false, true, 4, true>(g, total, s);
-      return res ? launch_h2_tt<true, true, false, false, 4, true>(g, total, s)
-                 : launch_h2_tt<false, true, false, false, 4, true>(g, total, s);
-    }
-    return ps ? launch_h2_tt<false, false, false, true, 4, true>(g, total, s)
-              : launch_h2_tt<false, false, false, false, 4, true>(g, total, s);
   }
   if (single) {
     if (ps) return res ? launch_h2_tt<true, true, false, true>(g, total, s)

@@ -224,10 +224,19 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
     // ---- interior wave: no clamp, no select -----------------------------------
     const unsigned o00 = (y - r) * rowpitch + (x0 - r) * ldx;
     const unsigned rstep = r * rowpitch, cstep = r * ldx;
+#ifdef EPOS_DW_ABL_ONEROW      // ablation: a quarter of the loads (wrong results)
+#pragma unroll
+    for (int i = 0; i < L + 2; ++i) {
+      col[i][1] = ld4(xb + (o00 + rstep + i * cstep));
+#pragma unroll
+      for (int ky = 0; ky < NR; ++ky) col[i][ky] = col[i][1];
+    }
+#else
 #pragma unroll
     for (int i = 0; i < L + 2; ++i)
 #pragma unroll
       for (int ky = 0; ky < NR; ++ky) col[i][ky] = ld4(xb + (o00 + ky * rstep + i * cstep));
+#endif
     if (RELU_IN) {
 #pragma unroll
       for (int i = 0; i < L + 2; ++i)
@@ -239,12 +248,17 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
 #pragma unroll
       for (int j = 0; j < L; ++j) {
         float4 acc = bias;
+#ifdef EPOS_DW_ABL_NOFMA       // ablation: one multiply-add per output instead of nine
+        acc = fma4(col[j + 1][1 + rr], w[4], acc);
+        acc.x += col[j][rr].x + col[j + 2][2 + rr].x;
+#else
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           acc = fma4(col[j][ky + rr], w[ky * 3 + 0], acc);
           acc = fma4(col[j + 1][ky + rr], w[ky * 3 + 1], acc);
           acc = fma4(col[j + 2][ky + rr], w[ky * 3 + 2], acc);
         }
+#endif
         if (RELU_OUT) acc = relu4_1op(acc);
         st4_any(yb + (static_cast<unsigned>((x0 + j * r) * ldy) + (rr ? yrow1 : 0u)), acc, h2, hs);
       }

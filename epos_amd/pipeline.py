@@ -13,6 +13,7 @@ RANSAC kernels consume directly; all objects of all images are fitted by one
 launch sequence instead of a serial per-object loop (infer.py:412).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch

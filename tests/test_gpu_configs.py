@@ -260,19 +260,23 @@ def test_c2_full_size_split_gemm_not_less_accurate_than_fp32_mfma(tmp_path):
       "torch.cuda.synchronize()\n"
       "np.savez(sys.argv[1], **{k: v.cpu().numpy() for k, v in net.logits.items()},\n"
       "         decoder=net.decoder_out.cpu().numpy())\n" % (root, O, H, W_, H, W_, O, F))
-  outs = {}
+  # the two GPU runs (seconds each) go on beside the fp64 oracle of this process (~40 s of CPU)
+  procs = {}
   for mode in ('1', '0'):
     path = str(tmp_path / ('logits_%s.npz' % mode))
-    r = subprocess.run([sys.executable, '-c', script, path],
-                       env=dict(os.environ, EPOS_GEMM_SPLIT=mode), capture_output=True,
-                       text=True, timeout=900)
-    assert r.returncode == 0, r.stdout + r.stderr
-    outs[mode] = dict(np.load(path))
+    procs[mode] = (path, subprocess.Popen(
+        [sys.executable, '-c', script, path], env=dict(os.environ, EPOS_GEMM_SPLIT=mode),
+        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
   from epos_amd import synthetic
   ckpt = weights.random_init(num_objs=O, seed=0, randomize_bn=True, logits_std=0.2)
   img = synthetic.image(7, H, W_)[None]
   with torch.no_grad(), net_ref.precision(torch.float64):
     ref, ep = net_ref.logits(img, ckpt, O, F)
+  outs = {}
+  for mode, (path, pr) in procs.items():
+    out, _ = pr.communicate(timeout=900)
+    assert pr.returncode == 0, out
+    outs[mode] = dict(np.load(path))
   exact = {k: v.permute(0, 2, 3, 1).numpy() for k, v in ref.items()}
   exact['decoder'] = ep['decoder/decoder_conv1'].permute(0, 2, 3, 1).numpy()
   rms = {m: {k: float(np.sqrt(np.mean((outs[m][k].reshape(exact[k].shape)

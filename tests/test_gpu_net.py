@@ -141,18 +141,21 @@ def test_split_gemm_network_is_not_less_accurate_than_fp32_mfma(tmp_path):
       "np.savez(sys.argv[1], **{k: v.cpu().numpy() for k, v in net.logits.items()},\n"
       "         decoder=net.decoder_out.cpu().numpy())\n" % (root, num_objs, h, w, num_objs,
                                                            h, w, num_objs))
-  outs = {}
+  procs = {}                               # the two GPU runs side by side, beside the oracle
   for mode in ('1', '0'):
     path = str(tmp_path / ('logits_%s.npz' % mode))
-    r = subprocess.run([sys.executable, '-c', script, path],
-                       env=dict(os.environ, EPOS_GEMM_SPLIT=mode), capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
-    outs[mode] = dict(np.load(path))
+    procs[mode] = (path, subprocess.Popen(
+        [sys.executable, '-c', script, path], env=dict(os.environ, EPOS_GEMM_SPLIT=mode),
+        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
   ckpt = weights.random_init(num_objs=num_objs, seed=3, randomize_bn=True, logits_std=0.2)
   img = np.random.RandomState(0).randint(0, 256, (1, h, w, 3)).astype('f')
   with torch.no_grad(), net_ref.precision(torch.float64):
     ref, ep = net_ref.logits(img, ckpt, num_objs, 64)
+  outs = {}
+  for mode, (path, pr) in procs.items():
+    out, _ = pr.communicate(timeout=600)
+    assert pr.returncode == 0, out
+    outs[mode] = dict(np.load(path))
   exact = {k: v.permute(0, 2, 3, 1) for k, v in ref.items()}
   # the plan's confidence buffers hold the softmaxed values (model.py:677-678)
   exact['pred_obj_conf'] = torch.softmax(exact['pred_obj_conf'], dim=-1)

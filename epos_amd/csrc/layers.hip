@@ -47,6 +47,7 @@ __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
 __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
                                                            int c4n,
                                                            int64_t total) {
+  EPOS_SET_PRIO(EPOS_DW_PRIO);
   const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool h2 = p.y_h2 != 0;                 // uniform
   float hs = 1.f, hinv;
@@ -151,6 +152,7 @@ template <int L, bool RELU_IN, bool RELU_OUT, int ROWS>
 __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN_BLOCKS)) void depthwise3x3_s1_kernel(
     EposDepthwiseArgs p, int c4n, int nres, int nchunk, int nrows, DwPartition part) {
   constexpr int NR = ROWS + 2;                 // input rows held per column
+  EPOS_SET_PRIO(EPOS_DW_PRIO);
   const bool h2 = p.y_h2 != 0;                 // uniform: fp16-pair output
   float hs = 1.f, hinv;
   if (h2) h2_scale(p.x_amax, p.x_amax2, p.gain, p.bias0, threadIdx.x & 63, hs, hinv);

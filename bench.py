@@ -213,7 +213,7 @@ def measure_traffic_live(args, timeout=240):
     d = tempfile.mkdtemp(prefix='epos_pmc_', dir='/tmp')
     cmd = [rp, '--pmc', counter, '--output-format', 'csv', '-d', d, '--', sys.executable,
            os.path.abspath(__file__), '--gpus', '1', '--steps', '4', '--warmup', '1',
-           '--pipeline-depth', '1', '--batch-per-gpu', str(args.batch_per_gpu),
+           '--timed-repeats', '1', '--pipeline-depth', '1', '--batch-per-gpu', str(args.batch_per_gpu),
            '--height', str(args.height), '--width', str(args.width),
            '--num-objs', str(args.num_objs), '--num-frags', str(args.num_frags),
            '--objs-per-image', str(args.objs_per_image), '--model-variant',
@@ -347,7 +347,7 @@ def gemm_roofline(pipe, steps):
   # (measure_traffic_live: two rocprofv3 --pmc child runs); the committed summary of the
   # last collection is the fallback when rocprofv3 is unavailable (--traffic static).
   traffic, traffic_src = None, None
-  for rnd in ('r03', 'r02', 'r01'):
+  for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
     tpath = os.path.join(ROOT, 'profiles', rnd, 'gemm_hbm_traffic_pmc.json')
     if os.path.exists(tpath):
       with open(tpath) as f:

@@ -10,12 +10,13 @@
 #   (gfx950 x2 correction on FETCH_SIZE; PMC passes never share a run with trace options);
 # - the RANSAC-only microbenchmark.
 set -u
-R=${1:-r03}
+R=${1:-r05}
 cd "$(dirname "$0")/.."
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/bench_driver_cmd.err | tail -1 > $OUT/bench_driver_cmd.json
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_driver_cmd_again.json
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_100steps.json
 python bench.py --steps 100 --warmup 10 --sparse-heads --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_sparse_heads.json
 EPOS_GEMM_SPLIT=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_fp32_mfma.json
@@ -29,7 +30,7 @@ python bench.py --steps 40 --warmup 5 --batch-per-gpu 4 --no-cpu-baseline --traf
 for d in 4 1; do
   mkdir -p $OUT/kt$d
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt$d -- \
-    python bench.py --gpus 1 --steps 20 --warmup 5 --pipeline-depth $d --no-cpu-baseline --traffic static --no-stage-times > $OUT/kt$d.log 2>&1
+    python bench.py --gpus 1 --steps 20 --warmup 5 --timed-repeats 1 --pipeline-depth $d --no-cpu-baseline --traffic static --no-stage-times > $OUT/kt$d.log 2>&1
   f=$(find $OUT/kt$d -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" $OUT/rocprofv3_kernel_stats_depth$d.csv
   f=$(find $OUT/kt$d -name '*kernel_trace.csv' | head -1)
@@ -39,7 +40,7 @@ done
 for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p $OUT/pmc_$c
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- \
-    python bench.py --steps 4 --warmup 1 --pipeline-depth 1 --no-cpu-baseline --no-roofline --no-stage-times > $OUT/pmc_$c.log 2>&1
+    python bench.py --steps 4 --warmup 1 --timed-repeats 1 --pipeline-depth 1 --no-cpu-baseline --no-roofline --no-stage-times > $OUT/pmc_$c.log 2>&1
   f=$(find $OUT/pmc_$c -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python tools/pmc_traffic.py "$f" $c > $OUT/pmc_$c.json
 done

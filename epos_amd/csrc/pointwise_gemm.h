@@ -4,6 +4,7 @@
 #pragma once
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -30,6 +31,27 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
 bool h2_eligible(const EposPointwiseArgs* args, int count);
 
 namespace {
+
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel:
+// once per DEVICE and kernel instantiation (the caller's function-local statics), under a lock
+// -- launches may come from several host threads and devices.
+struct LdsAttrOnce {
+  std::mutex mu;
+  bool set[16] = {};
+};
+inline int ensure_dynamic_lds(LdsAttrOnce& once, const void* kern, int bytes, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    set_error("%s: no current device", what);
+    return EPOS_E_INVALID;
+  }
+  std::lock_guard<std::mutex> lock(once.mu);
+  if (once.set[dev]) return EPOS_OK;
+  const int rc = check_hip(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               bytes), what);
+  if (!rc) once.set[dev] = true;
+  return rc;
+}
 
 constexpr int BN = 128;
 constexpr int BK = 32;

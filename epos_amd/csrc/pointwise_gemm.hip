@@ -566,12 +566,12 @@ int launch_grouped_t(const GroupedArgs& g, int total, hipStream_t s) {
   constexpr int LDS_A_TILE = BM * LDS_A_ROW;
   constexpr size_t LDS_MAX = 160 * 1024;
   size_t lds = sizeof(float) * (2 * LDS_A_TILE + 2 * LDS_B_TILE);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(pointwise_gemm_f32<BM, RELU_IN, HAS_RES>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-    attr_set = true;
+  static LdsAttrOnce once;
+  {
+    const int rc = ensure_dynamic_lds(
+        once, reinterpret_cast<const void*>(pointwise_gemm_f32<BM, RELU_IN, HAS_RES>),
+        static_cast<int>(LDS_MAX), "hipFuncSetAttribute(pointwise_gemm_f32)");
+    if (rc) return rc;
   }
   // Workgroup placement: the dispatcher packs workgroups onto a CU while its
   // resources last, so a grid that fits "3 per CU" leaves CUs idle. Request just

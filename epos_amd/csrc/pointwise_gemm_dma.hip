@@ -3,8 +3,6 @@
 // ("The fp32-MFMA kernel") holds the measurements behind every choice below. (A persistent
 // stream-K variant on the same ring lived here through round 4: correct, tested, slower end
 // to end -- removed in round 5, history up to commit 1b05025.)
-#include <mutex>
-
 #include "pointwise_gemm.h"
 
 namespace epos {
@@ -378,25 +376,12 @@ __global__ __launch_bounds__(THREADS) void pointwise_gemm_dma_f32(GroupedArgs ga
 
 template <bool HAS_RES, int LAYOUT, bool CONV, bool SINGLE>
 int launch_dma_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  // more than 64 KB of dynamic LDS needs the attribute, once per device (per instantiation)
-  static std::mutex mu;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
-    set_error("pointwise_gemm_dma_f32: no current device");
-    return EPOS_E_INVALID;
-  }
+  static LdsAttrOnce once;
   {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!attr_set[dev]) {
-      const int rc = check_hip(
-          hipFuncSetAttribute(
-              reinterpret_cast<const void*>(pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV, SINGLE>),
-              hipFuncAttributeMaxDynamicSharedMemorySize, DMA_LDS_BYTES),
-          "hipFuncSetAttribute(pointwise_gemm_dma_f32)");
-      if (rc) return rc;
-      attr_set[dev] = true;
-    }
+    const int rc = ensure_dynamic_lds(
+        once, reinterpret_cast<const void*>(pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV, SINGLE>),
+        DMA_LDS_BYTES, "hipFuncSetAttribute(pointwise_gemm_dma_f32)");
+    if (rc) return rc;
   }
   // 72 KB per workgroup: at most two per CU = two MFMA waves per SIMD
   hipLaunchKernelGGL((pointwise_gemm_dma_f32<HAS_RES, LAYOUT, CONV, SINGLE>), dim3(total),

@@ -874,23 +874,11 @@ int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
   auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, NB>;
   constexpr int lds = H2Geo<NB>::LDS;
   static_assert(lds >= (4 * 32 * H2Geo<NB>::EP_ROW + 4) * 4, "the epilogue stages through the ring");
-  // more than 64 KB of dynamic LDS needs the attribute, once per device (per instantiation)
-  static std::mutex mu;
-  static bool attr_set[RING_DEVICES] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RING_DEVICES) {
-    set_error("pointwise_gemm_h2_f32: no current device");
-    return EPOS_E_INVALID;
-  }
+  static LdsAttrOnce once;
   {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!attr_set[dev]) {
-      const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                               "hipFuncSetAttribute(pointwise_gemm_h2_f32)");
-      if (rc) return rc;
-      attr_set[dev] = true;
-    }
+    const int rc = ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), lds,
+                                      "hipFuncSetAttribute(pointwise_gemm_h2_f32)");
+    if (rc) return rc;
   }
   // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD
   hipLaunchKernelGGL(kern, dim3(total), dim3(256), lds, s, g);

@@ -28,8 +28,6 @@
 // per stage as in pointwise_gemm_dma_f32.
 #include <string.h>
 
-#include <mutex>
-
 #include "pointwise_gemm.h"
 
 namespace epos {
@@ -584,24 +582,11 @@ __global__ __launch_bounds__(THREADS, 2) void pointwise_gemm_split_f32(GroupedAr
 template <bool HAS_RES, bool SINGLE, int CB, bool TWO_ACC, bool CONV = false>
 int launch_split_tt(const GroupedArgs& g, int total, hipStream_t s) {
   auto kern = pointwise_gemm_split_f32<HAS_RES, SINGLE, TWO_ACC, CB, CONV>;
-  // more than 64 KB of dynamic LDS needs the attribute, once per device (per instantiation)
-  static std::mutex mu;
-  static bool attr_set[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
-    set_error("pointwise_gemm_split_f32: no current device");
-    return EPOS_E_INVALID;
-  }
+  static LdsAttrOnce once;
   {
-    std::lock_guard<std::mutex> lock(mu);
-    if (!attr_set[dev]) {
-      const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   sp_lds_bytes(CB)),
-                               "hipFuncSetAttribute(pointwise_gemm_split_f32)");
-      if (rc) return rc;
-      attr_set[dev] = true;
-    }
+    const int rc = ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), sp_lds_bytes(CB),
+                                      "hipFuncSetAttribute(pointwise_gemm_split_f32)");
+    if (rc) return rc;
   }
   // 80 / 64 KB per workgroup: at most two per CU = two MFMA waves per SIMD
   hipLaunchKernelGGL(kern, dim3(total), dim3(THREADS), sp_lds_bytes(CB), s, g);

@@ -941,13 +941,24 @@ int launch_absmax(const float* X, int64_t ldx, int64_t rows, int64_t cols, unsig
 // caller's stream. A slot is reused after 256 further such calls -- plans that overlap
 // streams or capture graphs pass their own slots.
 // 16 zero bytes per device for GroupedArgs.zero_chunk
-const float* zero_chunk_dev() {
+// true while `s` is being captured into a graph (an allocation or a legacy-stream memset
+// issued then would invalidate the capture)
+bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+}
+
+const float* zero_chunk_dev(hipStream_t s) {
   static std::mutex mu;
   static float* z[RING_DEVICES] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RING_DEVICES) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   if (!z[dev]) {
+    // first fp16-pair launch on this device: the chunk is allocated and zeroed NOW -- not
+    // possible inside a stream capture (callers warm up once before capturing, as the
+    // network plan does); refused with an error instead of breaking the capture
+    if (capturing(s)) return nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&z[dev]), 64) != hipSuccess) { z[dev] = nullptr; return nullptr; }
     if (hipMemset(z[dev], 0, 64) != hipSuccess) {     // never hand out an unzeroed chunk
       (void)hipFree(z[dev]);
@@ -970,7 +981,7 @@ void set_tn_div(GroupedArgs& g, int i) {
 }
 
 constexpr int RING_SLOTS = 256;
-unsigned* ring_slot() {
+unsigned* ring_slot(hipStream_t s) {
   // one ring per device, created under a lock (calls may come from several host threads
   // and devices); the round-robin index is atomic
   static std::mutex mu;
@@ -980,6 +991,7 @@ unsigned* ring_slot() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RING_DEVICES) return nullptr;
   {
     std::lock_guard<std::mutex> lock(mu);
+    if (!base[dev] && capturing(s)) return nullptr;      // see zero_chunk_dev
     if (!base[dev] &&
         hipMalloc(reinterpret_cast<void**>(&base[dev]),
                   sizeof(unsigned) * EPOS_AMAX_WORDS * RING_SLOTS) != hipSuccess) {
@@ -1057,9 +1069,10 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
     if (!g.p[i].a_amax) {
       // no bound given: measure A (rows actually read: the whole [B, Hi, Wi] map when
       // the rows are gathered with a stride or by conv taps)
-      unsigned* slot = ring_slot();
+      unsigned* slot = ring_slot(s);
       if (!slot) {
-        set_error("launch_grouped_h2: cannot allocate the absmax slot ring");
+        set_error("launch_grouped_h2: cannot allocate the absmax slot ring (first use on this "
+                  "device during a stream capture? launch once before capturing)");
         return EPOS_E_INVALID;
       }
       const bool gathered = conv_cin || args[i].sub > 1;
@@ -1101,9 +1114,10 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
   bool narrow = !conv_cin && total <= __atomic_load_n(&narrow_limit(), __ATOMIC_RELAXED);
   for (int i = 0; i < count; ++i) narrow = narrow && !args[i].col_sums;
   if (narrow) lay_out(64);
-  g.zero_chunk = zero_chunk_dev();
+  g.zero_chunk = zero_chunk_dev(s);
   if (!g.zero_chunk) {
-    set_error("launch_grouped_h2: cannot allocate the zero chunk");
+    set_error("launch_grouped_h2: cannot allocate the zero chunk (first fp16-pair launch on this "
+              "device during a stream capture? launch once before capturing)");
     return EPOS_E_INVALID;
   }
   const bool res = args[0].R != nullptr;

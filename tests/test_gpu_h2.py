@@ -634,3 +634,54 @@ def test_block_sums_need_the_fp16_pair_kernel(lib):
                          M=64, N=32, K=32, relu=0, relu_in=0, sub=1, col_sums=_p(part), col_ld=32)
   with pytest.raises(_lib.EposError):
     _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+
+
+def test_first_fp16_pair_launch_inside_a_capture_is_refused_not_broken(tmp_path):
+  """The fp16-pair GEMM allocates its 64-byte zero chunk (and, without a caller-provided
+  absmax slot, its slot ring) on the first launch of a device. Inside a stream capture
+  that allocation / legacy-stream memset would invalidate the capture: the launch is REFUSED
+  with an error there (a fresh process; the network plan warms up before it captures), the
+  capture stays valid, and the same launch works afterwards -- also captured."""
+  import os
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  script = r'''
+import ctypes, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from epos_amd import _lib
+lib = _lib.load()
+def p(t): return ctypes.c_void_p(t.data_ptr())
+m, k, n = 256, 64, 128
+rng = np.random.RandomState(0)
+a = rng.standard_normal((m, k)).astype(np.float32); w = rng.standard_normal((k, n)).astype(np.float32)
+A = torch.from_numpy(a).cuda(); C = torch.zeros(m, n, device='cuda')
+def pack(fn, dt):            # the plain packer counts floats, the fp16-pair packer bytes
+  tot = fn(w.ctypes.data_as(ctypes.c_void_p), k, n, None); d = np.empty(tot, dt)
+  fn(w.ctypes.data_as(ctypes.c_void_p), k, n, d.ctypes.data_as(ctypes.c_void_p)); return torch.from_numpy(d).cuda()
+Wh = pack(lib.epos_pack_pointwise_weights_h2, np.uint8); Wp = pack(lib.epos_pack_pointwise_weights, np.float32)
+slot = torch.zeros(_lib.AMAX_WORDS, dtype=torch.int32, device='cuda')
+_lib.check(lib.epos_absmax_f32(p(A), k, m, k, p(slot), None))
+args = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Wp), bias=None, R=None, ldr=n, C=p(C), ldc=n, M=m, N=n, K=k,
+                          relu=0, relu_in=0, sub=1, Wh=p(Wh), a_amax=p(slot))
+torch.cuda.synchronize()
+st = torch.cuda.Stream()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, stream=st):
+  rc = lib.epos_pointwise_conv_f32(ctypes.byref(args), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+msg = lib.epos_last_error().decode()
+assert rc != 0 and 'capture' in msg, (rc, msg)
+_lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))          # eager: allocates
+torch.cuda.synchronize()
+ref = a.astype(np.float64) @ w.astype(np.float64)
+assert np.abs(C.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+C.zero_()
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2, stream=st):
+  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+g2.replay(); torch.cuda.synchronize()
+assert np.abs(C.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+print('OK')
+''' % root
+  r = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0 and 'OK' in r.stdout, r.stdout + r.stderr

@@ -284,6 +284,39 @@ def test_h2_grouped_and_strided(lib):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
 
 
+def test_h2_group_with_residuals_equals_the_single_launches(lib):
+  """A group whose problems carry residuals (round 5: the library has no grouped residual
+  instantiation any more -- such a group goes out problem by problem) gives the bits of the
+  same problems launched one by one; a group that mixes pre-split and fp32 A is refused."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(5)
+  m, k = 1000, 96
+  a = rng.standard_normal((m, k)).astype(np.float32)
+  A = torch.from_numpy(a).cuda()
+  slot = _slot()
+  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+  arr = (_lib.PointwiseArgs * 2)()
+  keep, singles, grouped = [], [], []
+  for i, n in enumerate((200, 64)):
+    w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+    r = torch.from_numpy(rng.standard_normal((m, n)).astype(np.float32)).cuda()
+    Wp, Wh = _pack(lib, w), _pack(lib, w, 'h2')
+    C1, C2 = torch.zeros(m, n, device='cuda'), torch.zeros(m, n, device='cuda')
+    keep += [Wp, Wh, r]
+    kw = dict(A=_p(A), lda=k, Wp=_p(Wp), bias=None, R=_p(r), ldr=n, ldc=n, M=m, N=n, K=k,
+              relu=1, relu_in=0, sub=1, Wh=_p(Wh), a_amax=_p(slot))
+    one = _lib.PointwiseArgs(C=_p(C1), **kw)
+    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(one), None))
+    arr[i] = _lib.PointwiseArgs(C=_p(C2), **kw)
+    singles.append(C1); grouped.append(C2)
+  _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 2, None))
+  torch.cuda.synchronize()
+  for c1, c2 in zip(singles, grouped):
+    assert torch.equal(c1, c2) and float(c1.abs().max()) > 0
+  arr[1].a_presplit = 1                       # mixed kinds in one group
+  assert lib.epos_pointwise_conv_grouped_f32(arr, 2, None) != 0
+
+
 @pytest.mark.parametrize('b,h,w,cin,cout,stride,rate', [
     (2, 12, 16, 32, 64, 1, 1), (1, 9, 21, 64, 40, 1, 1), (2, 7, 5, 32, 136, 1, 1),
     (2, 15, 21, 64, 72, 2, 1), (1, 20, 28, 64, 130, 1, 2), (2, 13, 17, 32, 48, 1, 4),

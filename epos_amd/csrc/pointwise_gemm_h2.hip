@@ -91,13 +91,17 @@ constexpr int H2_EP_ROW = 132;                      // floats per staged epilogu
 // 8 KB W stage image of its 128-column tile; the A stage is the same. (Other launch shapes --
 // eight waves on a 128 x 128 tile, a 256 x 128 tile with eight waves, deeper rings -- were
 // built, bit-identical, and measured no better: DESIGN.md (e), profiles/r04, profiles/r05.)
-template <int NB> struct H2Geo {
-  static constexpr int BN = NB * 32;
+// NW = 8 with NB = 2 (EXPERIMENT, round 5): the 128 x 128 tile by EIGHT waves, 4 (rows) x 2
+// (column halves), each 32 x 64 -- with a register-lean K loop (fragments re-read IN PLACE as
+// they die) aimed at <= 128 VGPRs, so that TWO such workgroups fit a CU: four MFMA waves per
+// SIMD, three of which can cover a wave's barrier and fragment-read latency.
+template <int NB, int NW = 4> struct H2Geo {
+  static constexpr int BN = NB * 32 * (NW / 4);
   static constexpr int W_LDS = BN * 64;                    // W bytes per stage in LDS
   static constexpr int STAGE = W_LDS + H2_A_BYTES;
   static constexpr int LDS = H2_NST * STAGE;               // 81920 / 61440 (five stages)
-  static constexpr int NA = 2;                             // A pieces per wave and stage
-  static constexpr int NWP = NB / 2;                       // W pieces per wave and stage
+  static constexpr int NA = NW == 8 ? 1 : 2;               // A pieces per wave and stage
+  static constexpr int NWP = NW == 8 ? 1 : NB / 2;         // W pieces per wave and stage
   static constexpr int NP = NA + NWP;                      // LDS-DMA pieces per wave and stage
   static constexpr int EP_ROW = NB * 32 + 4;               // a wave stages its own columns
 };
@@ -264,12 +268,12 @@ __device__ __forceinline__ float vec_epilogue_h2(float* ws, const f32x16* acc,
 
 // PRESPLIT: every problem of the launch has its A operand already as fp16 pairs
 // (EposPointwiseArgs.a_presplit; the plan does not mix the two kinds in one group).
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, int NB = 4>
-__global__ __launch_bounds__(256, 2)
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, int NB = 4, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2)
 void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   static_assert(NB == 4 || NB == 2, "tile = 128 x 128 or 128 x 64");
-  using Geo = H2Geo<NB>;
-  constexpr int NW = 4;                        // waves 4 x 1: a wave owns 32 rows
+  static_assert(NW == 4 || (NW == 8 && NB == 2 && !CONV), "eight waves: 4 x 2 on a 128 x 128 tile");
+  using Geo = H2Geo<NB, NW>;
   constexpr int NST = H2_NST;
   constexpr int BM = H2_BM;
   constexpr int NP = Geo::NP;
@@ -281,7 +285,8 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wrow = wave;                       // the wave's 32-row group
+  const int wrow = NW == 8 ? (wave & 3) : wave;          // the wave's 32-row group
+  const int wcol = NW == 8 ? (wave >> 2) : 0;           //            column half (NW = 8)
   const int l31 = lane & 31, h = lane >> 5;
 
   (void)ga_;
@@ -349,7 +354,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   }
   const int m0 = tile_m * BM, n0 = tile_n * Geo::BN;
   const int tn128 = Geo::BN == 128 ? tiles_n : (tiles_n + 1) >> 1;   // packed W: 128-column images
-  const int n0w = n0;                                                   // this wave's first column
+  const int n0w = n0 + wcol * 64;                                       // this wave's first column
   const int nks = (K + H2_BK - 1) / H2_BK;
   const int cblocks = CONV ? gp->conv_cin[pi] / H2_BK : 1;   // channel blocks per tap
   const int crate = CONV ? gp->conv_rate[pi] : 1;
@@ -483,7 +488,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     for (int j = 0; j < 2; ++j)
       a_off[j] = Geo::W_LDS / 4 + (wrow * 32 + l31) * H2_BK + (((2 * h + j) ^ sw) << 2);
   }
-  const int b_off = lane * 4;   // + (cb*2 + piece) * 256 floats
+  const int b_off = lane * 4 + wcol * 1024;   // + (cb*2 + piece) * 256 floats
 
   float4 xa[2];             // raw fp32 A fragments of the NEXT stage to compute
   u32x4 bp[4][2];           // W fragments {hi, mid} per column block (NB of them live)
@@ -773,7 +778,104 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     });
     tile2(kt, stage, std::integral_constant<int, LA + 1>{}, PS{});
   };
-  if constexpr (NB == 4) {
+  // ---- NW = 8 (EXPERIMENT): a wave owns 32 rows x 64 columns (two column blocks x {acc, corr}
+  // = 64 accumulator registers) and keeps ONE set of fragments: each fragment of tile kt + 1 is
+  // read into the registers of its predecessor right behind the last MFMA that uses that one,
+  //     corr0 += ah bp01 | corr1 += ah bp11 | acc0 += ah bp00 | acc1 += ah bp10 | corr0 += am bp00 | corr1 += am bp10
+  //     bp01'            | bp11'            |                  | ah'              |                   | am', bp00', bp10'
+  // (per accumulator the order of the 128 x 128 tile: equal bits), so nothing is double
+  // buffered and the next use of every fragment is >= 2 of this wave's MFMAs away -- with four
+  // MFMA waves per SIMD that is ~250 cycles, more than an LDS read. Wait + barrier at the TOP of
+  // tile kt: tile kt + 1 is then visible; the pieces of tile kt + LA go into the stage of tile
+  // kt - 1, whose fragments every wave consumed before that barrier.
+  auto tile8 = [&](int kt, int stage, auto mode_tag, auto ps_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool PS = decltype(ps_tag)::value;
+    constexpr int LAST = LA + 1;
+    constexpr bool NEXT = MODE != LAST;
+    const int s4 = stage + LA >= NST ? stage + LA - NST : stage + LA;
+    const int s1 = stage + 1 >= NST ? stage + 1 - NST : stage + 1;
+    const float* sb = smem + s1 * (Geo::STAGE / 4);
+    u32x4 nh, nm;
+    if constexpr (NEXT) {
+      if constexpr (MODE <= 2) h2_wait_vm<(LA - 2) * NP>();
+      else h2_wait_vm<(LA - MODE) * NP>();
+      __builtin_amdgcn_s_barrier();
+      if constexpr (!PS) read_a(s1);                  // raw fp32 chunks, split behind the MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    auto split_unit = [&](auto u_tag) {
+      constexpr int u = decltype(u_tag)::value;
+      const float* x = reinterpret_cast<const float*>(&xa[u >> 1]);
+      float x0 = x[(u & 1) * 2], x1 = x[(u & 1) * 2 + 1];
+      asm volatile("" : "+v"(x0), "+v"(x1));         // anchored behind its MFMA (see tile)
+      unsigned hh, mm;
+      split_pair(x0, x1, sa, hh, mm);
+      nh[u] = hh; nm[u] = mm;
+    };
+    auto rd_b = [&](int cb, int pc) {
+      bp[cb][pc] = *reinterpret_cast<const u32x4*>(sb + b_off + (cb * 2 + pc) * 256);
+    };
+    auto rd_half = [&](u32x4& dst, int off) {        // pre-split A: the hi (off 0) or mid (2) halves
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const u32x2 v = *reinterpret_cast<const u32x2*>(sb + a_off[j] + off);
+        dst[2 * j] = v[0]; dst[2 * j + 1] = v[1];
+      }
+    };
+    auto fence = [&] { __builtin_amdgcn_sched_barrier(0); };
+    mfma_f16(ah, bp[0][1], corr[0]); fence();
+    if constexpr (MODE <= 1)
+      issue_piece(kt + LA, s4, std::integral_constant<int, 0>{}, std::integral_constant<bool, MODE == 1>{});
+    if constexpr (NEXT) rd_b(0, 1);
+    if constexpr (NEXT && !PS) split_unit(std::integral_constant<int, 0>{});
+    fence();
+    mfma_f16(ah, bp[1][1], corr[1]); fence();
+    if constexpr (MODE <= 1)
+      issue_piece(kt + LA, s4, std::integral_constant<int, 2>{}, std::integral_constant<bool, MODE == 1>{});
+    if constexpr (NEXT) rd_b(1, 1);
+    if constexpr (NEXT && !PS) split_unit(std::integral_constant<int, 1>{});
+    fence();
+    mfma_f16(ah, bp[0][0], acc[0]); fence();
+    if constexpr (NEXT && !PS) split_unit(std::integral_constant<int, 2>{});
+    fence();
+    mfma_f16(ah, bp[1][0], acc[1]); fence();
+    if constexpr (NEXT) {
+      if constexpr (PS) rd_half(ah, 0);
+      else { split_unit(std::integral_constant<int, 3>{}); ah = nh; }
+    }
+    fence();
+    mfma_f16(am, bp[0][0], corr[0]); fence();
+    mfma_f16(am, bp[1][0], corr[1]); fence();
+    if constexpr (NEXT) {
+      if constexpr (PS) rd_half(am, 2); else am = nm;
+      rd_b(0, 0);
+      rd_b(1, 0);
+    }
+    fence();
+  };
+  auto k_loop8 = [&](auto ps_tag) {
+    using PS = decltype(ps_tag);
+    using M0 = std::integral_constant<int, 0>;
+    int kt = 0;
+    for (; kt + 2 * NST - 1 < nks; kt += NST) {        // every LDS offset an immediate
+      h2_static_for(std::make_integer_sequence<int, NST>{}, [&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        tile8(kt + i, i, M0{}, PS{});
+      });
+    }
+    int stage = 0;
+    auto next = [&] { stage = stage + 1 == NST ? 0 : stage + 1; ++kt; };
+    for (; kt + LA + 1 < nks;) { tile8(kt, stage, M0{}, PS{}); next(); }
+    h2_static_for(std::make_integer_sequence<int, LA>{}, [&](auto i_tag) {
+      constexpr int m = decltype(i_tag)::value + 1;
+      if (kt + LA + 2 - m == nks) { tile8(kt, stage, std::integral_constant<int, m>{}, PS{}); next(); }
+    });
+    tile8(kt, stage, std::integral_constant<int, LA + 1>{}, PS{});
+  };
+  if constexpr (NW == 8) {
+    k_loop8(std::integral_constant<bool, PRESPLIT>{});
+  } else if constexpr (NB == 4) {
     if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{}, std::integral_constant<bool, PRESPLIT>{});
     else k_loop(std::integral_constant<int, 4>{}, std::integral_constant<bool, PRESPLIT>{});
   } else {
@@ -869,11 +971,11 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   }
 }
 
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, int NB = 4>
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, int NB = 4, int NW = 4>
 int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, NB>;
-  constexpr int lds = H2Geo<NB>::LDS;
-  static_assert(lds >= (4 * 32 * H2Geo<NB>::EP_ROW + 4) * 4, "the epilogue stages through the ring");
+  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, NB, NW>;
+  constexpr int lds = H2Geo<NB, NW>::LDS;
+  static_assert(lds >= (NW * 32 * H2Geo<NB, NW>::EP_ROW + NW) * 4, "the epilogue stages through the ring");
   static LdsAttrOnce once;
   {
     const int rc = ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), lds,
@@ -881,7 +983,7 @@ int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
     if (rc) return rc;
   }
   // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(256), lds, s, g);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(NW * 64), lds, s, g);
   return launch_status("pointwise_gemm_h2_f32");
 }
 
@@ -1132,6 +1234,22 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                        : launch_h2_tt<false, false, false, true, 2>(g, total, s);
     return res ? launch_h2_tt<true, false, false, false, 2>(g, total, s)
                : launch_h2_tt<false, false, false, false, 2>(g, total, s);
+  }
+  static const int w8 = [] {              // EXPERIMENT: eight register-lean waves per tile
+    const char* e = getenv("EPOS_H2_W8");
+    return e ? atoi(e) : 0;
+  }();
+  bool w8ok = w8 != 0;
+  for (int i = 0; i < count; ++i) w8ok = w8ok && !args[i].col_sums;
+  if (w8ok) {
+    if (single) {
+      if (ps) return res ? launch_h2_tt<true, true, false, true, 2, 8>(g, total, s)
+                         : launch_h2_tt<false, true, false, true, 2, 8>(g, total, s);
+      return res ? launch_h2_tt<true, true, false, false, 2, 8>(g, total, s)
+                 : launch_h2_tt<false, true, false, false, 2, 8>(g, total, s);
+    }
+    return ps ? launch_h2_tt<false, false, false, true, 2, 8>(g, total, s)
+              : launch_h2_tt<false, false, false, false, 2, 8>(g, total, s);
   }
   if (single) {
     if (ps) return res ? launch_h2_tt<true, true, false, true>(g, total, s)

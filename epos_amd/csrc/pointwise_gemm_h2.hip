@@ -568,8 +568,16 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   //      m >= 2: tile kt+LA+1-m is the last (five stages: 2: kt+3, 3: kt+2, 4: kt+1, 5: kt)
   // LIVE: column blocks that hold any column < N (4, or 3 for the last column tile of
   // e.g. N = 728: every wave of the workgroup then skips the same quarter of its MFMAs)
-  auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag, auto ps_tag) {
+  // PAIR (EXPERIMENT, round 5): ONE barrier per TWO K steps. 0: a barrier in every step (as
+  // always). 1: the even step of a pair -- its barrier waits for tiles kt+1 AND kt+2, and the
+  // pieces of tile kt+LA are issued BEHIND it (their stage, tile kt-1's, was read during step
+  // kt-2, after the previous barrier: only this one proves that everyone is done with it).
+  // 2: the odd step -- no wait, no barrier (tile kt+1 is visible since the even step; tile
+  // kt+LA goes into the stage of tile kt-1, read before that barrier).
+  auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag, auto ps_tag, auto pair_tag) {
+    constexpr int PAIR = decltype(pair_tag)::value;
     constexpr int MODE = decltype(mode_tag)::value;
+    static_assert(PAIR == 0 || MODE == 0, "pairs: steady-state steps only");
     constexpr int LIVE = decltype(live_tag)::value;
     constexpr bool PS = decltype(ps_tag)::value;       // A pre-split: no conversion
     constexpr int LAST = LA + 1;                       // the mode of the last tile
@@ -624,7 +632,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     using I3 = std::integral_constant<int, 3>;
     // first half: column blocks 0 and 1 interleaved (consecutive MFMAs never on the same
     // accumulator), small terms first per accumulator; the four DMA pieces ride along
-#define H2_D(i) std::integral_constant<int, ((i) < H2_NP ? (i) : -1)>{}   // the four pieces behind the first four MFMAs
+#define H2_D(i) std::integral_constant<int, (PAIR == 1 ? ((i) >= 6 && (i) < 6 + H2_NP ? (i) - 6 : -1) : ((i) < H2_NP ? (i) : -1))>{}   // the four pieces behind the first four MFMAs (PAIR 1: behind the barrier)
     step(ah, bp[0][1], corr[0], H2_D(0), N_{});
     step(ah, bp[1][1], corr[1], H2_D(1), N_{});
     step(am, bp[0][0], corr[0], H2_D(2), N_{});
@@ -636,9 +644,14 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
       // tile kt+1 have landed once at most the later tiles' pieces are outstanding
       // (of tile kt+LA: the four pieces issued above)
 #ifndef EPOS_H2_ABL_NOBAR
-      if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_NP>();
-      else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
-      __builtin_amdgcn_s_barrier();
+      if constexpr (PAIR == 1) {          // tiles kt+1, kt+2 landed: only tile kt+3 may be out
+        h2_wait_vm_lgkm0<NP>();
+        __builtin_amdgcn_s_barrier();
+      } else if constexpr (PAIR == 0) {
+        if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_NP>();
+        else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
+        __builtin_amdgcn_s_barrier();
+      }
 #endif
 #ifndef EPOS_H2_ABL_NOREAD
       if constexpr (PS) read_a_ps(s1, nh, nm); else read_a(s1);
@@ -652,13 +665,15 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
       step(ah, bp[2][1], corr[2], H2_D(6), N_{});
       step(ah, bp[3][1], corr[3], H2_D(7), I0{});
       step(am, bp[2][0], corr[2], H2_D(8), I1{});
-      step(am, bp[3][0], corr[3], N_{}, I2{});
+      step(am, bp[3][0], corr[3], H2_D(9), I2{});
       step(ah, bp[2][0], acc[2], N_{}, I3{});
       step(ah, bp[3][0], acc[3], N_{}, N_{});
     } else {
       step(ah, bp[2][1], corr[2], H2_D(6), I0{});
       step(am, bp[2][0], corr[2], H2_D(7), I1{});
       step(ah, bp[2][0], acc[2], H2_D(8), I2{});
+      if constexpr (PAIR == 1)            // three MFMAs behind the barrier, four pieces
+        issue_piece(kt + LA, s4, std::integral_constant<int, 3>{}, std::false_type{});
       if constexpr (!PS && MODE != LAST) split_unit(I3{});
     }
 #undef H2_D
@@ -674,21 +689,36 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     using LV = decltype(live_tag);
     using PS = decltype(ps_tag);
     using M0 = std::integral_constant<int, 0>;
+    using P0 = std::integral_constant<int, 0>;
     int kt = 0;
+    if (gp->pair_barriers) {                // EXPERIMENT: one barrier per two K steps
+      bool any = false;
+      for (; kt + 2 * NST + LA < nks; kt += 2 * NST) {
+        h2_static_for(std::make_integer_sequence<int, 2 * NST>{}, [&](auto i_tag) {
+          constexpr int i = decltype(i_tag)::value;
+          tile(kt + i, i % NST, M0{}, LV{}, PS{}, std::integral_constant<int, 1 + (i & 1)>{});
+        });
+        any = true;
+      }
+      if (any) {                            // back to a barrier per step: everyone is done with
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage the next step's pieces go to
+        __builtin_amdgcn_s_barrier();
+      }
+    }
     for (; kt + 2 * NST - 1 < nks; kt += NST) {        // every LDS offset an immediate
       h2_static_for(std::make_integer_sequence<int, NST>{}, [&](auto i_tag) {
         constexpr int i = decltype(i_tag)::value;
-        tile(kt + i, i, M0{}, LV{}, PS{});
+        tile(kt + i, i, M0{}, LV{}, PS{}, P0{});
       });
     }
     int stage = 0;                          // kt is a multiple of NST here
     auto next = [&] { stage = stage + 1 == NST ? 0 : stage + 1; ++kt; };
-    for (; kt + LA + 1 < nks;) { tile(kt, stage, M0{}, LV{}, PS{}); next(); }
+    for (; kt + LA + 1 < nks;) { tile(kt, stage, M0{}, LV{}, PS{}, P0{}); next(); }
     h2_static_for(std::make_integer_sequence<int, LA>{}, [&](auto i_tag) {
       constexpr int m = decltype(i_tag)::value + 1;                  // modes 1 .. LA
-      if (kt + LA + 2 - m == nks) { tile(kt, stage, std::integral_constant<int, m>{}, LV{}, PS{}); next(); }
+      if (kt + LA + 2 - m == nks) { tile(kt, stage, std::integral_constant<int, m>{}, LV{}, PS{}, P0{}); next(); }
     });
-    tile(kt, stage, std::integral_constant<int, LA + 1>{}, LV{}, PS{});
+    tile(kt, stage, std::integral_constant<int, LA + 1>{}, LV{}, PS{}, P0{});
   };
   // ---- NB = 2 (128 x 64 tile): six MFMAs per stage and wave. There is no second half to
   // read the next stage's fragments under, so the order is turned round: wait + barrier at
@@ -1217,6 +1247,8 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
   for (int i = 0; i < count; ++i) narrow = narrow && !args[i].col_sums;
   if (narrow) lay_out(64);
   g.zero_chunk = zero_chunk_dev(s);
+  static const int pairb = [] { const char* e = getenv("EPOS_H2_PAIR_BARRIERS"); return e ? atoi(e) : 0; }();
+  g.pair_barriers = pairb;
   if (!g.zero_chunk) {
     set_error("launch_grouped_h2: cannot allocate the zero chunk (first fp16-pair launch on this "
               "device during a stream capture? launch once before capturing)");

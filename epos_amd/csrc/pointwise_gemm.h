@@ -78,7 +78,6 @@ struct GroupedArgs {
   // variable its address comes through the GOT: two more dependent loads in every
   // workgroup's set-up
   const float* zero_chunk;
-  int pair_barriers;     // EXPERIMENT (fp16-pair kernel): one barrier per two K steps
 };
 
 // ---- LDS-DMA (global_load_lds_dwordx4) helpers, inline asm: hipcc neither waits for

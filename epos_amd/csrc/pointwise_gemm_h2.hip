@@ -54,7 +54,12 @@
 // of them issuing only the LDS-DMA pieces, four only MFMAs + fragment reads; bit-identical;
 // commit 374286e): SLOWER -- 344 vs 384 TFLOP/s in steady state -- one MFMA wave per SIMD
 // cannot cover the per-K-step barrier and fragment-read latency by itself, DMA issue or not
-// (profiles/r05/gemm_h2_loader_consumer_waves.txt).
+// (profiles/r05/gemm_h2_loader_consumer_waves.txt). Likewise eight register-lean waves per
+// tile (fragments re-read in place, 128 VGPRs, two workgroups = FOUR MFMA waves per SIMD;
+// commit 96bd7f9: pipe utilisation 61.7 vs 67.2 %, end to end -3.5 %) and one barrier per TWO
+// K steps (commit 417060e: +-0). All of these are bit-identical and all deliver the same
+// ~380 TFLOP/s in steady state although their pipe utilisation in CYCLES differs (62-70 %):
+// the socket sits at its 1400 W cap there and the clock gives back what the schedule gains.
 #include <string.h>
 
 #include <mutex>
@@ -91,17 +96,13 @@ constexpr int H2_EP_ROW = 132;                      // floats per staged epilogu
 // 8 KB W stage image of its 128-column tile; the A stage is the same. (Other launch shapes --
 // eight waves on a 128 x 128 tile, a 256 x 128 tile with eight waves, deeper rings -- were
 // built, bit-identical, and measured no better: DESIGN.md (e), profiles/r04, profiles/r05.)
-// NW = 8 with NB = 2 (EXPERIMENT, round 5): the 128 x 128 tile by EIGHT waves, 4 (rows) x 2
-// (column halves), each 32 x 64 -- with a register-lean K loop (fragments re-read IN PLACE as
-// they die) aimed at <= 128 VGPRs, so that TWO such workgroups fit a CU: four MFMA waves per
-// SIMD, three of which can cover a wave's barrier and fragment-read latency.
-template <int NB, int NW = 4> struct H2Geo {
-  static constexpr int BN = NB * 32 * (NW / 4);
+template <int NB> struct H2Geo {
+  static constexpr int BN = NB * 32;
   static constexpr int W_LDS = BN * 64;                    // W bytes per stage in LDS
   static constexpr int STAGE = W_LDS + H2_A_BYTES;
   static constexpr int LDS = H2_NST * STAGE;               // 81920 / 61440 (five stages)
-  static constexpr int NA = NW == 8 ? 1 : 2;               // A pieces per wave and stage
-  static constexpr int NWP = NW == 8 ? 1 : NB / 2;         // W pieces per wave and stage
+  static constexpr int NA = 2;                             // A pieces per wave and stage
+  static constexpr int NWP = NB / 2;                       // W pieces per wave and stage
   static constexpr int NP = NA + NWP;                      // LDS-DMA pieces per wave and stage
   static constexpr int EP_ROW = NB * 32 + 4;               // a wave stages its own columns
 };
@@ -268,12 +269,12 @@ __device__ __forceinline__ float vec_epilogue_h2(float* ws, const f32x16* acc,
 
 // PRESPLIT: every problem of the launch has its A operand already as fp16 pairs
 // (EposPointwiseArgs.a_presplit; the plan does not mix the two kinds in one group).
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, int NB = 4, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2)
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT, int NB = 4>
+__global__ __launch_bounds__(256, 2)
 void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   static_assert(NB == 4 || NB == 2, "tile = 128 x 128 or 128 x 64");
-  static_assert(NW == 4 || (NW == 8 && NB == 2 && !CONV), "eight waves: 4 x 2 on a 128 x 128 tile");
-  using Geo = H2Geo<NB, NW>;
+  using Geo = H2Geo<NB>;
+  constexpr int NW = 4;                        // waves 4 x 1: a wave owns 32 rows
   constexpr int NST = H2_NST;
   constexpr int BM = H2_BM;
   constexpr int NP = Geo::NP;
@@ -285,8 +286,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   const int lane = t & 63;
   const int wave = t >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wrow = NW == 8 ? (wave & 3) : wave;          // the wave's 32-row group
-  const int wcol = NW == 8 ? (wave >> 2) : 0;           //            column half (NW = 8)
+  const int wrow = wave;                       // the wave's 32-row group
   const int l31 = lane & 31, h = lane >> 5;
 
   (void)ga_;
@@ -354,7 +354,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   }
   const int m0 = tile_m * BM, n0 = tile_n * Geo::BN;
   const int tn128 = Geo::BN == 128 ? tiles_n : (tiles_n + 1) >> 1;   // packed W: 128-column images
-  const int n0w = n0 + wcol * 64;                                       // this wave's first column
+  const int n0w = n0;                                                   // this wave's first column
   const int nks = (K + H2_BK - 1) / H2_BK;
   const int cblocks = CONV ? gp->conv_cin[pi] / H2_BK : 1;   // channel blocks per tap
   const int crate = CONV ? gp->conv_rate[pi] : 1;
@@ -488,7 +488,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     for (int j = 0; j < 2; ++j)
       a_off[j] = Geo::W_LDS / 4 + (wrow * 32 + l31) * H2_BK + (((2 * h + j) ^ sw) << 2);
   }
-  const int b_off = lane * 4 + wcol * 1024;   // + (cb*2 + piece) * 256 floats
+  const int b_off = lane * 4;   // + (cb*2 + piece) * 256 floats
 
   float4 xa[2];             // raw fp32 A fragments of the NEXT stage to compute
   u32x4 bp[4][2];           // W fragments {hi, mid} per column block (NB of them live)
@@ -568,16 +568,8 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   //      m >= 2: tile kt+LA+1-m is the last (five stages: 2: kt+3, 3: kt+2, 4: kt+1, 5: kt)
   // LIVE: column blocks that hold any column < N (4, or 3 for the last column tile of
   // e.g. N = 728: every wave of the workgroup then skips the same quarter of its MFMAs)
-  // PAIR (EXPERIMENT, round 5): ONE barrier per TWO K steps. 0: a barrier in every step (as
-  // always). 1: the even step of a pair -- its barrier waits for tiles kt+1 AND kt+2, and the
-  // pieces of tile kt+LA are issued BEHIND it (their stage, tile kt-1's, was read during step
-  // kt-2, after the previous barrier: only this one proves that everyone is done with it).
-  // 2: the odd step -- no wait, no barrier (tile kt+1 is visible since the even step; tile
-  // kt+LA goes into the stage of tile kt-1, read before that barrier).
-  auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag, auto ps_tag, auto pair_tag) {
-    constexpr int PAIR = decltype(pair_tag)::value;
+  auto tile = [&](int kt, int stage, auto mode_tag, auto live_tag, auto ps_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
-    static_assert(PAIR == 0 || MODE == 0, "pairs: steady-state steps only");
     constexpr int LIVE = decltype(live_tag)::value;
     constexpr bool PS = decltype(ps_tag)::value;       // A pre-split: no conversion
     constexpr int LAST = LA + 1;                       // the mode of the last tile
@@ -632,7 +624,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     using I3 = std::integral_constant<int, 3>;
     // first half: column blocks 0 and 1 interleaved (consecutive MFMAs never on the same
     // accumulator), small terms first per accumulator; the four DMA pieces ride along
-#define H2_D(i) std::integral_constant<int, (PAIR == 1 ? ((i) >= 6 && (i) < 6 + H2_NP ? (i) - 6 : -1) : ((i) < H2_NP ? (i) : -1))>{}   // the four pieces behind the first four MFMAs (PAIR 1: behind the barrier)
+#define H2_D(i) std::integral_constant<int, ((i) < H2_NP ? (i) : -1)>{}   // the four pieces behind the first four MFMAs
     step(ah, bp[0][1], corr[0], H2_D(0), N_{});
     step(ah, bp[1][1], corr[1], H2_D(1), N_{});
     step(am, bp[0][0], corr[0], H2_D(2), N_{});
@@ -644,14 +636,9 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
       // tile kt+1 have landed once at most the later tiles' pieces are outstanding
       // (of tile kt+LA: the four pieces issued above)
 #ifndef EPOS_H2_ABL_NOBAR
-      if constexpr (PAIR == 1) {          // tiles kt+1, kt+2 landed: only tile kt+3 may be out
-        h2_wait_vm_lgkm0<NP>();
-        __builtin_amdgcn_s_barrier();
-      } else if constexpr (PAIR == 0) {
-        if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_NP>();
-        else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
-        __builtin_amdgcn_s_barrier();
-      }
+      if constexpr (MODE <= 1) h2_wait_vm_lgkm0<(LA - 2) * NP + H2_NP>();
+      else h2_wait_vm_lgkm0<(LA - MODE) * NP>();
+      __builtin_amdgcn_s_barrier();
 #endif
 #ifndef EPOS_H2_ABL_NOREAD
       if constexpr (PS) read_a_ps(s1, nh, nm); else read_a(s1);
@@ -665,15 +652,13 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
       step(ah, bp[2][1], corr[2], H2_D(6), N_{});
       step(ah, bp[3][1], corr[3], H2_D(7), I0{});
       step(am, bp[2][0], corr[2], H2_D(8), I1{});
-      step(am, bp[3][0], corr[3], H2_D(9), I2{});
+      step(am, bp[3][0], corr[3], N_{}, I2{});
       step(ah, bp[2][0], acc[2], N_{}, I3{});
       step(ah, bp[3][0], acc[3], N_{}, N_{});
     } else {
       step(ah, bp[2][1], corr[2], H2_D(6), I0{});
       step(am, bp[2][0], corr[2], H2_D(7), I1{});
       step(ah, bp[2][0], acc[2], H2_D(8), I2{});
-      if constexpr (PAIR == 1)            // three MFMAs behind the barrier, four pieces
-        issue_piece(kt + LA, s4, std::integral_constant<int, 3>{}, std::false_type{});
       if constexpr (!PS && MODE != LAST) split_unit(I3{});
     }
 #undef H2_D
@@ -689,36 +674,21 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     using LV = decltype(live_tag);
     using PS = decltype(ps_tag);
     using M0 = std::integral_constant<int, 0>;
-    using P0 = std::integral_constant<int, 0>;
     int kt = 0;
-    if (gp->pair_barriers) {                // EXPERIMENT: one barrier per two K steps
-      bool any = false;
-      for (; kt + 2 * NST + LA < nks; kt += 2 * NST) {
-        h2_static_for(std::make_integer_sequence<int, 2 * NST>{}, [&](auto i_tag) {
-          constexpr int i = decltype(i_tag)::value;
-          tile(kt + i, i % NST, M0{}, LV{}, PS{}, std::integral_constant<int, 1 + (i & 1)>{});
-        });
-        any = true;
-      }
-      if (any) {                            // back to a barrier per step: everyone is done with
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage the next step's pieces go to
-        __builtin_amdgcn_s_barrier();
-      }
-    }
     for (; kt + 2 * NST - 1 < nks; kt += NST) {        // every LDS offset an immediate
       h2_static_for(std::make_integer_sequence<int, NST>{}, [&](auto i_tag) {
         constexpr int i = decltype(i_tag)::value;
-        tile(kt + i, i, M0{}, LV{}, PS{}, P0{});
+        tile(kt + i, i, M0{}, LV{}, PS{});
       });
     }
     int stage = 0;                          // kt is a multiple of NST here
     auto next = [&] { stage = stage + 1 == NST ? 0 : stage + 1; ++kt; };
-    for (; kt + LA + 1 < nks;) { tile(kt, stage, M0{}, LV{}, PS{}, P0{}); next(); }
+    for (; kt + LA + 1 < nks;) { tile(kt, stage, M0{}, LV{}, PS{}); next(); }
     h2_static_for(std::make_integer_sequence<int, LA>{}, [&](auto i_tag) {
       constexpr int m = decltype(i_tag)::value + 1;                  // modes 1 .. LA
-      if (kt + LA + 2 - m == nks) { tile(kt, stage, std::integral_constant<int, m>{}, LV{}, PS{}, P0{}); next(); }
+      if (kt + LA + 2 - m == nks) { tile(kt, stage, std::integral_constant<int, m>{}, LV{}, PS{}); next(); }
     });
-    tile(kt, stage, std::integral_constant<int, LA + 1>{}, LV{}, PS{}, P0{});
+    tile(kt, stage, std::integral_constant<int, LA + 1>{}, LV{}, PS{});
   };
   // ---- NB = 2 (128 x 64 tile): six MFMAs per stage and wave. There is no second half to
   // read the next stage's fragments under, so the order is turned round: wait + barrier at
@@ -808,104 +778,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     });
     tile2(kt, stage, std::integral_constant<int, LA + 1>{}, PS{});
   };
-  // ---- NW = 8 (EXPERIMENT): a wave owns 32 rows x 64 columns (two column blocks x {acc, corr}
-  // = 64 accumulator registers) and keeps ONE set of fragments: each fragment of tile kt + 1 is
-  // read into the registers of its predecessor right behind the last MFMA that uses that one,
-  //     corr0 += ah bp01 | corr1 += ah bp11 | acc0 += ah bp00 | acc1 += ah bp10 | corr0 += am bp00 | corr1 += am bp10
-  //     bp01'            | bp11'            |                  | ah'              |                   | am', bp00', bp10'
-  // (per accumulator the order of the 128 x 128 tile: equal bits), so nothing is double
-  // buffered and the next use of every fragment is >= 2 of this wave's MFMAs away -- with four
-  // MFMA waves per SIMD that is ~250 cycles, more than an LDS read. Wait + barrier at the TOP of
-  // tile kt: tile kt + 1 is then visible; the pieces of tile kt + LA go into the stage of tile
-  // kt - 1, whose fragments every wave consumed before that barrier.
-  auto tile8 = [&](int kt, int stage, auto mode_tag, auto ps_tag) {
-    constexpr int MODE = decltype(mode_tag)::value;
-    constexpr bool PS = decltype(ps_tag)::value;
-    constexpr int LAST = LA + 1;
-    constexpr bool NEXT = MODE != LAST;
-    const int s4 = stage + LA >= NST ? stage + LA - NST : stage + LA;
-    const int s1 = stage + 1 >= NST ? stage + 1 - NST : stage + 1;
-    const float* sb = smem + s1 * (Geo::STAGE / 4);
-    u32x4 nh, nm;
-    if constexpr (NEXT) {
-      if constexpr (MODE <= 2) h2_wait_vm<(LA - 2) * NP>();
-      else h2_wait_vm<(LA - MODE) * NP>();
-      __builtin_amdgcn_s_barrier();
-      if constexpr (!PS) read_a(s1);                  // raw fp32 chunks, split behind the MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    auto split_unit = [&](auto u_tag) {
-      constexpr int u = decltype(u_tag)::value;
-      const float* x = reinterpret_cast<const float*>(&xa[u >> 1]);
-      float x0 = x[(u & 1) * 2], x1 = x[(u & 1) * 2 + 1];
-      asm volatile("" : "+v"(x0), "+v"(x1));         // anchored behind its MFMA (see tile)
-      unsigned hh, mm;
-      split_pair(x0, x1, sa, hh, mm);
-      nh[u] = hh; nm[u] = mm;
-    };
-    auto rd_b = [&](int cb, int pc) {
-      bp[cb][pc] = *reinterpret_cast<const u32x4*>(sb + b_off + (cb * 2 + pc) * 256);
-    };
-    auto rd_half = [&](u32x4& dst, int off) {        // pre-split A: the hi (off 0) or mid (2) halves
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const u32x2 v = *reinterpret_cast<const u32x2*>(sb + a_off[j] + off);
-        dst[2 * j] = v[0]; dst[2 * j + 1] = v[1];
-      }
-    };
-    auto fence = [&] { __builtin_amdgcn_sched_barrier(0); };
-    mfma_f16(ah, bp[0][1], corr[0]); fence();
-    if constexpr (MODE <= 1)
-      issue_piece(kt + LA, s4, std::integral_constant<int, 0>{}, std::integral_constant<bool, MODE == 1>{});
-    if constexpr (NEXT) rd_b(0, 1);
-    if constexpr (NEXT && !PS) split_unit(std::integral_constant<int, 0>{});
-    fence();
-    mfma_f16(ah, bp[1][1], corr[1]); fence();
-    if constexpr (MODE <= 1)
-      issue_piece(kt + LA, s4, std::integral_constant<int, 2>{}, std::integral_constant<bool, MODE == 1>{});
-    if constexpr (NEXT) rd_b(1, 1);
-    if constexpr (NEXT && !PS) split_unit(std::integral_constant<int, 1>{});
-    fence();
-    mfma_f16(ah, bp[0][0], acc[0]); fence();
-    if constexpr (NEXT && !PS) split_unit(std::integral_constant<int, 2>{});
-    fence();
-    mfma_f16(ah, bp[1][0], acc[1]); fence();
-    if constexpr (NEXT) {
-      if constexpr (PS) rd_half(ah, 0);
-      else { split_unit(std::integral_constant<int, 3>{}); ah = nh; }
-    }
-    fence();
-    mfma_f16(am, bp[0][0], corr[0]); fence();
-    mfma_f16(am, bp[1][0], corr[1]); fence();
-    if constexpr (NEXT) {
-      if constexpr (PS) rd_half(am, 2); else am = nm;
-      rd_b(0, 0);
-      rd_b(1, 0);
-    }
-    fence();
-  };
-  auto k_loop8 = [&](auto ps_tag) {
-    using PS = decltype(ps_tag);
-    using M0 = std::integral_constant<int, 0>;
-    int kt = 0;
-    for (; kt + 2 * NST - 1 < nks; kt += NST) {        // every LDS offset an immediate
-      h2_static_for(std::make_integer_sequence<int, NST>{}, [&](auto i_tag) {
-        constexpr int i = decltype(i_tag)::value;
-        tile8(kt + i, i, M0{}, PS{});
-      });
-    }
-    int stage = 0;
-    auto next = [&] { stage = stage + 1 == NST ? 0 : stage + 1; ++kt; };
-    for (; kt + LA + 1 < nks;) { tile8(kt, stage, M0{}, PS{}); next(); }
-    h2_static_for(std::make_integer_sequence<int, LA>{}, [&](auto i_tag) {
-      constexpr int m = decltype(i_tag)::value + 1;
-      if (kt + LA + 2 - m == nks) { tile8(kt, stage, std::integral_constant<int, m>{}, PS{}); next(); }
-    });
-    tile8(kt, stage, std::integral_constant<int, LA + 1>{}, PS{});
-  };
-  if constexpr (NW == 8) {
-    k_loop8(std::integral_constant<bool, PRESPLIT>{});
-  } else if constexpr (NB == 4) {
+  if constexpr (NB == 4) {
     if (n0 + 96 >= N) k_loop(std::integral_constant<int, 3>{}, std::integral_constant<bool, PRESPLIT>{});
     else k_loop(std::integral_constant<int, 4>{}, std::integral_constant<bool, PRESPLIT>{});
   } else {
@@ -1001,11 +874,11 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   }
 }
 
-template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, int NB = 4, int NW = 4>
+template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, int NB = 4>
 int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
-  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, NB, NW>;
-  constexpr int lds = H2Geo<NB, NW>::LDS;
-  static_assert(lds >= (NW * 32 * H2Geo<NB, NW>::EP_ROW + NW) * 4, "the epilogue stages through the ring");
+  auto kern = pointwise_gemm_h2_f32<HAS_RES, SINGLE, CONV, PRESPLIT, NB>;
+  constexpr int lds = H2Geo<NB>::LDS;
+  static_assert(lds >= (4 * 32 * H2Geo<NB>::EP_ROW + 4) * 4, "the epilogue stages through the ring");
   static LdsAttrOnce once;
   {
     const int rc = ensure_dynamic_lds(once, reinterpret_cast<const void*>(kern), lds,
@@ -1013,7 +886,7 @@ int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
     if (rc) return rc;
   }
   // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(total), dim3(NW * 64), lds, s, g);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(256), lds, s, g);
   return launch_status("pointwise_gemm_h2_f32");
 }
 
@@ -1247,8 +1120,6 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
   for (int i = 0; i < count; ++i) narrow = narrow && !args[i].col_sums;
   if (narrow) lay_out(64);
   g.zero_chunk = zero_chunk_dev(s);
-  static const int pairb = [] { const char* e = getenv("EPOS_H2_PAIR_BARRIERS"); return e ? atoi(e) : 0; }();
-  g.pair_barriers = pairb;
   if (!g.zero_chunk) {
     set_error("launch_grouped_h2: cannot allocate the zero chunk (first fp16-pair launch on this "
               "device during a stream capture? launch once before capturing)");
@@ -1266,22 +1137,6 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
                        : launch_h2_tt<false, false, false, true, 2>(g, total, s);
     return res ? launch_h2_tt<true, false, false, false, 2>(g, total, s)
                : launch_h2_tt<false, false, false, false, 2>(g, total, s);
-  }
-  static const int w8 = [] {              // EXPERIMENT: eight register-lean waves per tile
-    const char* e = getenv("EPOS_H2_W8");
-    return e ? atoi(e) : 0;
-  }();
-  bool w8ok = w8 != 0;
-  for (int i = 0; i < count; ++i) w8ok = w8ok && !args[i].col_sums;
-  if (w8ok) {
-    if (single) {
-      if (ps) return res ? launch_h2_tt<true, true, false, true, 2, 8>(g, total, s)
-                         : launch_h2_tt<false, true, false, true, 2, 8>(g, total, s);
-      return res ? launch_h2_tt<true, true, false, false, 2, 8>(g, total, s)
-                 : launch_h2_tt<false, true, false, false, 2, 8>(g, total, s);
-    }
-    return ps ? launch_h2_tt<false, false, false, true, 2, 8>(g, total, s)
-              : launch_h2_tt<false, false, false, false, 2, 8>(g, total, s);
   }
   if (single) {
     if (ps) return res ? launch_h2_tt<true, true, false, true>(g, total, s)

@@ -6,7 +6,7 @@ profiles/r05/gemm_h2_tall_tile_shapes*.txt -- and left the library again). Round
 a time on one stream, and 2 / 4 streams round robin (what a pipeline of images looks like).
 With and without pre-split A, residual epilogue for the middle-flow shape.
 
-    python tools/bench_gemm_h2_tiles.py [128x128,128x64,'8 waves']     # on the GPU box
+    python tools/bench_gemm_h2_tiles.py [128x128,128x64]     # on the GPU box
 (EPOS_HIP_LIB=<variant> selects another build of the library)
 """
 import ctypes, os, sys

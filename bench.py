@@ -83,6 +83,11 @@ def workload_name(args, B):
   return 'custom, batch %d per GPU' % B
 
 
+def planted_suffix(args):
+  return (' planted (known poses rendered into the heads of the target objects, %d %% outlier '
+          'pixels, 1 px noise)' % round(100 * args.planted_outliers)) if args.planted_poses else ''
+
+
 def parse_args():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -108,6 +113,24 @@ def parse_args():
                   choices=['xception_65', 'resnet_v1_101_beta'],
                   help='backbone (the headline workload C2 is xception_65; '
                        'resnet_v1_101_beta with --num-objs 15 --batch-per-gpu 8 is C5)')
+  ap.add_argument('--weights', default='init', choices=['init', 'heavy-tailed'],
+                  help='"init": the reference\'s initialisers; "heavy-tailed": the same checkpoint '
+                       'with the tails of a trained network in every GEMM matrix (1 %% of the '
+                       'weights scaled by 1e-10, every fourth column log-normal sigma 3: '
+                       'weights.heavy_tailed) -- same shapes, same flops; it must run on the same '
+                       'kernels at the same rate (config.h2_layers / h2_refused)')
+  ap.add_argument('--planted-poses', action='store_true',
+                  help='the fitting stage gets EPOS-like work: after the network ran, the head '
+                       'values of every target object are overwritten (three scatter launches '
+                       'per image, inside the timed step) by a rendering of the object at a '
+                       'KNOWN pose -- object confidence, two live fragments per pixel, '
+                       'fragment-local 3D coordinates with 1 px-equivalent noise, and '
+                       '--planted-outliers of the masked pixels replaced by outliers '
+                       '(synthetic.planted_scene). The CNN does its full work; correspondences '
+                       'and PnP-RANSAC see thousands of inliers per object instead of ~30, and '
+                       'the recovered poses are checked against the planted ones')
+  ap.add_argument('--planted-outliers', type=float, default=0.5,
+                  help='fraction of outlier pixels per planted object (0.3 / 0.5 / 0.7)')
   ap.add_argument('--no-calibrate', action='store_true',
                   help='keep the raw random-init logits layers (every confidence '
                        'then stays below tau_a and corr/RANSAC get no work)')
@@ -218,7 +241,7 @@ def measure_traffic_live(args, timeout=240):
            '--num-objs', str(args.num_objs), '--num-frags', str(args.num_frags),
            '--objs-per-image', str(args.objs_per_image), '--model-variant',
            args.model_variant, '--no-cpu-baseline', '--no-roofline', '--no-stage-times',
-           '--traffic', 'off']
+           '--traffic', 'off', '--weights', args.weights]
     if args.sparse_heads:
       cmd.append('--sparse-heads')
     env = dict(os.environ, TMPDIR='/tmp', EPOS_BENCH_CHILD='1')
@@ -444,6 +467,8 @@ def main():
   # that the correspondence / RANSAC stages see YCB-V-like amounts of work.
   ckpt = weights.random_init(args.model_variant, num_objs=args.num_objs,
                              num_frags=args.num_frags, seed=0, randomize_bn=True)
+  if args.weights == 'heavy-tailed':
+    ckpt = weights.heavy_tailed(ckpt, seed=0)
   from epos_amd import model
   mo = model.ModelOptions(
       model.get_outputs_to_num_channels(args.num_objs, args.num_frags),
@@ -480,6 +505,41 @@ def main():
            synthetic.targets(i, args.num_objs, args.objs_per_image)} for i in idx]
     pool.append((torch.from_numpy(imgs).to(dev), tg, idx))
   Ks = np.tile(synthetic.YCBV_K, (B, 1, 1))
+  # --planted-poses: per pool entry, the rendered head values of its target objects (device
+  # resident like the frames) and the poses they were rendered from
+  plants = None
+  if args.planted_poses:
+    if args.sparse_heads:
+      raise SystemExit('--planted-poses writes the dense head buffers; not with --sparse-heads')
+    plants = []
+    for imgs_, tg, idx in pool:
+      scenes = [synthetic.planted_scene(i, store, tg[b], synthetic.YCBV_K, pipe.net.out_h,
+                                        pipe.net.out_w, args.num_objs, args.num_frags,
+                                        outlier_frac=args.planted_outliers, image_in_batch=b)
+                for b, i in enumerate(idx)]
+      dv = {}
+      for key in ('obj', 'frag', 'loc'):
+        off = np.concatenate([sc[key][0] for sc in scenes])
+        val = np.concatenate([sc[key][1].reshape(len(sc[key][0]), -1) for sc in scenes])
+        dv[key] = (torch.from_numpy(off).to(dev), torch.from_numpy(np.ascontiguousarray(val)).to(dev),
+                   int(val.shape[1]))
+      plants.append({'dev': dv, 'scenes': scenes})
+
+  def planter(j):
+    """after_net hook of pool entry j: three scatter launches on the pipeline's stream."""
+    if plants is None:
+      return None
+    dv = plants[j]['dev']
+
+    def plant(p):
+      st = ctypes.c_void_p(p.stream.cuda_stream)
+      for key, name in (('obj', weights.PRED_OBJ_CONF), ('frag', weights.PRED_FRAG_CONF),
+                        ('loc', weights.PRED_FRAG_LOC)):
+        off, val, width = dv[key]
+        _lib.check(lib.epos_scatter_blocks_f32(
+            ctypes.c_void_p(p.net.logits[name].data_ptr()), ctypes.c_void_p(off.data_ptr()),
+            ctypes.c_void_p(val.data_ptr()), off.numel(), width, st), 'scatter_blocks')
+    return plant
   lib = _lib.load()
   clk = torch.zeros((64, 2), dtype=torch.int64, device=dev)
   clk_stream = None      # created after the timed region (an extra stream changes
@@ -499,7 +559,7 @@ def main():
       if len(inflight) == d:
         local += inflight.pop(0).collect()[0]
       imgs, tg, idx = pool[i % n_pool]
-      p.launch(imgs, Ks, tg, image_ids=idx, seed=i)
+      p.launch(imgs, Ks, tg, image_ids=idx, seed=i, after_net=planter(i % n_pool))
       inflight.append(p)
       if probe:
         _lib.check(lib.epos_clock_probe(
@@ -517,7 +577,7 @@ def main():
   # would be captured inside the timed region).
   for j in range(depth):
     imgs, tg, idx = pool[j % n_pool]
-    pipes[j].launch(imgs, Ks, tg, image_ids=idx, seed=0)
+    pipes[j].launch(imgs, Ks, tg, image_ids=idx, seed=0, after_net=planter(j % n_pool))
     pipes[j].collect()
   torch.cuda.synchronize()
   def timed_regions(first):
@@ -542,7 +602,7 @@ def main():
   elapsed = sum(region_s) / repeats           # seconds per region of --steps steps
 
   # correspondence statistics of the last step (work actually done by corr/RANSAC)
-  totals = pipes[(args.warmup + args.steps - 1) % depth].last_totals
+  totals = pipes[(args.warmup + repeats * args.steps - 1) % depth].last_totals
   images = args.steps * B * world
   value = images / elapsed
   result = {
@@ -561,7 +621,7 @@ def main():
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
       'dtype': 'f32', 'data': 'synthetic',
       'config': {
-          'workload': workload_name(args, B) +
+          'workload': workload_name(args, B) + planted_suffix(args) +
                       ': synthetic %dx%d RGB, %s random-init ' % (
                           args.width, args.height, args.model_variant) +
                       '(reference initialisers, randomised BN statistics, logits '
@@ -593,6 +653,11 @@ def main():
           'rccl_ranks_seen': (torch.distributed.get_world_size()
                               if torch.distributed.is_initialized() else 1),
           'hip_graph': not args.no_graph, 'pipeline_depth': depth,
+          'weights': args.weights,
+          # which kernel every GEMM layer of the plan runs on: fp16-pair ("h2") layers and
+          # layers whose weight matrix the fp16-pair packer refused (-> bf16 x 6 kernel)
+          'h2_layers': len(pipe.net.h2_layers), 'h2_refused': len(pipe.net.h2_refused),
+          'h2_refused_names': list(pipe.net.h2_refused)[:8],
           'heads': 'sparse (target objects only)' if args.sparse_heads else 'dense',
           'fitting_method': args.fitting_method,
           'corr_per_slot_last_step': [int(x) for x in totals[:, 1]],
@@ -600,6 +665,38 @@ def main():
           'algorithmic_gflop_per_image': round(pipe.net.flops / B / 1e9, 1),
       },
   }
+  # --planted-poses: the poses that come back are the planted ones (every pool frame once more
+  # through pipes[0], outside the timed region): < 1 degree, < 5 mm
+  if plants is not None:
+    rot, tr, n_gt, n_ok, inl = [], [], 0, 0, []
+    for j, (imgs, tg, idx) in enumerate(pool):
+      est, _ = pipes[0].process_batch(imgs, Ks, tg, image_ids=idx, seed=1000 + j,
+                                      after_net=planter(j))
+      for b, sc in enumerate(plants[j]['scenes']):
+        inl += [2 * (m - o_) for m, o_ in sc['stats'].values()]
+        for obj_id, R_gt, t_gt in sc['poses']:
+          n_gt += 1
+          cand = [synthetic.pose_errors(e['R'], e['t'], R_gt, t_gt) for e in est
+                  if e['im_id'] == idx[b] and e['obj_id'] == obj_id]
+          if cand:
+            best = min(cand, key=lambda c: c[0] + c[1])
+            rot.append(best[0]); tr.append(best[1])
+            n_ok += int(best[0] < 1.0 and best[1] < 5.0)
+    result['planted'] = {
+        'outlier_pixel_fraction': args.planted_outliers, 'noise_px': 1.0,
+        'planted_poses': n_gt, 'recovered_within_1deg_5mm': n_ok,
+        'rot_err_deg_median': round(float(np.median(rot)), 4) if rot else None,
+        'rot_err_deg_max': round(float(np.max(rot)), 4) if rot else None,
+        'trans_err_mm_median': round(float(np.median(tr)), 4) if tr else None,
+        'trans_err_mm_max': round(float(np.max(tr)), 4) if tr else None,
+        'inlier_correspondences_per_object_mean': round(float(np.mean(inl)), 1) if inl else 0,
+        'ok': bool(n_gt and n_ok == n_gt),
+        'how': 'after the network ran, epos_scatter_blocks_f32 overwrites pred_obj_conf / '
+               'pred_frag_conf / pred_frag_loc of the target objects with a rendering of each '
+               'object at a known pose (ray-cast ellipsoid of the synthetic model store; two '
+               'live fragments per pixel; 3D noise of 1 px of reprojection; the given fraction '
+               'of masked pixels turned into outliers); three launches per step inside the '
+               'timed region; the check runs every pool frame once more after it'}
   # Comparability: what a step is made of, at the top level of the line
   fitp = pipe.fit
   result['batch_per_gpu'] = B
@@ -686,7 +783,8 @@ def main():
     stage = {}
     for i in range(k):
       imgs, tg, idx = pool[i % n_pool]
-      _, rt = pipes[0].process_batch(imgs, Ks, tg, image_ids=idx, seed=i, timing=True)
+      _, rt = pipes[0].process_batch(imgs, Ks, tg, image_ids=idx, seed=i, timing=True,
+                                     after_net=planter(i % n_pool))
       for name, v in rt.items():
         stage[name] = stage.get(name, 0.0) + v * 1e3 / k
     serial = {'images_per_sec': round(k * B * world / dt, 2),

@@ -171,6 +171,8 @@ SYMBOLS = {
     'epos_add_relu_f32': (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, vp]),
     'epos_softmax_groups_f32': (ctypes.c_int,
                                 [vp, ctypes.c_int64, ctypes.c_int, vp]),
+    'epos_u8_to_f32': (ctypes.c_int, [vp, vp, ctypes.c_int64, vp]),
+    'epos_scatter_blocks_f32': (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int, vp]),
     'epos_argmax_i64': (ctypes.c_int, [
         vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int, vp]),
     'epos_softmax_slots_f32': (ctypes.c_int, [

@@ -527,6 +527,40 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* X, int64_t ldx
   labels[i] = arg;
 }
 
+// Sparse update of a device tensor from host-prepared data: block b of `width` floats goes to
+// dst + offsets[b]. (bench.py --planted-poses writes rendered head values for the target
+// objects over the network's outputs with it -- three launches per image.)
+__global__ __launch_bounds__(256) void scatter_blocks_kernel(float* __restrict__ dst,
+                                                             const int64_t* __restrict__ offsets,
+                                                             const float* __restrict__ src,
+                                                             int64_t total, int width) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / width;
+  dst[offsets[b] + (i - b * width)] = src[i];
+}
+
+// Decoded frames -> the network's input tensor: tf.cast(decode_image(...), tf.float32)
+// (datagen.py:435-436) on the device, so that a frame crosses PCIe as 1 byte per value
+// (0.92 MB instead of 3.7 MB at 640 x 480). 16 values per thread: one dwordx4 load, four
+// float4 stores; exact (every uint8 is an fp32 value).
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ X,
+                                                        float* __restrict__ Y, int64_t n) {
+  const int64_t i = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 16;
+  if (i >= n) return;
+  if (i + 16 <= n) {
+    const uint4 v = *reinterpret_cast<const uint4*>(X + i);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      reinterpret_cast<float4*>(Y + i)[q] = make_float4(
+          static_cast<float>(w[q] & 0xffu), static_cast<float>((w[q] >> 8) & 0xffu),
+          static_cast<float>((w[q] >> 16) & 0xffu), static_cast<float>(w[q] >> 24));
+  } else {
+    for (int64_t j = i; j < n; ++j) Y[j] = static_cast<float>(X[j]);
+  }
+}
+
 // --------------------------------------------------------------------------
 // ResNet-v1-beta helpers (BASELINE config C5): 3x3 stride-2 'SAME' max pool
 // (net_resnet_v1_beta.py:190), spatial subsampling (slim resnet_utils.subsample,
@@ -832,6 +866,27 @@ extern "C" int epos_argmax_i64(const float* X, int64_t ldx, int64_t* labels,
   hipLaunchKernelGGL(argmax_kernel, dim3(blocks_for(P, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), X, ldx, labels, P, C);
   return launch_status("argmax_kernel");
+}
+
+extern "C" int epos_scatter_blocks_f32(float* dst, const int64_t* offsets, const float* src,
+                                       int64_t n_blocks, int width, void* stream) {
+  EPOS_REQUIRE(n_blocks >= 0 && width > 0, "bad sizes");
+  if (n_blocks == 0) return EPOS_OK;
+  EPOS_REQUIRE(dst && offsets && src, "null pointer");
+  const int64_t total = n_blocks * width;
+  hipLaunchKernelGGL(scatter_blocks_kernel, dim3(blocks_for(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), dst, offsets, src, total, width);
+  return launch_status("scatter_blocks_kernel");
+}
+
+extern "C" int epos_u8_to_f32(const uint8_t* X, float* Y, int64_t n, void* stream) {
+  EPOS_REQUIRE(X && Y, "null pointer");
+  EPOS_REQUIRE(reinterpret_cast<uintptr_t>(X) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(Y) % 16 == 0, "16-byte aligned buffers");
+  if (n == 0) return EPOS_OK;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(blocks_for((n + 15) / 16, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), X, Y, n);
+  return launch_status("u8_to_f32_kernel");
 }
 
 extern "C" int epos_maxpool3x3_s2_f32(const float* X, int64_t ldx, float* Y,

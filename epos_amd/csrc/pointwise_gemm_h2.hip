@@ -18,8 +18,10 @@
 //
 // What fp16 costs is exponent range (5 bits), so both operands are scaled by powers of two:
 //   * W per output column on the host (epos_pack_pointwise_weights_h2: column maximum into
-//     [2^14, 2^15); a matrix with a weight outside the ~2^27 window below its column maximum
-//     is REFUSED there and the layer keeps the bf16 x 6 kernel);
+//     [2^14, 2^15); weights down to 2^-28 of their column's maximum keep full precision,
+//     smaller ones degrade gracefully -- absolute error <= 2^-50 x column maximum -- exactly
+//     like the activation side below. Only Inf / NaN weights and columns whose scale leaves
+//     the fp32 exponent range are refused; such a layer keeps the bf16 x 6 kernel);
 //   * A per tensor, at run time, from an upper bound of max|A| that the producers of A
 //     maintain in device memory (EposPointwiseArgs.a_amax: "absmax slots", atomic max in the
 //     GEMM epilogues; for a depthwise output the bound follows from the depthwise input's
@@ -1240,6 +1242,15 @@ extern "C" int64_t epos_pack_pointwise_weights_h2(const float* w_kn, int K, int 
     if (e > 100 || e < -100) ok = false;
     scale[n] = ldexpf(1.f, e);
   }
+  // Every finite weight is representable (round 6; until round 5 a weight more than ~2^27
+  // below its column's maximum made the packer refuse the whole matrix): with the column
+  // maximum in [2^14, 2^15) a scaled weight t is reproduced to
+  //     |hi + mid * 2^-11 - t| <= max(2^-22 |t|, 2^-36)
+  // -- full precision down to |t| = 2^-14 (2^-28..2^-29 of the column maximum), and below that
+  // hi / mid are fp16 subnormals (the matrix pipe does not flush them) on an absolute grid of
+  // 2^-35: an error of at most 2^-50 of the column maximum, which is below the fp32 rounding
+  // of any sum the column's larger weights take part in -- the same graceful degradation as
+  // on the activation side. The loop below is the packer's self-check of that bound.
   for (int64_t n = 0; ok && n < N; ++n)
     for (int64_t k = 0; k < K; ++k) {
       const float w = w_kn[k * static_cast<int64_t>(N) + n];
@@ -1247,8 +1258,9 @@ extern "C" int64_t epos_pack_pointwise_weights_h2(const float* w_kn, int K, int 
       const float t = w * scale[n];
       const float hi = f16_to_f32(f32_to_f16_rne(t));
       const float mid = f16_to_f32(f32_to_f16_rne((t - hi) * 2048.f));
-      const float err = fabsf((hi + mid * (1.f / 2048.f)) - t);   // exact: both on t's grid
-      if (!(err <= fabsf(t) * 0x1p-22f)) { ok = false; break; }
+      const double err = fabs((static_cast<double>(hi) + static_cast<double>(mid) / 2048.0) - t);
+      const double tol = fmax(fabs(static_cast<double>(t)) * 0x1p-22, 0x1p-36);
+      if (!(err <= tol)) { ok = false; break; }
     }
   if (!ok) { free(scale); return 0; }
   if (!dst) { free(scale); return total; }

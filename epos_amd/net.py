@@ -693,6 +693,7 @@ class EposNet(object):
   def _build_plan(self):
     B, H, Wd = self.B, self.H, self.W
     self.images = self._empty(B, H, Wd, 3)
+    self._images_u8 = None          # device staging for uint8 frames (set_images)
     self._set_expr(self.images, 'input')
     lib0 = self.lib
 
@@ -1031,9 +1032,22 @@ class EposNet(object):
     return flops
 
   def set_images(self, images):
-    """images: float32 [B,H,W,3] in [0,255] (host numpy or device tensor)."""
+    """images: [B,H,W,3] in [0,255] (host numpy or device tensor), float32 -- or uint8 as the
+    decoder delivers them (datagen.py:435-436 casts to float32 right behind decode_image; here
+    the bytes are uploaded and cast on the device, epos_u8_to_f32). Enqueued on the current
+    stream; a pinned host tensor is uploaded without blocking the host."""
     t = torch.as_tensor(images)
+    if t.dtype == torch.uint8:
+      n = self.B * self.H * self.W * 3
+      if self._images_u8 is None:
+        self._images_u8 = torch.empty(n, dtype=torch.uint8, device=self.dev)
+      self._images_u8.copy_(t.reshape(-1), non_blocking=True)
+      _lib.check(self.lib.epos_u8_to_f32(_ptr(self._images_u8), _ptr(self.images), n,
+                                         self._stream()), 'u8_to_f32')
+      return
     if t.dtype != torch.float32:
+      if t.is_cuda:
+        raise TypeError('device images must be float32 or uint8, got %s' % t.dtype)
       t = t.float()
     self.images.copy_(t.reshape(self.B, self.H, self.W, 3), non_blocking=True)
 

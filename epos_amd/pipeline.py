@@ -199,12 +199,14 @@ class EposPipeline(object):
     return slots, wants
 
   def launch(self, images, Ks, targets, task_type=LOCALIZATION, image_ids=None,
-             scene_ids=None, seed=0, timing=False):
+             scene_ids=None, seed=0, timing=False, after_net=None):
     """Enqueues one batch on this pipeline's stream -- network, correspondences,
     PnP-RANSAC and the single device->host copy of the results -- and returns
     without synchronising. ``collect()`` waits for it and builds the pose list.
     Two pipelines used alternately overlap one batch's (latency-bound) fitting
-    tail with the next batch's network."""
+    tail with the next batch's network. after_net: optional callable(pipeline), invoked on
+    the pipeline's stream between the network and the correspondence stage (bench.py
+    --planted-poses overwrites head values there)."""
     if self._pending is not None:
       raise _lib.EposError('launch() called twice without collect()')
     B = self.B
@@ -241,6 +243,8 @@ class EposPipeline(object):
           self.head_flops = self.net.run_sparse_heads(slots, self.corr.slots)
           if timing:
             self._ev[1].record()
+        if after_net is not None:
+          after_net(self)
         self.corr.count(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
                         self.tau_a, self.tau_b)
         self.corr.fill(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
@@ -336,9 +340,9 @@ class EposPipeline(object):
     return poses_out, run_times
 
   def process_batch(self, images, Ks, targets, task_type=LOCALIZATION,
-                    image_ids=None, scene_ids=None, seed=0, timing=False):
+                    image_ids=None, scene_ids=None, seed=0, timing=False, after_net=None):
     """images f32 [B,H,W,3]; Ks [B,3,3]; targets per image {obj_id: count}.
     Returns (poses, run_times) like process_image (infer.py:348-554)."""
     self.launch(images, Ks, targets, task_type, image_ids, scene_ids, seed,
-                timing)
+                timing, after_net)
     return self.collect()

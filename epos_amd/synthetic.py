@@ -15,8 +15,10 @@ class ModelStore(object):
     rng = np.random.RandomState(seed)
     self.dp_model = {'obj_ids': list(range(1, num_objs + 1))}
     self.frag_centers, self.frag_sizes = {}, {}
+    self.radii = {}                 # the ellipsoid the fragment centres lie on (planted scenes)
     for o in self.dp_model['obj_ids']:
       radii = rng.uniform(30, 80, 3)
+      self.radii[o] = radii
       d = rng.standard_normal((num_frags, 3))
       self.frag_centers[o] = d / np.linalg.norm(d, axis=1, keepdims=True) * radii
       self.frag_sizes[o] = rng.uniform(5, 40, num_frags)
@@ -60,3 +62,123 @@ def calibrate_logits(ckpt, decoder_features, std_obj=2.0, std_frag=3.0,
     ckpt['logits/%s/weights' % name] = w.astype(np.float32).reshape(1, 1, 256, -1)
     ckpt['logits/%s/biases' % name] = (-(mu @ w)).astype(np.float32)
   return ckpt
+
+
+# ---------------------------------------------------------------------------------------
+# Planted scenes (bench.py --planted-poses): with random-init heads the
+# accepted poses of the benchmark have ~30 inliers among ~5000 correspondences, so the local
+# optimisation / graph-cut / refit stages of the fitting run on almost nothing. A planted
+# scene puts every target object at a KNOWN pose, renders its visible surface into the three
+# heads at the decoder resolution -- object confidence, a fragment distribution with two live
+# fragments per pixel (many-to-many, as EPOS predicts them), fragment-local 3D coordinates with
+# sigma = noise_px pixels of reprojection noise -- and replaces a fraction of the masked pixels
+# by outliers (random fragment, random coordinates): SURVEY.md 8(d)'s RANSAC recipe carried
+# through the heads. The network still does its full work; the rendered values overwrite its
+# outputs for the target objects between the network and the correspondence stage.
+# ---------------------------------------------------------------------------------------
+def _random_rotation(rng):
+  q = rng.standard_normal(4)
+  q /= np.linalg.norm(q)
+  w, x, y, z = q
+  return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def planted_scene(index, store, targets, K, out_h, out_w, num_objs, num_frags, stride=4,
+                  outlier_frac=0.5, noise_px=1.0, image_in_batch=0, depth_mm=(450.0, 900.0)):
+  """Renders the target objects of frame ``index`` (targets: {obj_id: instances}) at random
+  known poses into head updates for image ``image_in_batch`` of a batch.
+
+  Returns dict(
+    poses    = [(obj_id, R f64[3,3], t f64[3,1]), ...]            the planted ground truth
+    obj      = (offsets i64[n], values f32[n])          into pred_obj_conf [B,h,w,O+1], width 1
+    frag     = (offsets i64[m], values f32[m,F])        into pred_frag_conf [B,h,w,O,F]
+    loc      = (offsets i64[m], values f32[m,3F])       into pred_frag_loc  [B,h,w,O,F,3]
+    stats    = {obj_id: (masked pixels, outlier pixels)})
+  Every pixel of the target objects' confidence channels is written (0 outside the masks), so
+  the correspondences of a planted object come from its rendering alone."""
+  rng = np.random.RandomState(9176 * index + 5)
+  P, O, F = out_h * out_w, num_objs, num_frags
+  Kinv = np.linalg.inv(K)
+  v, u = np.mgrid[0:out_h, 0:out_w]
+  # pixel centres in input-image coordinates (misc.py:14-26: (idx + 0.5) * stride)
+  rays = (Kinv @ np.stack([(u.ravel() + 0.5) * stride, (v.ravel() + 0.5) * stride,
+                           np.ones(P)])).T                            # [P,3], z = 1
+  W_in, H_in = out_w * stride, out_h * stride
+  poses, stats = [], {}
+  obj_off, obj_val, blk_px, blk_obj, blk_conf, blk_loc = [], [], [], [], [], []
+  for obj_id in sorted(targets):
+    r = np.asarray(store.radii[obj_id], np.float64)
+    centers = np.asarray(store.frag_centers[obj_id], np.float64)
+    sizes = np.asarray(store.frag_sizes[obj_id], np.float64)
+    depth = np.full(P, np.inf)
+    X = np.zeros((P, 3))
+    for _ in range(int(targets[obj_id])):
+      R = _random_rotation(rng)
+      tz = rng.uniform(*depth_mm)
+      px = rng.uniform(0.2, 0.8) * W_in
+      py = rng.uniform(0.2, 0.8) * H_in
+      t = (Kinv @ np.array([px, py, 1.0])) * tz
+      poses.append((obj_id, R, t.reshape(3, 1)))
+      # ray / ellipsoid intersection in the object frame: |(o + s d) / r| = 1
+      o = (-R.T @ t) / r
+      d = (rays @ R) / r                       # rows: R^T ray
+      a = (d * d).sum(1)
+      b = 2 * (d @ o)
+      c = o @ o - 1.0
+      disc = b * b - 4 * a * c
+      hit = disc > 0
+      s = np.where(hit, (-b - np.sqrt(np.where(hit, disc, 0))) / (2 * a), np.inf)
+      hit &= (s > 0) & (s < depth)
+      Xo = (rays[hit] * s[hit, None] - t) @ R             # R^T (s ray - t), object frame
+      depth[hit] = s[hit]
+      X[hit] = Xo
+    mask = np.isfinite(depth)
+    idx = np.nonzero(mask)[0]
+    n = idx.size
+    # reprojection noise of noise_px input pixels: sigma_mm = noise_px * z / f
+    sigma = noise_px * depth[idx] / K[0, 0]
+    Xn = X[idx] + rng.standard_normal((n, 3)) * sigma[:, None]
+    d2 = ((Xn[:, None, :] - centers[None]) ** 2).sum(2)
+    order = np.argsort(d2, axis=1)
+    f1, f2 = order[:, 0].copy(), order[:, 1].copy()
+    loc1 = (Xn - centers[f1]) / sizes[f1, None]
+    loc2 = (Xn - centers[f2]) / sizes[f2, None]
+    out = rng.uniform(size=n) < outlier_frac
+    no = int(out.sum())
+    f1[out] = rng.randint(0, F, no)
+    f2[out] = (f1[out] + 1 + rng.randint(0, F - 1, no)) % F
+    loc1[out] = rng.uniform(-1.5, 1.5, (no, 3))
+    loc2[out] = rng.uniform(-1.5, 1.5, (no, 3))
+    conf = np.full((n, F), 0.10 / (F - 2), np.float32)
+    conf[np.arange(n), f1] = 0.55
+    conf[np.arange(n), f2] = 0.35                        # > 0.5 x 0.55: a second correspondence
+    loc = np.zeros((n, F, 3), np.float32)
+    loc[np.arange(n), f1] = loc1
+    loc[np.arange(n), f2] = loc2
+    base = image_in_batch * P
+    obj_off.append((base + np.arange(P)) * (O + 1) + obj_id)
+    obj_val.append(np.where(mask, np.float32(0.9), np.float32(0.0)))
+    blk_px.append(base + idx)
+    blk_obj.append(np.full(n, obj_id - 1))
+    blk_conf.append(conf)
+    blk_loc.append(loc.reshape(n, F * 3))
+    stats[obj_id] = (int(n), no)
+  cat = lambda xs, dt: (np.concatenate(xs).astype(dt) if xs else np.zeros((0,), dt))  # noqa: E731
+  pxs, objs = cat(blk_px, np.int64), cat(blk_obj, np.int64)
+  blocks = pxs * O + objs
+  return {
+      'poses': poses, 'stats': stats,
+      'obj': (cat(obj_off, np.int64), cat(obj_val, np.float32)),
+      'frag': (blocks * F, np.concatenate(blk_conf) if blk_conf else np.zeros((0, F), np.float32)),
+      'loc': (blocks * F * 3,
+              np.concatenate(blk_loc) if blk_loc else np.zeros((0, 3 * F), np.float32)),
+  }
+
+
+def pose_errors(R, t, R_gt, t_gt):
+  """(rotation error in degrees, translation error in mm)."""
+  c = (np.trace(R_gt.T @ R) - 1.0) / 2.0
+  return float(np.degrees(np.arccos(np.clip(c, -1.0, 1.0)))), float(np.linalg.norm(
+      np.asarray(t).reshape(3) - np.asarray(t_gt).reshape(3)))

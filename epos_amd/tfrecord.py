@@ -72,6 +72,14 @@ def read_records(path, verify_crc=False):
       yield data
 
 
+def scan_records(path, verify_crc=False):
+  """Yields (file offset of the record's data, data) for every record of a .tfrecord file."""
+  off = 0
+  for data in read_records(path, verify_crc):
+    yield off + 12, data
+    off += 12 + len(data) + 4
+
+
 def write_records(path, records):
   with open(path, 'wb') as f:
     for data in records:
@@ -163,6 +171,54 @@ def parse_example(data):
       if key is not None:
         feats[key] = _parse_feature(value)
   return feats
+
+
+def locate_bytes_feature(data, key):
+  """(offset, length) of the FIRST bytes value of feature ``key`` inside the serialized
+  Example ``data`` -- positional walk of the same messages parse_example reads (Example{1:
+  Features{1: map entry{1: key, 2: Feature{1: BytesList{1: bytes}}}}}), so that a decoder
+  thread can read an encoded image straight from the file (epos_amd/frames.py) without
+  parsing the record again. None if the key is absent or not a bytes feature."""
+  want = key.encode('utf-8') if isinstance(key, str) else key
+
+  def walk(start, end):
+    pos = start
+    while pos < end:
+      tag, pos = _varint(data, pos)
+      num, wt = tag >> 3, tag & 7
+      if wt == 0:
+        _, pos = _varint(data, pos)
+      elif wt == 1:
+        pos += 8
+      elif wt == 5:
+        pos += 4
+      elif wt == 2:
+        ln, pos = _varint(data, pos)
+        yield num, pos, pos + ln
+        pos += ln
+      else:
+        raise ValueError('unsupported protobuf wire type %d' % wt)
+  for num, fs, fe in walk(0, len(data)):
+    if num != 1:
+      continue
+    for fnum, es, ee in walk(fs, fe):
+      if fnum != 1:
+        continue
+      k, val = None, None
+      for n, a, b in walk(es, ee):
+        if n == 1:
+          k = bytes(data[a:b])
+        elif n == 2:
+          val = (a, b)
+      if k != want or val is None:
+        continue
+      for n, a, b in walk(*val):
+        if n == 1:                                   # BytesList
+          for m, c, d in walk(a, b):
+            if m == 1:
+              return c, d - c
+      return None
+  return None
 
 
 def _enc_varint(x):
@@ -266,24 +322,25 @@ def crop_offsets(max_offset_h, max_offset_w, crop_seed, scene_id, im_id):
   return off_h, off_w
 
 
-def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
-                  min_visib_fract=0.1, crop_seed=0, crop_offset=None):
-  """One parsed Example -> the inference sample of datagen.py:424-476,545-575:
-  dict(scene_id, im_id, image_path, image f32[crop_h, crop_w, 3], K f64[3,3],
-  gt_obj_ids list, crop_offset (h, w)). crop_size = (width, height) as the reference
-  consumes it (datagen.py:448-449). A frame larger than the crop is cropped at a
-  random offset (datagen.py:451-455, see crop_offsets; ``crop_offset=(h, w)`` fixes
-  it) and the principal point moves with it (datagen.py:465-466)."""
-  from PIL import Image
-  im = np.asarray(Image.open(io.BytesIO(feats['image/encoded'][0])).convert('RGB'),
-                  dtype=np.float32)
-  h_orig = int(_scalar(feats, 'image/height', im.shape[0]))
-  w_orig = int(_scalar(feats, 'image/width', im.shape[1]))
+def sample_meta(feats, crop_size, max_height_before_crop, obj_ids=None,
+                min_visib_fract=0.1, crop_seed=0, crop_offset=None, image_size=None):
+  """Everything of an inference sample EXCEPT the pixels (datagen.py:424-476,545-575):
+  dict(scene_id, im_id, image_path, K f64[3,3], gt_obj_ids, gt_poses, crop_offset (h, w),
+  geometry = (h_orig, w_orig, h_new, w_new, crop_h, crop_w)). image_size = (h, w) of the
+  encoded image, used when the record has no image/height, image/width features."""
+  h_orig = _scalar(feats, 'image/height', None)
+  w_orig = _scalar(feats, 'image/width', None)
+  if h_orig is None or w_orig is None:
+    if image_size is None:
+      from PIL import Image
+      with Image.open(io.BytesIO(feats['image/encoded'][0])) as im_:
+        image_size = (im_.size[1], im_.size[0])          # header only: no decode
+    h_orig = image_size[0] if h_orig is None else h_orig
+    w_orig = image_size[1] if w_orig is None else w_orig
+  h_orig, w_orig = int(h_orig), int(w_orig)
   h_new = min(max_height_before_crop, h_orig)
   scale = np.float32(h_new) / np.float32(h_orig)
   w_new = int(np.float32(w_orig) * scale)
-  if h_new != h_orig:                      # misc.py:79-93 (shrinking: area filter)
-    im = resize_area(im, h_new, w_new)
   crop_w, crop_h = crop_size
   if crop_h > h_new or crop_w > w_new:
     raise ValueError('crop %dx%d larger than the frame %dx%d' % (
@@ -296,7 +353,6 @@ def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
   off_h, off_w = crop_offset
   if not (0 <= off_h <= h_new - crop_h and 0 <= off_w <= w_new - crop_w):
     raise ValueError('crop offset (%d, %d) outside the frame' % (off_h, off_w))
-  im = im[off_h:off_h + crop_h, off_w:off_w + crop_w]       # misc.crop_image
   # float32 arithmetic as in the TF graph (datagen.py:463-466)
   fx = np.float32(_scalar(feats, 'image/camera/fx', -1.0)) * scale
   fy = np.float32(_scalar(feats, 'image/camera/fy', -1.0)) * scale
@@ -312,10 +368,46 @@ def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
   return {
       'scene_id': scene_id, 'im_id': im_id, 'crop_offset': (off_h, off_w),
       'image_path': path.decode('utf-8') if isinstance(path, bytes) else path,
-      'image': np.ascontiguousarray(im), 'K': K,
-      'gt_obj_ids': [ids[i] for i in keep],
+      'K': K, 'gt_obj_ids': [ids[i] for i in keep],
       'gt_poses': _gt_poses(feats, ids, keep),
+      'geometry': (h_orig, w_orig, h_new, w_new, crop_h, crop_w),
   }
+
+
+def decode_image(encoded, geometry, crop_offset, out=None):
+  """The pixels of an inference sample: decode (PIL: JPEG / PNG) -> [shrink to
+  max_height_before_crop, misc.py:79-93] -> crop (misc.crop_image). Returns uint8 [crop_h,
+  crop_w, 3] when no resize is involved (every value is exactly what
+  tf.cast(decode_image(..), tf.float32) holds, datagen.py:435-436; the cast itself happens
+  on the device or in decode_sample), float32 after a resize. ``out``: an array of that
+  dtype and shape to decode into (a pinned staging buffer)."""
+  from PIL import Image
+  h_orig, w_orig, h_new, w_new, crop_h, crop_w = geometry
+  off_h, off_w = crop_offset
+  with Image.open(io.BytesIO(encoded)) as pil:
+    im = np.asarray(pil.convert('RGB'))
+  if h_new != h_orig:                      # misc.py:79-93 (shrinking: area filter)
+    im = resize_area(im.astype(np.float32), h_new, w_new)
+  im = im[off_h:off_h + crop_h, off_w:off_w + crop_w]       # misc.crop_image
+  if out is not None:
+    np.copyto(out, im, casting='same_kind')
+    return out
+  return np.ascontiguousarray(im)
+
+
+def decode_sample(feats, crop_size, max_height_before_crop, obj_ids=None,
+                  min_visib_fract=0.1, crop_seed=0, crop_offset=None):
+  """One parsed Example -> the inference sample of datagen.py:424-476,545-575:
+  dict(scene_id, im_id, image_path, image f32[crop_h, crop_w, 3], K f64[3,3],
+  gt_obj_ids list, crop_offset (h, w)). crop_size = (width, height) as the reference
+  consumes it (datagen.py:448-449). A frame larger than the crop is cropped at a
+  random offset (datagen.py:451-455, see crop_offsets; ``crop_offset=(h, w)`` fixes
+  it) and the principal point moves with it (datagen.py:465-466)."""
+  meta = sample_meta(feats, crop_size, max_height_before_crop, obj_ids, min_visib_fract,
+                     crop_seed, crop_offset)
+  im = decode_image(feats['image/encoded'][0], meta['geometry'], meta['crop_offset'])
+  meta['image'] = np.ascontiguousarray(im, np.float32)
+  return meta
 
 
 def _gt_poses(feats, ids, keep):

@@ -176,6 +176,34 @@ def random_init(model_variant='xception_65', num_objs=21, num_frags=64, seed=0,
   return w
 
 
+def heavy_tailed(w, seed=0, tiny_frac=0.01, tiny_scale=1e-10, lognormal_every=4,
+                 sigma=3.0):
+  """A copy of checkpoint ``w`` whose every conv / logits matrix has the tails of a TRAINED
+  network (weight decay drives many weights far below their column's maximum) that the
+  reference's initialisers never draw: ``tiny_frac`` of the entries of every matrix are
+  scaled by ``tiny_scale``, and every ``lognormal_every``-th output column gets log-normal
+  (sigma) magnitudes, renormalised to the column's l2 norm so that activations keep their
+  scale. Used by the tests and by ``bench.py --weights heavy-tailed`` to show that such a
+  checkpoint stays on the fp16-pair GEMM (until round 5 one such weight moved the whole layer
+  to the 20 % slower bf16 x 6 kernel). Depthwise filters and BatchNorm are left alone."""
+  rng = np.random.RandomState(seed + 77)
+  out = dict(w)
+  for key in sorted(w):
+    if not key.endswith('/weights'):
+      continue
+    a = np.asarray(w[key], np.float64)
+    shape = a.shape
+    m = a.reshape(-1, shape[-1]).copy()
+    cols = np.arange(m.shape[1]) % lognormal_every == lognormal_every - 1
+    if cols.any() and m.shape[0] > 1:
+      norm = np.sqrt((m[:, cols] ** 2).sum(0, keepdims=True))
+      h = m[:, cols] * np.exp(sigma * rng.standard_normal((m.shape[0], int(cols.sum()))))
+      m[:, cols] = h * (norm / np.maximum(np.sqrt((h ** 2).sum(0, keepdims=True)), 1e-300))
+    m[rng.uniform(size=m.shape) < tiny_frac] *= tiny_scale
+    out[key] = m.reshape(shape).astype(np.float32)
+  return out
+
+
 def fold_bn(w, scope, eps, kind):
   """Folds inference-mode BatchNorm into a per-output-channel (scale, bias):
   y = scale * conv(x) + bias, scale = gamma / sqrt(var + eps),

@@ -82,10 +82,16 @@ int64_t epos_pack_pointwise_weights_split(const float* w_kn, int K, int N, void*
  * Half the matrix-pipe work of the bf16 x 6 split above, 4 instead of 6 bytes per weight.
  * Layout: [ceil(N/128)][ceil(K/16)][4 column blocks][2 pieces][64 lanes][8 fp16] (fragment
  * order of v_mfma_f32_32x32x16_f16), then round_up(N,128) floats 2^-e_n.
- * NOT every matrix qualifies: if some nonzero weight is not reproduced to 2^-22 relative
- * (it lies more than ~2^27 below its column's maximum, or the column's scale leaves the
- * fp32 exponent range) the function returns 0 and writes nothing -- the caller then keeps
- * the bf16 x 6 split kernel for this layer (Wh = NULL).
+ * Every finite matrix qualifies (round 6): a scaled weight t is reproduced to
+ *     |hi + mid * 2^-11 - t| <= max(2^-22 |t|, 2^-36)
+ * i.e. to full precision down to 2^-28 of its column's maximum and, below that (fp16
+ * subnormal pieces, which the matrix pipe does not flush), with an ABSOLUTE error of at most
+ * 2^-50 x the column maximum -- the same graceful degradation as the activation side, and
+ * below the fp32 rounding of any sum the column's larger weights take part in. (Until ABI 7's
+ * first release a single such weight made the packer refuse the whole matrix.) The function
+ * returns 0 and writes nothing only for Inf / NaN weights or a column whose scale leaves the
+ * fp32 exponent range (column maximum outside ~2^-85 .. 2^115); the caller then keeps the
+ * bf16 x 6 split kernel for this layer (Wh = NULL).
  * Host-side helper (host pointers). Returns the number of BYTES written (or required, if
  * dst == NULL; 0 = not representable). */
 int64_t epos_pack_pointwise_weights_h2(const float* w_kn, int K, int N, void* dst);
@@ -305,6 +311,19 @@ int epos_subsample_f32(const float* X, int64_t ldx, float* Y, int64_t ldy, int B
  * pre-sum conv3 output is itself an end point, feature.py:50-54). */
 int epos_add_relu_f32(const float* A, const float* B, float* Y, int64_t n,
                       void* stream);
+
+/* Sparse update: for b < n_blocks, dst[offsets[b] .. offsets[b] + width) = src[b * width ..]
+ * (all pointers [device]; offsets in elements; blocks must not overlap). Synthetic-workload
+ * support: bench.py --planted-poses overwrites the head values of the target objects with
+ * values rendered from known poses, between the network and the correspondence stage. */
+int epos_scatter_blocks_f32(float* dst, const int64_t* offsets, const float* src,
+                            int64_t n_blocks, int width, void* stream);
+
+/* uint8 -> float32, n values (both pointers [device], 16-byte aligned): the
+ * tf.cast(decode_image(...), tf.float32) of the reference's input pipeline
+ * (datagen.py:435-436) done on the device, so that decoded frames are uploaded as bytes.
+ * Exact. */
+int epos_u8_to_f32(const uint8_t* X, float* Y, int64_t n, void* stream);
 
 /* In-place softmax over groups of `G` consecutive floats (model.py:677-678):
  * X holds n_groups * G floats, group g at X + g*G (G <= 64). */

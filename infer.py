@@ -145,9 +145,23 @@ def build_parser():
     help='object channels (default: from the checkpoint)')
   a('--batch', type=int, default=1, help='images per GPU per step')
   a('--seed', type=int, default=0)
-  a('--pipeline_depth', type=int, default=1,
-    help='batches in flight (independent plans on their own HIP streams); 1 = one '
-         'image at a time with per-stage times like the reference, >1 = throughput')
+  a('--pipeline_depth', type=int, default=0,
+    help='batches in flight (independent plans on their own HIP streams, each with its own '
+         'per-stage timers). 0 (default) = bench.py\'s rule: 4 at one image per batch, 2 from '
+         'four images per batch on, 3 in between; 1 = strictly one batch at a time (the '
+         'reference\'s loop). --vis, --save_corresp and the operator path (--use_prosac, '
+         '--max_correspondences, --project_to_surface) read the plan\'s buffers after every '
+         'step and always run at depth 1. The poses do not depend on the depth.')
+  a('--sparse_heads', default='auto',
+    help='evaluate the fragment heads only for the target objects of each image. '
+         'corresp.establish_many_to_many never reads the other objects\' channels in '
+         'localization mode (corresp.py:39-43), so the poses are bit-identical and ~7 %% of the '
+         'step is saved. auto (default) = on for --task_type=localization unless --vis, '
+         '--save_corresp or the operator path need the dense prediction; true / false force it')
+  a('--decode_threads', type=int, default=0,
+    help='decoder processes working ahead of the GPU (0 = min(8, cores - 2); '
+         'EPOS_DECODE_PROCS=0 makes them in-process threads)')
+  a('--prefetch', type=int, default=6, help='batches decoded ahead of the GPU')
   return ap
 
 
@@ -274,60 +288,39 @@ def find_checkpoint(checkpoint_dir, name):
 
 
 def load_frames(args, num_objs, rank, world, store_obj_ids=None):
-  """Returns this rank's list of (scene_id, im_id, image f32[H,W,3], K, targets)."""
+  """Returns this rank's list of epos_amd.frames.Frame (ids, K, targets known; pixels decoded
+  on demand by the prefetcher's threads), plus the frame height and width."""
+  from epos_amd import frames as eframes
   w, h = [int(x) for x in str(args.infer_crop_size).split(',')][:2] \
       if not isinstance(args.infer_crop_size, (list, tuple)) \
       else args.infer_crop_size[:2]
-  frames = []
   if args.infer_tfrecord_names:
     # <TF_DATA_PATH>/<name>.tfrecord for each name (infer.py:581-583,
     # datagen.py:707-723), read without TensorFlow (epos_amd/tfrecord.py).
-    from epos_amd import tfrecord
     names = args.infer_tfrecord_names
     if not isinstance(names, (list, tuple)):
       names = [n for n in str(names).split(',') if n]
     data_path = os.environ.get('TF_DATA_PATH', '.')
-    obj_ids = store_obj_ids if store_obj_ids else None
-    all_samples = []
+    paths = []
     for name in names:
       path = os.path.join(data_path, name + '.tfrecord')
       if not os.path.exists(path):
         raise ValueError('No input files: {}'.format(path))   # datagen.py:720-721
-      # min_visib_fract=None: the reference builds its inference Dataset without a
-      # visibility filter (scripts/infer.py:614), every annotated instance is a target
-      all_samples += list(tfrecord.load_samples(
-          path, (w, h), args.infer_max_height_before_crop, obj_ids, None,
-          crop_seed=args.seed))
-    b, e = edist.shard_range(len(all_samples), rank, world)
-    for sm in all_samples[b:e]:
-      tg = {}
-      for o in sm['gt_obj_ids']:             # instance counts, infer.py:462-463
-        tg[o] = tg.get(o, 0) + 1
-      frames.append((sm['scene_id'], sm['im_id'], sm['image'], sm['K'], tg,
-                     sm.get('gt_poses')))
+      paths.append(path)
+    # min_visib_fract=None: the reference builds its inference Dataset without a
+    # visibility filter (scripts/infer.py:614), every annotated instance is a target
+    all_frames = eframes.scan_tfrecords(
+        paths, (w, h), args.infer_max_height_before_crop,
+        store_obj_ids if store_obj_ids else None, crop_seed=args.seed)
+    b, e = edist.shard_range(len(all_frames), rank, world)
+    frames = all_frames[b:e]
   elif args.frames:
     meta = json.load(open(os.path.join(args.frames, 'frames.json')))
     b, e = edist.shard_range(len(meta), rank, world)
-    for m in meta[b:e]:
-      path = os.path.join(args.frames, m['path'])
-      if path.endswith('.npy'):
-        img = np.load(path)
-      else:
-        from PIL import Image
-        img = np.asarray(Image.open(path).convert('RGB'))
-      img = np.asarray(img, np.float32)[:h, :w]
-      if img.shape[:2] != (h, w):
-        raise ValueError('frame %s is %s, expected %dx%d (resize/crop of '
-                         'datagen.py:424-476 is a "next" item)' % (
-                             path, img.shape, w, h))
-      frames.append((m.get('scene_id', 0), m['im_id'], img,
-                     np.asarray(m['K'], np.float64).reshape(3, 3),
-                     {int(k): int(v) for k, v in m.get('targets', {}).items()}))
+    frames = eframes.frames_from_dir(args.frames, meta[b:e], h, w)
   elif args.synthetic:
     b, e = edist.shard_range(args.synthetic, rank, world)
-    for i in range(b, e):
-      frames.append((0, i, synthetic.image(i, h, w), synthetic.YCBV_K.copy(),
-                     synthetic.targets(i, num_objs, 5)))
+    frames = eframes.synthetic_frames(range(b, e), h, w, num_objs, 5)
   else:
     raise ValueError(
         'No input files: give --infer_tfrecord_names, --frames <dir> or '
@@ -337,7 +330,7 @@ def load_frames(args, num_objs, rank, world, store_obj_ids=None):
 
 def save_correspondences(infer_dir, infer_name, frame, im_ind, corr, pred_time):
   """infer.py:294-345 text dump (sorted by confidence)."""
-  scene_id, im_id, _, K = frame[:4]
+  scene_id, im_id, K = frame.scene_id, frame.im_id, frame.K
   suffix = '' if infer_name is None else '_' + infer_name
   for obj_id, c in corr.items():
     txt = '# Corr format: u v x y z px_id frag_id conf conf_obj conf_frag\n'
@@ -400,16 +393,16 @@ def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
         # algorithm (5-point EPnP sets drawn by cv::RNG, float32 inlier rule, the 0.99
         # confidence bound, EPnP over the inliers) in HIP -- csrc/epnp_ransac.hip.
         ok, r_est, t_est, _ = fitting.solvePnPRansac(
-            objectPoints=c['coord_3d'], imagePoints=c['coord_2d'], cameraMatrix=f[3],
+            objectPoints=c['coord_3d'], imagePoints=c['coord_2d'], cameraMatrix=f.K,
             distCoeffs=None, iterationsCount=fit.max_iters,
             reprojectionError=fit.threshold, confidence=0.99,
             flags=fitting.SOLVEPNP_EPNP)
         if ok:
-          poses.append({'scene_id': f[0], 'im_id': f[1], 'obj_id': obj_id,
+          poses.append({'scene_id': f.scene_id, 'im_id': f.im_id, 'obj_id': obj_id,
                         'R': fitting.Rodrigues(r_est), 't': t_est, 'score': 0.0})
         continue
       est, _, quals = fitting.find6DPoses(
-          c['coord_2d'], c['coord_3d'], f[3], threshold=fit.threshold,
+          c['coord_2d'], c['coord_3d'], f.K, threshold=fit.threshold,
           neighborhood_ball_radius=fit.neighborhood_ball_radius,
           spatial_coherence_weight=fit.spatial_coherence_weight,
           scaling_from_millimeters=fit.scaling_from_millimeters,
@@ -421,10 +414,10 @@ def process_by_operators(pipe, store, imgs, chunk, targets, args, fit):
           max_model_number=num_inst,
           max_model_number_for_optimization=fit.max_model_number_for_optimization,
           use_prosac=args.use_prosac,
-          seed=args.seed * 1000003 + f[1] * 1009 + obj_id)
+          seed=args.seed * 1000003 + f.im_id * 1009 + obj_id)
       if est is not None:                                 # infer.py:490-503
         for i in range(est.shape[0] // 3):
-          poses.append({'scene_id': f[0], 'im_id': f[1], 'obj_id': obj_id,
+          poses.append({'scene_id': f.scene_id, 'im_id': f.im_id, 'obj_id': obj_id,
                         'R': est[3 * i:3 * i + 3, :3],
                         't': est[3 * i:3 * i + 3, 3].reshape(3, 1),
                         'score': float(quals[i])})
@@ -556,28 +549,49 @@ def main(argv=None):
   # bounds "all found" by --detection_instance_cap (static buffers) and reports every
   # (frame, object) that reaches the cap.
   if args.task_type == pipeline.LOCALIZATION:
-    max_inst = max([1] + [int(c) for f in frames for c in f[4].values()])
+    max_inst = max([1] + [int(c) for f in frames for c in f.targets.values()])
     if args.max_instances_to_fit is not None:
       max_inst = max(1, min(max_inst, args.max_instances_to_fit))
   else:
     max_inst = max(1, int(args.detection_instance_cap))
-  depth = max(1, args.pipeline_depth)
-  if operator_path or args.save_corresp or args.vis:
+  needs_dense = bool(operator_path or args.save_corresp or args.vis)
+  depth = args.pipeline_depth if args.pipeline_depth > 0 else (
+      4 if B == 1 else 2 if B >= 4 else 3)         # bench.py's rule
+  if needs_dense:
     depth = 1                      # those paths read the plan's buffers after the step
+  sh = str(args.sparse_heads).lower()
+  if sh == 'auto':
+    sparse_heads = args.task_type == pipeline.LOCALIZATION and not needs_dense
+  else:
+    sparse_heads = str2bool(sh)
+    if sparse_heads and (needs_dense or args.task_type != pipeline.LOCALIZATION):
+      raise ValueError('--sparse_heads=true needs --task_type=localization without --vis / '
+                       '--save_corresp / the operator path (they read every object\'s heads)')
+  # the decoder processes start (import numpy / PIL) while the plans are built; nothing is
+  # decoded before the loop below asks for it
+  from epos_amd import frames as eframes
+  feed = eframes.Prefetcher(frames, B, h, w, workers=args.decode_threads or None,
+                            ahead=max(1, args.prefetch), inflight=depth)
   pipes = [pipeline.EposPipeline(
       ckpt, B, h, w, num_objs, args.num_frags, store, fit_params=fit,
       corr_min_obj_conf=args.corr_min_obj_conf,
       corr_min_frag_rel_conf=args.corr_min_frag_rel_conf,
       max_instances=max_inst, model_options=mo, device=dev, instance=j,
-      fitting_method=args.fitting_method)
+      sparse_heads=sparse_heads, fitting_method=args.fitting_method)
            for j in range(depth)]
   pipe = pipes[0]
+  if rank == 0:
+    print('plan: {} image(s) per step, {} step(s) in flight, {} heads, {} GEMM layers on the '
+          'fp16-pair kernel ({} on the bf16 x 6 fallback)'.format(
+              B, depth, 'sparse' if sparse_heads else 'dense', len(pipe.net.h2_layers),
+              len(pipe.net.h2_refused)))
 
-  poses_all, time_start = [], time.time()
+  poses_all = []
+  time_start = time.time()           # first decode -> CSV written
 
   def finish(i0, chunk, poses, rt):
     n_real = len(frames[i0:i0 + B])
-    real_ids = set((f[0], f[1]) for f in frames[i0:i0 + n_real])
+    real_ids = set((f.scene_id, f.im_id) for f in frames[i0:i0 + n_real])
     seen = set()
     for p in poses:
       key = (p['scene_id'], p['im_id'], p['obj_id'], float(p['score']))
@@ -586,39 +600,38 @@ def main(argv=None):
         poses_all.append(p)
     if args.save_corresp:
       from epos_amd import corresp as ecorresp
-      pred = pipe.net.outputs() if not pipe.sparse_heads else pipe.net.forward()
+      pred = pipe.net.outputs()
       for b, f in enumerate(chunk[:n_real]):
         c = ecorresp.establish_many_to_many(
             pred['pred_obj_conf'][b], pred['pred_frag_conf'][b],
-            pred['pred_frag_loc'][b], list(f[4]), store, 0.25,
+            pred['pred_frag_loc'][b], list(f.targets), store, 0.25,
             args.corr_min_obj_conf, args.corr_min_frag_rel_conf, False,
             args.task_type == pipeline.LOCALIZATION, device=dev)
         save_correspondences(infer_dir, args.infer_name, f, i0 + b, c,
                              rt.get('total', 0.0))
     if args.vis:                                # infer.py:540-552, <model>/vis (:577)
       from epos_amd import vis as evis
-      pred = {k: v.cpu().numpy() for k, v in
-              (pipe.net.outputs() if not pipe.sparse_heads else pipe.net.forward()).items()}
+      pred = {k: v.cpu().numpy() for k, v in pipe.net.outputs().items()}
       flags = {k: getattr(args, k) for k in vars(args) if k.startswith('vis_')}
       for b, f in enumerate(chunk[:n_real]):
-        est = [p for p in poses if (p['scene_id'], p['im_id']) == (f[0], f[1])]
-        evis.visualize(f[2], f[3], {k: v[b] for k, v in pred.items()}, est, i0 + b,
+        est = [p for p in poses if (p['scene_id'], p['im_id']) == (f.scene_id, f.im_id)]
+        evis.visualize(f.image_f32(), f.K, {k: v[b] for k, v in pred.items()}, est, i0 + b,
                        store, os.path.join(model_dir, 'vis'),
-                       gt_poses=f[5] if len(f) > 5 else None, flags=flags)
+                       gt_poses=f.gt_poses, flags=flags)
     if rank == 0:                               # infer.py:730-734
       print('Image: {}, prediction: {:.3f}, establish_corr: {:.3f}, fitting: '
             '{:.3f}, total time: {:.3f}'.format(
                 i0, rt.get('prediction', 0), rt.get('establish_corr', 0),
                 rt.get('fitting', 0), rt.get('total', 0)))
+    feed.release(i0)                            # its staging buffer may be decoded into again
 
   inflight = []                                 # (pipeline, i0, chunk), oldest first
-  for step, i0 in enumerate(range(0, len(frames), B)):
-    chunk = frames[i0:i0 + B]
-    while len(chunk) < B:                      # pad the last batch
-      chunk = chunk + [chunk[-1]]
-    imgs = torch.from_numpy(np.stack([f[2] for f in chunk])).to(dev)
-    Ks = np.stack([f[3] for f in chunk])
-    tg = [f[4] for f in chunk]
+  for step, (i0, chunk, imgs) in enumerate(feed):
+    # imgs: pinned host memory, uint8 as decoded (float32 only for frames that are not
+    # byte-valued); the upload is enqueued on the step's own stream and the cast to float32
+    # (datagen.py:435-436) runs on the device
+    Ks = np.stack([f.K for f in chunk])
+    tg = [f.targets for f in chunk]
     if args.max_instances_to_fit is not None:  # infer.py:467-468
       tg = [{o: min(c, args.max_instances_to_fit) for o, c in t.items()}
             for t in tg]
@@ -631,23 +644,27 @@ def main(argv=None):
       finish(j0, ch, *q.collect())
     p = pipes[step % depth]
     p.launch(imgs, Ks, tg, task_type=args.task_type,
-             image_ids=[f[1] for f in chunk], scene_ids=[f[0] for f in chunk],
+             image_ids=[f.im_id for f in chunk], scene_ids=[f.scene_id for f in chunk],
              seed=args.seed, timing=True)
     inflight.append((p, i0, chunk))
   while inflight:
     q, j0, ch = inflight.pop(0)
     finish(j0, ch, *q.collect())
+  loop_s = time.time() - time_start
   hits = sorted(set(h for q in pipes for h in q.cap_hits))
   n_hits = sum(q.cap_hit_count for q in pipes)
   if hits:
-    print('Instance cap (--detection_instance_cap={}) reached for {} (scene, image, object) '
-          'triples{}; more instances may exist there:'.format(
-              max_inst, n_hits, '' if n_hits == len(hits) else ' (the last {} listed)'.format(len(hits))))
+    overflowed = any(q.cap_hit_count > q.CAP_HITS_KEPT for q in pipes)
+    print('Instance cap (--detection_instance_cap={}) reached {} time(s), for {} distinct '
+          '(scene, image, object) triples{}; more instances may exist there:'.format(
+              max_inst, n_hits, len(hits),
+              ' among the last {} hits kept per pipeline'.format(pipe.CAP_HITS_KEPT)
+              if overflowed else ''))
     for sc_, im_, ob_, n_ in hits:
       print('  scene {} image {} object {}: {} instances'.format(sc_, im_, ob_, n_))
   # First-image time := mean time of the others (infer.py:741-749).
   if len(poses_all) > 1 and frames:
-    first = (frames[0][0], frames[0][1])
+    first = (frames[0].scene_id, frames[0].im_id)
     rest = [p['time'] for p in poses_all if (p['scene_id'], p['im_id']) != first]
     if rest:
       for p in poses_all:
@@ -660,8 +677,15 @@ def main(argv=None):
     suffix = '' if args.infer_name is None else '_' + args.infer_name
     path = os.path.join(infer_dir, 'estimated-poses{}.csv'.format(suffix))
     bop_io.save_bop_results(path, merged, version='bop19')
-    print('Saved {} pose estimates to: {}  ({:.2f} s)'.format(
-        len(merged), path, time.time() - time_start))
+    total_s = time.time() - time_start
+    print('Saved {} pose estimates to: {}  ({:.2f} s)'.format(len(merged), path, total_s))
+    # from the first decode to the CSV on disk (this rank's frames; with N ranks each rank
+    # runs its own shard concurrently, so the job's rate is ~N x this)
+    print('Throughput: {} images in {:.3f} s = {:.1f} images/s (inference loop {:.3f} s = '
+          '{:.1f} images/s; first decode -> CSV written; plan construction and weight packing '
+          'before it are not included)'.format(
+              len(frames), total_s, len(frames) / max(total_s, 1e-9), loop_s,
+              len(frames) / max(loop_s, 1e-9)))
   if world > 1:
     torch.distributed.destroy_process_group()
 

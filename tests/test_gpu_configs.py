@@ -234,8 +234,12 @@ def test_c3_per_gpu_shard_batch4():
     assert np.array_equal(a['R'], b_['R']) and np.array_equal(a['t'], b_['t'])
 
 
-def test_c2_full_size_split_gemm_not_less_accurate_than_fp32_mfma(tmp_path):
-  """At the full C2 size: the network through the split-operand GEMM (default) and
+@pytest.mark.parametrize('tails', ['init', 'heavy_tailed'])
+def test_c2_full_size_split_gemm_not_less_accurate_than_fp32_mfma(tmp_path, tails):
+  """(tails = 'heavy_tailed', round 6: the same statement on weights.heavy_tailed(checkpoint)
+  -- every GEMM matrix has 1 % of its weights at 1e-10 and every fourth column log-normal
+  sigma 3, the tails a trained network has; every layer must stay on the fp16-pair kernel.)
+  At the full C2 size: the network through the split-operand GEMM (default) and
   through the fp32-MFMA GEMM (EPOS_GEMM_SPLIT=0, read once per process: two
   subprocesses), both against the oracle carried out in fp64 on the same fp32 weights.
   Per head, rms(split - fp64) <= rms(fp32-MFMA - fp64): the precision statement the
@@ -254,12 +258,15 @@ def test_c2_full_size_split_gemm_not_less_accurate_than_fp32_mfma(tmp_path):
       "sys.path.insert(0, %r)\n"
       "from epos_amd import model, weights, synthetic\n"
       "ckpt = weights.random_init(num_objs=%d, seed=0, randomize_bn=True, logits_std=0.2)\n"
+      "if %r == 'heavy_tailed': ckpt = weights.heavy_tailed(ckpt, seed=0)\n"
       "img = synthetic.image(7, %d, %d)[None]\n"
       "net = model.get_net(ckpt, 1, %d, %d, %d, %d)\n"
+      "assert not net.h2_refused or not net.use_h2, net.h2_refused\n"
+      "assert len(net.h2_layers) >= 70 or not net.use_h2, len(net.h2_layers)\n"
       "net.set_images(torch.from_numpy(img).cuda()); net.run_plan(with_post=False)\n"
       "torch.cuda.synchronize()\n"
       "np.savez(sys.argv[1], **{k: v.cpu().numpy() for k, v in net.logits.items()},\n"
-      "         decoder=net.decoder_out.cpu().numpy())\n" % (root, O, H, W_, H, W_, O, F))
+      "         decoder=net.decoder_out.cpu().numpy())\n" % (root, O, tails, H, W_, H, W_, O, F))
   # the two GPU runs (seconds each) go on beside the fp64 oracle of this process (~40 s of CPU)
   procs = {}
   for mode in ('1', '0'):
@@ -269,6 +276,8 @@ def test_c2_full_size_split_gemm_not_less_accurate_than_fp32_mfma(tmp_path):
         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
   from epos_amd import synthetic
   ckpt = weights.random_init(num_objs=O, seed=0, randomize_bn=True, logits_std=0.2)
+  if tails == 'heavy_tailed':
+    ckpt = weights.heavy_tailed(ckpt, seed=0)
   img = synthetic.image(7, H, W_)[None]
   with torch.no_grad(), net_ref.precision(torch.float64):
     ref, ep = net_ref.logits(img, ckpt, O, F)

@@ -213,6 +213,55 @@ def test_infer_from_tfrecord(tmp_path):
 
 
 @pytest.mark.gpu
+def test_infer_streaming_default_matches_the_serial_dense_run(tmp_path):
+  """The drop-in's default configuration since round 6 -- frames decoded by the prefetcher's
+  threads into pinned uint8 buffers, uploaded as bytes and cast on the device, four steps in
+  flight, fragment heads evaluated for the target objects only -- writes the same CSV rows as
+  the strictly serial run with dense heads (--pipeline_depth 1 --sparse_heads false), up to the
+  time column; 9 JPEG frames at batch 1 and at batch 2 (padded last batch)."""
+  import io
+  from PIL import Image
+  from epos_amd import tfrecord
+  data = tmp_path / 'data'
+  data.mkdir()
+  rng = np.random.RandomState(0)
+  recs = []
+  for i in range(9):
+    buf = io.BytesIO()
+    Image.fromarray(rng.randint(0, 256, (96, 128, 3)).astype(np.uint8)).save(
+        buf, format='JPEG', quality=92)
+    recs.append(tfrecord.encode_example({
+        'image/scene_id': [3], 'image/im_id': [i], 'image/path': [b'x.jpg'],
+        'image/encoded': [buf.getvalue()], 'image/height': [96],
+        'image/width': [128], 'image/channels': [3],
+        'image/camera/fx': [300.0], 'image/camera/fy': [300.0],
+        'image/camera/cx': [64.0], 'image/camera/cy': [48.0],
+        'image/object/id': [1, 3] if i % 2 else [2], 'image/object/visibility': [0.9] * (1 + i % 2)}))
+  tfrecord.write_records(str(data / 'toy_test.tfrecord'), recs)
+  rows = {}
+  for name, extra in (('serial', ['--pipeline_depth', '1', '--sparse_heads', 'false']),
+                      ('default', []), ('batch2', ['--batch', '2'])):
+    models = tmp_path / name
+    (models / 'toy').mkdir(parents=True)
+    (models / 'toy' / 'params.yml').write_text('infer_crop_size: "128,96"\n')
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'infer.py'), '--model=toy',
+         '--infer_tfrecord_names', 'toy_test', '--synthetic', '1', '--num_objs', '3'] + extra,
+        env=dict(os.environ, TF_MODELS_PATH=str(models), TF_DATA_PATH=str(data)),
+        capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    plan = [l for l in out.stdout.split('\n') if l.startswith('plan:')][0]
+    assert ('1 step(s) in flight, dense' in plan) == (name == 'serial'), plan
+    if name == 'default':
+      assert '4 step(s) in flight, sparse' in plan, plan
+    assert 'Throughput:' in out.stdout
+    txt = (models / 'toy' / 'infer' / 'estimated-poses.csv').read_text().strip().split('\n')
+    rows[name] = [','.join(r.split(',')[:-1]) for r in txt]
+  assert len(rows['serial']) > 1
+  assert rows['serial'] == rows['default'] == rows['batch2']
+
+
+@pytest.mark.gpu
 def test_infer_restores_tf_checkpoint(tmp_path):
   """<model>/train/model.ckpt-N.{index,data-*} is restored by variable name
   (infer.py:670-683) through the TensorFlow-free TensorBundle reader."""

@@ -67,6 +67,12 @@ def gemm_family():
   return 'h2' 
 ALGO_GFLOP_C2 = 455.0           # SURVEY.md App. A, per image
 
+# EPOS_GEMM_SPLIT=0 (the fp32-MFMA comparison line of BASELINE.md's table): those kernels are
+# test-only since round 6 -- the line is then measured on the test build of the library
+if gemm_family() == 'fp32' and not os.environ.get('EPOS_HIP_LIB'):
+  from epos_amd import build as _hip_build
+  os.environ['EPOS_HIP_LIB'] = _hip_build.REF_LIB_PATH
+
 
 def workload_name(args, B):
   """BASELINE.json's config the flags describe (C2 is the metric's; the others are the

@@ -220,18 +220,37 @@ def lib_path():
   return os.environ.get('EPOS_HIP_LIB') or _build.LIB_PATH
 
 
+def load_ref():
+  """The TEST build of the library: the product library + the fp32-MFMA reference GEMM kernels
+  (epos_amd/build.py: build_ref). A second, independent handle -- the accuracy tests run the
+  product kernels and the reference kernels through it side by side. Not used by the product
+  path (a process that wants its whole plan on the reference kernels sets
+  EPOS_HIP_LIB=<libepos_hip_ref.so> and EPOS_GEMM_SPLIT=0 instead)."""
+  global _ref
+  if _ref is None:
+    _ref = _open(_build.REF_LIB_PATH)
+  return _ref
+
+
+_ref = None
+
+
 def load():
   """Loads libepos_hip.so (never builds implicitly on a GPU box: the library must
   have been built by __graft_entry__.build() / python -m epos_amd.build)."""
   global _lib
   if _lib is not None:
     return _lib
+  _lib = _open(lib_path())
+  return _lib
+
+
+def _open(path):
   # PyTorch's HIP runtime has to be the first one mapped into the process: loading
   # this library (linked against /opt/rocm's libamdhip64) BEFORE torch initialises
   # leaves the process with a runtime that reports "no ROCm-capable device" to
   # whichever side came second (seen with build() and smoke() in one interpreter).
   import torch  # noqa: F401
-  path = lib_path()
   if not os.path.exists(path):
     raise EposError(
         'libepos_hip.so not found at %s -- build it with '
@@ -244,15 +263,14 @@ def load():
       fn.argtypes = argtypes
   if lib.epos_abi_version() != 7:
     raise EposError('libepos_hip.so ABI version mismatch')
-  _lib = lib
   return lib
 
 
 AMAX_WORDS = 64          # EPOS_AMAX_WORDS: uint32 words per absmax slot
 
 
-def check(rc, what=''):
+def check(rc, what='', lib=None):
   if rc < 0:
-    msg = load().epos_last_error().decode('utf-8', 'replace')
+    msg = (lib or load()).epos_last_error().decode('utf-8', 'replace')
     raise EposError('%s failed (%d): %s' % (what or 'epos call', rc, msg))
   return rc

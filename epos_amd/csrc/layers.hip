@@ -198,15 +198,9 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
   if (!live) return;
   const bool row1 = ROWS == 2 && y + r < p.Ho;   // the pair's second row exists
   float4 w[9];
-#ifdef EPOS_DW_ABL_NOW
-#pragma unroll
-  for (int i = 0; i < 9; ++i) w[i] = make_float4(0.1f * i, 0.2f, 0.3f, 0.4f);
-  const float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-#else
 #pragma unroll
   for (int i = 0; i < 9; ++i) w[i] = ld4(p.w9c + i * p.C + c);
   const float4 bias = ld4(p.bias + c);
-#endif
   // 32-bit element offsets from one per-thread base (the host checks the range)
   const float* xb = p.X + static_cast<int64_t>(b) * p.Hi * p.Wi * p.ldx + c;
   float* yb = p.Y + ((static_cast<int64_t>(b) * p.Ho + y) * p.Wo) * p.ldy + c;
@@ -226,19 +220,10 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
     // ---- interior wave: no clamp, no select -----------------------------------
     const unsigned o00 = (y - r) * rowpitch + (x0 - r) * ldx;
     const unsigned rstep = r * rowpitch, cstep = r * ldx;
-#ifdef EPOS_DW_ABL_ONEROW      // ablation: a quarter of the loads (wrong results)
-#pragma unroll
-    for (int i = 0; i < L + 2; ++i) {
-      col[i][1] = ld4(xb + (o00 + rstep + i * cstep));
-#pragma unroll
-      for (int ky = 0; ky < NR; ++ky) col[i][ky] = col[i][1];
-    }
-#else
 #pragma unroll
     for (int i = 0; i < L + 2; ++i)
 #pragma unroll
       for (int ky = 0; ky < NR; ++ky) col[i][ky] = ld4(xb + (o00 + ky * rstep + i * cstep));
-#endif
     if (RELU_IN) {
 #pragma unroll
       for (int i = 0; i < L + 2; ++i)
@@ -250,17 +235,12 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
 #pragma unroll
       for (int j = 0; j < L; ++j) {
         float4 acc = bias;
-#ifdef EPOS_DW_ABL_NOFMA       // ablation: one multiply-add per output instead of nine
-        acc = fma4(col[j + 1][1 + rr], w[4], acc);
-        acc.x += col[j][rr].x + col[j + 2][2 + rr].x;
-#else
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
           acc = fma4(col[j][ky + rr], w[ky * 3 + 0], acc);
           acc = fma4(col[j + 1][ky + rr], w[ky * 3 + 1], acc);
           acc = fma4(col[j + 2][ky + rr], w[ky * 3 + 2], acc);
         }
-#endif
         if (RELU_OUT) acc = relu4_1op(acc);
         st4_any(yb + (static_cast<unsigned>((x0 + j * r) * ldy) + (rr ? yrow1 : 0u)), acc, h2, hs);
       }
@@ -281,14 +261,8 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
     const int xi = x0 + (i - 1) * r;
     const bool xok = xi >= 0 && xi < p.Wi;
     const unsigned off = (xok ? xi : 0) * ldx;
-#ifdef EPOS_DW_ABL_ONEROW
-    col[i][1] = ld4(xb + (rowoff[1] + off));
-#pragma unroll
-    for (int ky = 0; ky < NR; ++ky) col[i][ky] = col[i][1];
-#else
 #pragma unroll
     for (int ky = 0; ky < NR; ++ky) col[i][ky] = ld4(xb + (rowoff[ky] + off));
-#endif
   }
 #pragma unroll
   for (int i = 0; i < L + 2; ++i) {
@@ -628,36 +602,8 @@ inline unsigned blocks_for(int64_t total, int threads) {
 
 using namespace epos;
 
-#ifdef EPOS_DW_ABL_LIGHT
-// ablation (tools/, WRONG results): the centre tap only -- one 16-byte load and one store per
-// thread, ~16 VGPRs: what would a depthwise kernel cost inside the pipelined step if it
-// co-resided with anything and issued next to nothing? (the same bytes move)
-namespace epos { namespace {
-__global__ __launch_bounds__(256) void dw_light_kernel(EposDepthwiseArgs p, int64_t total) {
-  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int c4n = p.C / 4;
-  const int64_t pix = i / c4n;
-  const int c4 = static_cast<int>(i - pix * c4n);
-  const float4 x = *reinterpret_cast<const float4*>(p.X + pix * p.ldx + 4 * c4);
-  const float4 wv = *reinterpret_cast<const float4*>(p.w9c + 4 * p.C + 4 * c4);
-  const float4 b = *reinterpret_cast<const float4*>(p.bias + 4 * c4);
-  float4 y;
-  y.x = x.x * wv.x + b.x; y.y = x.y * wv.y + b.y; y.z = x.z * wv.z + b.z; y.w = x.w * wv.w + b.w;
-  *reinterpret_cast<float4*>(p.Y + pix * p.ldy + 4 * c4) = y;
-}
-} }
-#endif
 
 extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
-#ifdef EPOS_DW_ABL_LIGHT
-  if (a->stride == 1 && a->Hi == a->Ho && a->Wi == a->Wo && !a->y_h2) {
-    const int64_t total = static_cast<int64_t>(a->B) * a->Ho * a->Wo * (a->C / 4);
-    hipLaunchKernelGGL(epos::dw_light_kernel, dim3(static_cast<unsigned>((total + 255) / 256)),
-                       dim3(256), 0, static_cast<hipStream_t>(stream), *a, total);
-    return EPOS_OK;
-  }
-#endif
   EPOS_REQUIRE(a && a->X && a->w9c && a->bias && a->Y, "null pointer");
   EPOS_REQUIRE(a->C % 4 == 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0,
                "C, ldx, ldy must be multiples of 4");

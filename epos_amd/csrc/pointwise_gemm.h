@@ -1,5 +1,6 @@
-// Shared pieces of the pointwise-GEMM kernels (pointwise_gemm.hip: register-staged
-// kernels + the C entry points; pointwise_gemm_dma.hip: the LDS-DMA kernels).
+// Shared pieces of the pointwise-GEMM kernels (pointwise_gemm.hip: the C entry points and the
+// routing; pointwise_gemm_h2.hip / _split.hip: the product kernels; ref/*.hip: the fp32-MFMA
+// reference kernels of the test build).
 // Everything here has internal linkage: each translation unit gets its own copy.
 #pragma once
 #include <stdlib.h>
@@ -11,13 +12,20 @@
 
 namespace epos {
 
-// Launcher defined in pointwise_gemm_dma.hip (the fp32-MFMA data path for every GEMM
-// without a pre-activation ReLU).
+// The fp32-MFMA kernels (v_mfma_f32_32x32x2_f32; rounds 1-2) are TEST-ONLY since round 6:
+// ref/pointwise_gemm_dma.hip (LDS-DMA data path) and ref/pointwise_gemm_staged.hip
+// (register-staged, pre-activation ReLU) are linked into libepos_hip_ref.so only and announce
+// themselves here when they are (static initialisers); the product library leaves both null
+// and refuses a problem without Wh / Ws. Same argument meaning as launch_grouped_h2 below:
 // conv_cin != nullptr: implicit 3x3 conv, problem i has conv_cin[i] input channels and
 // dilation conv_rate[i] (K = 9 * conv_cin[i], A = the NHWC input of Hi x Wi pixels,
 // `sub` = stride, M = B * Ho * Wo output pixels).
-int launch_grouped_dma(const EposPointwiseArgs* args, int count, hipStream_t s,
-                       const int* conv_cin = nullptr, const int* conv_rate = nullptr);
+struct Fp32MfmaRef {
+  int (*dma)(const EposPointwiseArgs* args, int count, hipStream_t s, const int* conv_cin,
+             const int* conv_rate);
+  int (*staged)(const EposPointwiseArgs* args, int count, hipStream_t s);
+};
+Fp32MfmaRef& fp32_mfma_ref();        // pointwise_gemm.hip
 // pointwise_gemm_split.hip: fp32 GEMM on the bf16 matrix pipe (exact three-way operand
 // split, six piece products); every problem carries split-packed weights (p.Ws).
 int launch_grouped_split(const EposPointwiseArgs* args, int count, hipStream_t s,

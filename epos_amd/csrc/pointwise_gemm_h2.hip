@@ -1064,7 +1064,14 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
       if (args[i].R) {
         for (int j = 0; j < count; ++j) {
           const int rc = launch_grouped_h2(args + j, 1, s, nullptr, nullptr);
-          if (rc) return rc;
+          if (rc) {       // say which problem failed: the ones before it are already enqueued
+            char inner[400];
+            snprintf(inner, sizeof(inner), "%s", epos_last_error());
+            set_error("epos_pointwise_conv_grouped_f32: problem %d of %d (a group with residuals "
+                      "is issued problem by problem; 0..%d are enqueued): %s", j, count, j - 1,
+                      inner);
+            return rc;
+          }
         }
         return EPOS_OK;
       }

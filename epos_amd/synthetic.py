@@ -114,11 +114,16 @@ def planted_scene(index, store, targets, K, out_h, out_w, num_objs, num_frags, s
     sizes = np.asarray(store.frag_sizes[obj_id], np.float64)
     depth = np.full(P, np.inf)
     X = np.zeros((P, 3))
+    placed = []
     for _ in range(int(targets[obj_id])):
       R = _random_rotation(rng)
       tz = rng.uniform(*depth_mm)
-      px = rng.uniform(0.2, 0.8) * W_in
-      py = rng.uniform(0.2, 0.8) * H_in
+      for _try in range(50):      # instances of one object do not hide each other (much)
+        px = rng.uniform(0.2, 0.8) * W_in
+        py = rng.uniform(0.2, 0.8) * H_in
+        if all((px - qx) ** 2 + (py - qy) ** 2 > (0.3 * W_in) ** 2 for qx, qy in placed):
+          break
+      placed.append((px, py))
       t = (Kinv @ np.array([px, py, 1.0])) * tz
       poses.append((obj_id, R, t.reshape(3, 1)))
       # ray / ellipsoid intersection in the object frame: |(o + s d) / r| = 1

@@ -176,7 +176,11 @@ int epos_pointwise_conv_f32(const EposPointwiseArgs* args, void* stream);
 /* Grouped form: `count` (1..8) independent problems in ONE launch, so that small
  * problems (the four ASPP branches, the three logit heads, a shortcut next to a
  * separable conv) fill the chip together. All problems of a group must agree on
- * relu_in and on whether a residual is present. */
+ * relu_in, on a_presplit and on whether a residual is present. On the fp16-pair kernel a
+ * group WITH residuals is issued as `count` consecutive launches (same bits: an element's value
+ * does not depend on the launch that computes it; the one-launch form with residuals measured
+ * no better and left the library in ABI 7); if one of them fails the earlier ones are already
+ * enqueued and epos_last_error() names the failing problem's index. */
 int epos_pointwise_conv_grouped_f32(const EposPointwiseArgs* args, int count,
                                     void* stream);
 

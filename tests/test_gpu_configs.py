@@ -9,6 +9,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _ref_lib():
+  from epos_amd import build
+  return build.REF_LIB_PATH
+
+
 def _oracle_chain(pipe, store, pred, slots, wants, Ks, seed):
   from oracle import corresp_ref, pnp_ref
   exp = []
@@ -272,7 +277,10 @@ def test_c2_full_size_split_gemm_not_less_accurate_than_fp32_mfma(tmp_path, tail
   for mode in ('1', '0'):
     path = str(tmp_path / ('logits_%s.npz' % mode))
     procs[mode] = (path, subprocess.Popen(
-        [sys.executable, '-c', script, path], env=dict(os.environ, EPOS_GEMM_SPLIT=mode),
+        [sys.executable, '-c', script, path],
+        # mode '0' = the whole plan on the fp32-MFMA kernels: they live in the test build
+        env=dict(os.environ, EPOS_GEMM_SPLIT=mode,
+                 **({'EPOS_HIP_LIB': _ref_lib()} if mode == '0' else {})),
         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
   from epos_amd import synthetic
   ckpt = weights.random_init(num_objs=O, seed=0, randomize_bn=True, logits_std=0.2)

@@ -15,9 +15,17 @@ EPS = 2.0 ** -24
 
 @pytest.fixture(scope='module')
 def lib():
+  """The TEST build of the library (libepos_hip_ref.so: the product library's own objects +
+  the fp32-MFMA reference GEMM kernels of csrc/ref/): this module runs the product kernels
+  against the fp32-MFMA kernel side by side, which the product library no longer carries."""
   from epos_amd import _lib
   assert torch.cuda.is_available(), 'GPU tests need a HIP device'
-  return _lib.load()
+  return _lib.load_ref()
+
+
+def _check(rc, what=''):
+  from epos_amd import _lib
+  return _lib.check(rc, what, lib=_lib.load_ref())
 
 
 @pytest.fixture(autouse=True, params=['tile128', 'tile64'])
@@ -86,7 +94,7 @@ def _gemm(lib, a, w, kind, bias=None, res=None, relu=0, a_amax=None, a_gain=0.0,
                             a_amax=_p(a_amax) if a_amax is not None else None,
                             a_gain=a_gain, a_bias=a_bias,
                             c_amax=_p(c_amax) if c_amax is not None else None)
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   return C.cpu().numpy()
 
@@ -119,7 +127,7 @@ def test_pointwise_gemm_h2_ring(lib, k, m, n, aligned, res):
   args = _lib.PointwiseArgs(A=_p(A), lda=lda, Wp=_p(Wp), bias=_p(Bd),
                             R=_p(R) if res else None, ldr=n, C=_p(C, off), ldc=ldc,
                             M=m, N=n, K=k, relu=res, relu_in=0, sub=1, Wh=_p(Wh))
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   out = C.cpu().numpy()
   ref = a.astype(np.float64) @ w.astype(np.float64) + bias
@@ -215,7 +223,7 @@ def test_h2_subnormal_weight_pieces_reach_the_matrix_pipe(lib):
   slot = _slot()
   A = torch.from_numpy(a).cuda()
   from epos_amd import _lib
-  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+  _check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
   c = _gemm(lib, a, w, 'h2', a_amax=slot).astype(np.float64)
   ref = a.astype(np.float64) @ w.astype(np.float64)
   assert np.abs(ref).min() > 0 and (c != 0).all()
@@ -250,7 +258,7 @@ def test_h2_result_does_not_depend_on_the_bound(lib):
   for gain, bias in ((0.0, 0.0), (8.0, 0.0), (1.0, 3.7), (1000.0, 50.0)):
     slot = _slot()
     A = torch.from_numpy(a).cuda()
-    _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+    _check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
     torch.cuda.synchronize()
     assert _slot_value(slot) == np.abs(a).max()
     c = _gemm(lib, a, w, 'h2', a_amax=slot, a_gain=gain, a_bias=bias)
@@ -261,7 +269,7 @@ def test_h2_result_does_not_depend_on_the_bound(lib):
   ref = a2.astype(np.float64) @ w.astype(np.float64)
   slot = _slot()
   A = torch.from_numpy(a2).cuda()
-  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+  _check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
   c = _gemm(lib, a2, w, 'h2', a_amax=slot, a_gain=1000.0, a_bias=50.0)
   bound = 1000.0 * np.abs(a2).max() + 50.0
   floor = 2.0 ** -50 * 2 * bound * np.abs(w).astype(np.float64).sum(0)
@@ -295,10 +303,10 @@ def test_absmax_kernel(lib):
     x[:, cols:] = 1e9                                        # outside the window
     X = torch.from_numpy(x).cuda()
     slot = _slot()
-    _lib.check(lib.epos_absmax_f32(_p(X), ldx, rows, cols, _p(slot), None))
+    _check(lib.epos_absmax_f32(_p(X), ldx, rows, cols, _p(slot), None))
     torch.cuda.synchronize()
     assert _slot_value(slot) == np.abs(x[:, :cols]).max()
-    _lib.check(lib.epos_amax_clear(_p(slot), 1, None))
+    _check(lib.epos_amax_clear(_p(slot), 1, None))
     torch.cuda.synchronize()
     assert _slot_value(slot) == 0.0
 
@@ -323,7 +331,7 @@ def test_h2_bits_do_not_depend_on_the_tile(lib, m, k, n, res, relu):
       lib.epos_set_h2_narrow_tile_limit(limit)
       slot_a, slot_c = _slot(), _slot()
       A = torch.from_numpy(a).cuda()
-      _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot_a), None))
+      _check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot_a), None))
       c = _gemm(lib, a, w, 'h2', bias=bias, res=r, relu=relu, a_amax=slot_a, c_amax=slot_c)
       outs.append((c, _slot_value(slot_c)))
   finally:
@@ -362,7 +370,7 @@ def test_h2_grouped_and_strided(lib):
                                 Wh=_p(Wh))
     outs.append(C)
     refs.append(x[:, ::2, ::2, :].reshape(-1, cin).astype(np.float64) @ w)
-  _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
+  _check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
   torch.cuda.synchronize()
   for C, ref in zip(outs, refs):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
@@ -378,7 +386,7 @@ def test_h2_group_with_residuals_equals_the_single_launches(lib):
   a = rng.standard_normal((m, k)).astype(np.float32)
   A = torch.from_numpy(a).cuda()
   slot = _slot()
-  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+  _check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
   arr = (_lib.PointwiseArgs * 2)()
   keep, singles, grouped = [], [], []
   for i, n in enumerate((200, 64)):
@@ -390,10 +398,10 @@ def test_h2_group_with_residuals_equals_the_single_launches(lib):
     kw = dict(A=_p(A), lda=k, Wp=_p(Wp), bias=None, R=_p(r), ldr=n, ldc=n, M=m, N=n, K=k,
               relu=1, relu_in=0, sub=1, Wh=_p(Wh), a_amax=_p(slot))
     one = _lib.PointwiseArgs(C=_p(C1), **kw)
-    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(one), None))
+    _check(lib.epos_pointwise_conv_f32(ctypes.byref(one), None))
     arr[i] = _lib.PointwiseArgs(C=_p(C2), **kw)
     singles.append(C1); grouped.append(C2)
-  _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 2, None))
+  _check(lib.epos_pointwise_conv_grouped_f32(arr, 2, None))
   torch.cuda.synchronize()
   for c1, c2 in zip(singles, grouped):
     assert torch.equal(c1, c2) and float(c1.abs().max()) > 0
@@ -429,12 +437,12 @@ def test_conv3x3_implicit_gemm_h2(lib, b, h, w, cin, cout, stride, rate):
   Bd = torch.from_numpy(bpad).cuda()
   Y = torch.full((b, ho, wo, cout), -3.0, device='cuda')
   xs, ys = _slot(), _slot()
-  _lib.check(lib.epos_absmax_f32(_p(X), cin, b * h * w, cin, _p(xs), None))
+  _check(lib.epos_absmax_f32(_p(X), cin, b * h * w, cin, _p(xs), None))
   args = _lib.Conv3x3Args(X=_p(X), ldx=cin, Wp=_p(Wp), bias=_p(Bd), Y=_p(Y), ldy=cout,
                           B=b, H=h, W=w, Cin=cin, Cout=cout, stride=stride, rate=rate,
                           relu=1, Wh=_p(Wh), x_amax=_p(xs),
                           y_amax=_p(ys) if cout % 4 == 0 else None)
-  _lib.check(lib.epos_conv3x3_f32(ctypes.byref(args), None))
+  _check(lib.epos_conv3x3_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   got = Y.cpu().numpy()
   np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-4)
@@ -566,7 +574,7 @@ def test_depthwise_fp16_pair_output_and_presplit_gemm(lib, hi, wi, c, stride, ra
   X = torch.from_numpy(x).cuda()
   W9, Bd = torch.from_numpy(w9c).cuda(), torch.from_numpy(bias).cuda()
   xs = _slot()
-  _lib.check(lib.epos_absmax_f32(_p(X), c, b * hi * wi, c, _p(xs), None))
+  _check(lib.epos_absmax_f32(_p(X), c, b * hi * wi, c, _p(xs), None))
   gain = float(np.abs(w9c.astype(np.float64)).sum(0).max())
   bias0 = float(np.abs(bias).max())
   outs = {}
@@ -576,7 +584,7 @@ def test_depthwise_fp16_pair_output_and_presplit_gemm(lib, hi, wi, c, stride, ra
                               Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c, stride=stride, rate=rate,
                               relu_in=relu_in, relu_out=relu_out, y_h2=h2, x_amax=_p(xs),
                               gain=gain, bias0=bias0)
-    _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(args), None))
+    _check(lib.epos_depthwise3x3_f32(ctypes.byref(args), None))
     torch.cuda.synchronize()
     outs[h2] = Y
   y32 = outs[0].cpu().numpy()
@@ -600,7 +608,7 @@ def test_depthwise_fp16_pair_output_and_presplit_gemm(lib, hi, wi, c, stride, ra
     a = _lib.PointwiseArgs(A=_p(outs[h2]), lda=c, Wp=_p(Wp), bias=None, R=None, ldr=0, C=_p(C),
                            ldc=n, M=b * ho * wo, N=n, K=c, relu=0, relu_in=0, sub=1,
                            Wh=_p(Wh), a_amax=_p(xs), a_gain=gain, a_bias=bias0, a_presplit=h2)
-    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+    _check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
     torch.cuda.synchronize()
     res[h2] = C.cpu().numpy()
   assert np.array_equal(res[0], res[1])
@@ -618,7 +626,7 @@ def test_presplit_needs_the_fp16_pair_kernel(lib):
   a = _lib.PointwiseArgs(A=_p(A), lda=32, Wp=_p(Wp), bias=None, R=None, ldr=0, C=_p(C), ldc=32,
                          M=64, N=32, K=32, relu=0, relu_in=0, sub=1, a_presplit=1)
   with pytest.raises(_lib.EposError):
-    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+    _check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
 
 
 # ------------------------------- fused separable conv on the fp16-pair kernel (round 4) ---
@@ -641,7 +649,7 @@ def _sepconv_h2_problem(lib, b, h, w, cin, cout, rate, relu_in, relu_out, res, s
            bias=torch.from_numpy(bpad).cuda(),
            R=torch.from_numpy(rng.standard_normal((m, cout)).astype(np.float32)).cuda(),
            xs=_slot())
-  _lib.check(lib.epos_absmax_f32(_p(t['X']), cin, m, cin, _p(t['xs']), None))
+  _check(lib.epos_absmax_f32(_p(t['X']), cin, m, cin, _p(t['xs']), None))
   gain = float(np.abs(w9c.astype(np.float64)).sum(0).max())
   bias0 = float(np.abs(dbias).max())
 
@@ -673,12 +681,12 @@ def test_separable_conv_one_call_form(lib, b, h, w, cin, cout, rate, relu_in, re
   assert t['Wh'] is not None
   T0 = torch.full((m, cin), 3.0, device='cuda'); C0 = torch.zeros(m, cout, device='cuda')
   dw, pw, _ = make(T0, C0)
-  _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))
+  _check(lib.epos_depthwise3x3_f32(ctypes.byref(dw), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(pw), None))
   torch.cuda.synchronize()
   T1 = torch.full((m, cin), 7.0, device='cuda'); C1 = torch.full((m, cout), -1.0, device='cuda')
   _, _, sa = make(T1, C1)
-  _lib.check(lib.epos_separable_conv_f32(ctypes.byref(sa), None))
+  _check(lib.epos_separable_conv_f32(ctypes.byref(sa), None))
   torch.cuda.synchronize()
   assert torch.equal(T1.view(torch.int32), T0.view(torch.int32))
   assert torch.equal(C1, C0)
@@ -720,7 +728,7 @@ def test_block_sums_in_the_epilogue_give_the_image_pooling_mean(lib, b, hw, k, n
   w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
   A = torch.from_numpy(a).cuda()
   slot = _slot()
-  _lib.check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
+  _check(lib.epos_absmax_f32(_p(A), k, m, k, _p(slot), None))
   Wp, Wh = _pack(lib, w), _pack(lib, w, 'h2')
   bias = torch.from_numpy(np.pad(rng.standard_normal(n).astype(np.float32), (0, (-n) % 128))).cuda()
   blocks = (hw + 31) // 32
@@ -733,10 +741,10 @@ def test_block_sums_in_the_epilogue_give_the_image_pooling_mean(lib, b, hw, k, n
     args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=_p(bias), R=None, ldr=0, C=_p(C),
                               ldc=n, M=m, N=n, K=k, relu=relu, relu_in=0, sub=1, Wh=_p(Wh),
                               a_amax=_p(slot), col_sums=_p(part) if with_sums else None, col_ld=n)
-    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+    _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
     Y = torch.zeros(b, n, device='cuda')
     if with_sums:
-      _lib.check(lib.epos_global_avg_pool_partial_f32(_p(part), n, _p(Y), b, blocks, n, hw, None))
+      _check(lib.epos_global_avg_pool_partial_f32(_p(part), n, _p(Y), b, blocks, n, hw, None))
     torch.cuda.synchronize()
     outs.append((C, Y))
   assert torch.equal(outs[0][0], outs[1][0])                    # C untouched by the extra output
@@ -755,7 +763,7 @@ def test_block_sums_need_the_fp16_pair_kernel(lib):
   a = _lib.PointwiseArgs(A=_p(A), lda=32, Wp=_p(Wp), bias=None, R=None, ldr=0, C=_p(C), ldc=32,
                          M=64, N=32, K=32, relu=0, relu_in=0, sub=1, col_sums=_p(part), col_ld=32)
   with pytest.raises(_lib.EposError):
-    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
+    _check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
 
 
 def test_first_fp16_pair_launch_inside_a_capture_is_refused_not_broken(tmp_path):

@@ -14,9 +14,17 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope='module')
 def lib():
+  """The TEST build of the library (libepos_hip_ref.so: the product library's own objects +
+  the fp32-MFMA reference GEMM kernels of csrc/ref/): this module runs the product kernels
+  against the fp32-MFMA kernel side by side, which the product library no longer carries."""
   from epos_amd import _lib
   assert torch.cuda.is_available(), 'GPU tests need a HIP device'
-  return _lib.load()
+  return _lib.load_ref()
+
+
+def _check(rc, what=''):
+  from epos_amd import _lib
+  return _lib.check(rc, what, lib=_lib.load_ref())
 
 
 def _p(t, off=0):
@@ -53,7 +61,7 @@ def test_pointwise_gemm(lib, m, k, n, relu, relu_in, res):
   args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=_p(Bd),
                             R=_p(R) if res else None, ldr=n, C=_p(C, 3), ldc=ldc,
                             M=m, N=n, K=k, relu=relu, relu_in=relu_in, sub=1)
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   out = C.cpu().numpy()
   aa = np.maximum(a, 0) if relu_in else a
@@ -93,7 +101,7 @@ def test_pointwise_gemm_dma_ring(lib, k, m, n, aligned, res):
   args = _lib.PointwiseArgs(A=_p(A), lda=lda, Wp=_p(Wp), bias=_p(Bd),
                             R=_p(R) if res else None, ldr=n, C=_p(C, off), ldc=ldc,
                             M=m, N=n, K=k, relu=res, relu_in=0, sub=1)
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   out = C.cpu().numpy()
   ref = a.astype(np.float64) @ w.astype(np.float64) + bias
@@ -142,7 +150,7 @@ def test_pointwise_gemm_split_ring(lib, k, m, n, aligned, res):
   args = _lib.PointwiseArgs(A=_p(A), lda=lda, Wp=_p(Wp), bias=_p(Bd),
                             R=_p(R) if res else None, ldr=n, C=_p(C, off), ldc=ldc,
                             M=m, N=n, K=k, relu=res, relu_in=0, sub=1, Ws=_p(Ws))
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   out = C.cpu().numpy()
   ref = a.astype(np.float64) @ w.astype(np.float64) + bias
@@ -174,7 +182,7 @@ def test_pointwise_gemm_split_grouped_and_strided(lib):
                                 Ws=_p(Ws))
     outs.append(C)
     refs.append(x[:, ::2, ::2, :].reshape(-1, cin).astype(np.float64) @ w)
-  _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
+  _check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
   torch.cuda.synchronize()
   for C, ref in zip(outs, refs):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
@@ -198,7 +206,7 @@ def test_pointwise_gemm_split_accuracy(lib, m, k, n):
     args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=None, R=None, ldr=0,
                               C=_p(C), ldc=n, M=m, N=n, K=k, relu=0, relu_in=0, sub=1,
                               Ws=_p(ws) if ws is not None else None)
-    _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+    _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
     torch.cuda.synchronize()
     e = np.abs(C.cpu().numpy().astype(np.float64) - ref) / mag
     errs[name] = (float(np.sqrt((e * e).mean())), float(e.max()))
@@ -229,7 +237,7 @@ def test_pointwise_gemm_dma_grouped_and_strided(lib):
                                 relu_in=0, sub=sub, Ho=ho, Wo=wo, Hi=hi, Wi=wi)
     outs.append(C)
     refs.append(x[:, ::2, ::2, :].reshape(-1, cin).astype(np.float64) @ w)
-  _lib.check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
+  _check(lib.epos_pointwise_conv_grouped_f32(arr, 3, None))
   torch.cuda.synchronize()
   for C, ref in zip(outs, refs):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
@@ -246,7 +254,7 @@ def test_pointwise_gemm_layout_is_not_transposed(lib):
   args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=None, R=None, ldr=0,
                             C=_p(C), ldc=n, M=k, N=n, K=k, relu=0, relu_in=0,
                             sub=1)
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   assert np.array_equal(C.cpu().numpy(), w)
 
 
@@ -268,7 +276,7 @@ def test_pointwise_stride2_shortcut(lib):
                             ldr=0, C=_p(C), ldc=cout, M=b * ho * wo, N=cout,
                             K=cin, relu=0, relu_in=0, sub=2, Ho=ho, Wo=wo, Hi=hi,
                             Wi=wi)
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
 
 
@@ -307,7 +315,7 @@ def test_conv3x3_implicit_gemm(lib, b, h, w, cin, cout, stride, rate, split):
   args = _lib.Conv3x3Args(X=_p(X), ldx=cin, Wp=_p(Wp), bias=_p(Bd), Y=_p(Y), ldy=cout,
                           B=b, H=h, W=w, Cin=cin, Cout=cout, stride=stride, rate=rate,
                           relu=1, Ws=_p(Ws) if split else None)
-  _lib.check(lib.epos_conv3x3_f32(ctypes.byref(args), None))
+  _check(lib.epos_conv3x3_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
 
@@ -347,7 +355,7 @@ def test_depthwise(lib, hi, wi, c, stride, rate, relu_in, relu_out):
                             ldy=c, B=b, Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c,
                             stride=stride, rate=rate, relu_in=relu_in,
                             relu_out=relu_out)
-  _lib.check(lib.epos_depthwise3x3_f32(ctypes.byref(args), None))
+  _check(lib.epos_depthwise3x3_f32(ctypes.byref(args), None))
   np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
@@ -376,13 +384,13 @@ def test_stem_conv_im2col_gemm(lib, hi, wi, cin, cout, stride, pre):
   ia = _lib.Im2colArgs(X=_p(X), ldx=cin, col=_p(col), ldcol=ld, B=b, Hi=hi, Wi=wi,
                        Ho=ho, Wo=wo, C=cin, stride=stride, rate=1, pad=1,
                        preprocess=pre)
-  _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(ia), None))
+  _check(lib.epos_im2col3x3_f32(ctypes.byref(ia), None))
   wk = np.zeros((ld, cout), np.float32); wk[:k] = w.reshape(k, cout)
   C = torch.zeros(b * ho * wo, cout, device='cuda')
   args = _lib.PointwiseArgs(A=_p(col), lda=ld, Wp=_p(_pack(lib, wk)), bias=None,
                             R=None, ldr=0, C=_p(C), ldc=cout, M=b * ho * wo,
                             N=cout, K=ld, relu=0, relu_in=0, sub=1)
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   np.testing.assert_allclose(C.cpu().numpy().reshape(ref.shape), ref, rtol=1e-4,
                              atol=1e-4)
 
@@ -397,13 +405,13 @@ def test_slim_conv2d_same_kat_on_device(lib):
   col = torch.zeros(4, 12, device='cuda')
   ia = _lib.Im2colArgs(X=_p(X), ldx=1, col=_p(col), ldcol=12, B=1, Hi=4, Wi=4,
                        Ho=2, Wo=2, C=1, stride=2, rate=1, pad=1, preprocess=0)
-  _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(ia), None))
+  _check(lib.epos_im2col3x3_f32(ctypes.byref(ia), None))
   wk = np.zeros((12, 1), np.float32); wk[:9] = w
   C = torch.zeros(4, 1, device='cuda')
   args = _lib.PointwiseArgs(A=_p(col), lda=12, Wp=_p(_pack(lib, wk)), bias=None,
                             R=None, ldr=0, C=_p(C), ldc=1, M=4, N=1, K=12, relu=0,
                             relu_in=0, sub=1)
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   assert C.cpu().numpy().reshape(2, 2).tolist() == [[14, 43], [43, 84]]
 
 
@@ -415,21 +423,21 @@ def test_global_avg_pool_and_resize(lib):
   x = rng.standard_normal((b, h, w, c)).astype(np.float32)
   X = torch.from_numpy(x).cuda()
   Y = torch.zeros(b, c, device='cuda')
-  _lib.check(lib.epos_global_avg_pool_f32(_p(X), c, _p(Y), b, h * w, c, None))
+  _check(lib.epos_global_avg_pool_f32(_p(X), c, _p(Y), b, h * w, c, None))
   np.testing.assert_allclose(Y.cpu().numpy(), x.mean(axis=(1, 2)), rtol=1e-5,
                              atol=1e-6)
   for (ho, wo) in [(29, 39), (30, 40), (h, w)]:
     ref = net_ref.resize_bilinear_align_corners(
         torch.from_numpy(x).permute(0, 3, 1, 2), (ho, wo)).permute(0, 2, 3, 1).numpy()
     Z = torch.zeros(b, ho, wo, c + 8, device='cuda')
-    _lib.check(lib.epos_resize_bilinear_f32(_p(X), c, _p(Z, 4), c + 8, b, h, w, ho,
+    _check(lib.epos_resize_bilinear_f32(_p(X), c, _p(Z, 4), c + 8, b, h, w, ho,
                                             wo, c, None))
     np.testing.assert_allclose(Z.cpu().numpy()[..., 4:4 + c], ref, rtol=1e-5,
                                atol=1e-5)
   # broadcast from 1x1 (image pooling branch)
   P1 = torch.from_numpy(x[:, :1, :1, :].copy()).cuda()
   Z = torch.zeros(b, 6, 7, c, device='cuda')
-  _lib.check(lib.epos_resize_bilinear_f32(_p(P1), c, _p(Z), c, b, 1, 1, 6, 7, c,
+  _check(lib.epos_resize_bilinear_f32(_p(P1), c, _p(Z), c, b, 1, 1, 6, 7, c,
                                           None))
   assert np.array_equal(Z.cpu().numpy(), np.broadcast_to(x[:, :1, :1, :],
                                                          (b, 6, 7, c)))
@@ -444,8 +452,8 @@ def test_softmax_and_argmax(lib, g):
   x[5, :] = 1.25                                    # exact tie -> first index
   X = torch.from_numpy(x).cuda()
   lab = torch.zeros(n, dtype=torch.int64, device='cuda')
-  _lib.check(lib.epos_softmax_groups_f32(_p(X), n, g, None))
-  _lib.check(lib.epos_argmax_i64(_p(X), g, _p(lab), n, g, None))
+  _check(lib.epos_softmax_groups_f32(_p(X), n, g, None))
+  _check(lib.epos_argmax_i64(_p(X), g, _p(lab), n, g, None))
   ref = torch.softmax(torch.from_numpy(x), dim=-1).numpy()
   out = X.cpu().numpy()
   np.testing.assert_allclose(out, ref, rtol=2e-6, atol=1e-7)
@@ -457,7 +465,7 @@ def test_clock_probe_reports_a_plausible_core_clock(lib):
   """epos_clock_probe: shader cycles per 100 MHz tick while a wave spins for 200 us."""
   from epos_amd import _lib
   out = torch.zeros(2, dtype=torch.int64, device='cuda')
-  _lib.check(lib.epos_clock_probe(_p(out), 200, None))
+  _check(lib.epos_clock_probe(_p(out), 200, None))
   torch.cuda.synchronize()
   cyc, ticks = [int(v) for v in out.cpu()]
   assert 19000 <= ticks <= 40000                    # ~200 us of the 100 MHz counter
@@ -500,6 +508,9 @@ for (m, k, n) in [(700, 728, 200), (16500, 80, 520)]:
   np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
 print('ok')
 ''' % root
+  if env.get('EPOS_GEMM_SPLIT') == '0':       # the fp32-MFMA kernels live in the test build
+    from epos_amd import build
+    env = dict(env, EPOS_HIP_LIB=build.REF_LIB_PATH)
   r = subprocess.run([sys.executable, '-c', script], env=dict(os.environ, **env),
                      capture_output=True, text=True, timeout=600)
   assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
@@ -522,7 +533,7 @@ def _split_vs_fp32(lib, a, w, split):
   args = _lib.PointwiseArgs(A=_p(A), lda=k, Wp=_p(Wp), bias=None, R=None, ldr=n, C=_p(C),
                             ldc=n, M=m, N=n, K=k, relu=0, relu_in=0, sub=1,
                             Ws=_p(Ws) if split else None)
-  _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
+  _check(lib.epos_pointwise_conv_f32(ctypes.byref(args), None))
   torch.cuda.synchronize()
   return C.cpu().numpy().astype(np.float64)
 
@@ -608,11 +619,11 @@ def test_im2col_can_clear_the_absmax_slot_table(lib):
     a = _lib.Im2colArgs(X=_p(X), ldx=3, col=_p(col), ldcol=ld, B=1, Hi=20, Wi=24, Ho=ho, Wo=wo,
                         C=3, stride=2, rate=1, pad=1, preprocess=1,
                         amax_clear=_p(table) if clear else None, amax_words=37 * 64)
-    _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(a), None))
+    _check(lib.epos_im2col3x3_f32(ctypes.byref(a), None))
     torch.cuda.synchronize()
     cols.append(col)
     assert int(table.abs().sum()) == (0 if clear else 37 * 64 * 0x3f800000)
   assert torch.equal(cols[0], cols[1])
   a.amax_words = ho * wo * ld + 1
   with pytest.raises(_lib.EposError):
-    _lib.check(lib.epos_im2col3x3_f32(ctypes.byref(a), None))
+    _check(lib.epos_im2col3x3_f32(ctypes.byref(a), None))

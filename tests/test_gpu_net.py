@@ -9,6 +9,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _ref_lib():
+  from epos_amd import build
+  return build.REF_LIB_PATH
+
+
 @pytest.mark.parametrize('h,w,num_objs,batch', [(96, 128, 2, 1), (65, 97, 1, 2)])
 def test_net_matches_oracle(h, w, num_objs, batch):
   from epos_amd import model, weights
@@ -145,7 +150,10 @@ def test_split_gemm_network_is_not_less_accurate_than_fp32_mfma(tmp_path):
   for mode in ('1', '0'):
     path = str(tmp_path / ('logits_%s.npz' % mode))
     procs[mode] = (path, subprocess.Popen(
-        [sys.executable, '-c', script, path], env=dict(os.environ, EPOS_GEMM_SPLIT=mode),
+        [sys.executable, '-c', script, path],
+        # mode '0' = the whole plan on the fp32-MFMA kernels: they live in the test build
+        env=dict(os.environ, EPOS_GEMM_SPLIT=mode,
+                 **({'EPOS_HIP_LIB': _ref_lib()} if mode == '0' else {})),
         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
   ckpt = weights.random_init(num_objs=num_objs, seed=3, randomize_bn=True, logits_std=0.2)
   img = np.random.RandomState(0).randint(0, 256, (1, h, w, 3)).astype('f')

@@ -281,3 +281,22 @@ def test_heavy_tailed_checkpoint_stays_on_the_fp16_pair_kernel():
     assert total > 0, key
     n_mat += 1
   assert n_mat == 81          # every conv / logits matrix of xception_65 + heads
+
+
+def test_product_library_carries_no_fp32_mfma_gemm_and_the_test_build_does():
+  """Round 6 hygiene: the default library is the fp16-pair kernel, its
+  bf16 x 6 fallback, the layer / correspondence / fitting kernels. The fp32-MFMA GEMM families of
+  rounds 1-2 are only in libepos_hip_ref.so (same C ABI, every declared symbol), where the
+  accuracy tests compare against them."""
+  from epos_amd import _lib, build
+  build.build()
+  ref = build.build_ref()
+  prod = open(build.LIB_PATH, 'rb').read()
+  test = open(ref, 'rb').read()
+  for kern in (b'pointwise_gemm_dma_f32', b'pointwise_gemm_wp_f32'):
+    assert kern not in prod and kern in test, kern
+  for kern in (b'pointwise_gemm_h2_f32', b'pointwise_gemm_split_f32', b'pointwise_gemv_f32'):
+    assert kern in prod and kern in test, kern
+  lib = ctypes.CDLL(ref)
+  for name in _lib.SYMBOLS:
+    assert hasattr(lib, name), name

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box comparison of bench.py argument sets (interleaved, REPS rounds):
-#   bash tools/ab_args.sh "" "--cu-partitions 4" "--cu-partitions 4 --pipeline-depth 8"
+#   bash tools/ab_args.sh "" "--pipeline-depth 2" "--sparse-heads --pipeline-depth 4"
 # extra environment / common arguments: COMMON="--steps 40 ..." (default below)
 COMMON=${COMMON:---steps 40 --warmup 8 --no-cpu-baseline --traffic off}
 for rep in $(seq ${REPS:-2}); do for A in "$@"; do

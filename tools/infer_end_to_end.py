@@ -116,8 +116,9 @@ def run_infer(models, data, name, tag, extra, log):
   thr = [l for l in out.stdout.split('\n') if l.startswith('Throughput:')][-1]
   plan = [l for l in out.stdout.split('\n') if l.startswith('plan:')][-1]
   m = re.search(r'= ([0-9.]+) images/s \(inference loop ([0-9.]+) s = ([0-9.]+) images/s', thr)
-  stage = [re.findall(r'([a-z_]+): ([0-9.]+)', l) for l in out.stdout.split('\n')
-           if l.startswith('Image:')]
+  stage = [re.findall(r'(prediction|establish_corr|fitting|total time): ([0-9.]+)', l)
+           for l in out.stdout.split('\n') if l.startswith('Image:')]
+  host = [l for l in out.stdout.split('\n') if l.startswith('Host time per step')]
   mean = {}
   for row in stage[len(stage) // 10:]:
     for k, v in row:
@@ -128,6 +129,7 @@ def run_infer(models, data, name, tag, extra, log):
           'loop_images_per_s': float(m.group(3)), 'process_wall_s': round(wall, 1), 'plan': plan,
           'mean_stage_ms': {k: round(v * 1e3, 3) for k, v in mean.items()},
           'rows': [','.join(r.split(',')[:-1]) for r in rows], 'n_rows': len(rows) - 1,
+          'host': host[-1] if host else '',
           'csv_bytes': os.path.getsize(csv)}
 
 
@@ -173,8 +175,8 @@ def main():
       continue
     runs.append(r)
     log('infer.py %-16s %7.1f images/s first decode -> CSV (loop %7.1f); %d poses; %s; mean '
-        'per-image stage ms %s' % (tag, r['images_per_s'], r['loop_images_per_s'], r['n_rows'],
-                                   r['plan'], r['mean_stage_ms']))
+        'per-image stage ms %s; %s' % (tag, r['images_per_s'], r['loop_images_per_s'],
+                                       r['n_rows'], r['plan'], r['mean_stage_ms'], r['host']))
   if runs:
     base = runs[0]
     for r in runs[1:]:

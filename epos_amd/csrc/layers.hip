@@ -48,11 +48,23 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
                                                            int c4n,
                                                            int64_t total) {
   EPOS_SET_PRIO(EPOS_DW_PRIO);
-  const int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  int64_t id = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const bool h2 = p.y_h2 != 0;                 // uniform
-  float hs = 1.f, hinv;
-  if (h2) h2_scale(p.x_amax, p.x_amax2, p.gain, p.bias0, threadIdx.x & 63, hs, hinv);
-  if (id >= total) return;
+  // the output scale's slot word is requested first and reduced behind the taps' loads (see
+  // depthwise3x3_s1_kernel); lanes past the end stay for the wave-wide reduction, recompute
+  // the last item and store nothing
+  float hs = 1.f;
+  unsigned am_raw, am_raw2;
+  {
+    const unsigned* s1 = h2 ? p.x_amax : reinterpret_cast<const unsigned*>(p.bias);
+    const unsigned* s2 = (h2 && p.x_amax2) ? p.x_amax2 : s1;
+    const int li = h2 ? static_cast<int>(threadIdx.x & 63) : 0;
+    am_raw = s1[li];
+    am_raw2 = s2[li];
+  }
+  const bool live = id < total;
+  if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+  id = live ? id : total - 1;
   const int c = static_cast<int>(id % c4n) * 4;
   int64_t pix = id / c4n;
   const int xo = static_cast<int>(pix % p.Wo);
@@ -76,7 +88,11 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(EposDepthwiseArgs p,
     }
   }
   if (p.relu_out) acc = relu4(acc);
-  st4_any(p.Y + ((static_cast<int64_t>(b) * p.Ho + yo) * p.Wo + xo) * p.ldy + c, acc, h2, hs);
+  if (h2) {
+    float hinv;
+    h2_scale_finish(am_raw, am_raw2, p.gain, p.bias0, hs, hinv);
+  }
+  if (live) st4_any(p.Y + ((static_cast<int64_t>(b) * p.Ho + yo) * p.Wo + xo) * p.ldy + c, acc, h2, hs);
 }
 
 // Stride-1 depthwise 3x3 with a SLIDING WINDOW: one thread = 4 channels x a run
@@ -153,9 +169,57 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
     EposDepthwiseArgs p, int c4n, int nres, int nchunk, int nrows, DwPartition part) {
   constexpr int NR = ROWS + 2;                 // input rows held per column
   EPOS_SET_PRIO(EPOS_DW_PRIO);
+  {
+    // One round trip for the kernel arguments (~70 words): left to itself the compiler
+    // fetches them where they are first used -- seven dependent scalar-load rounds in front
+    // of the first vector load of a kernel that lives ~10 us (as in the fp16-pair GEMM).
+    uint64_t a0 = reinterpret_cast<uint64_t>(p.X), a1 = reinterpret_cast<uint64_t>(p.w9c),
+             a2 = reinterpret_cast<uint64_t>(p.bias), a3 = reinterpret_cast<uint64_t>(p.Y),
+             a4 = reinterpret_cast<uint64_t>(p.x_amax), a5 = reinterpret_cast<uint64_t>(p.x_amax2),
+             l0 = static_cast<uint64_t>(p.ldx), l1 = static_cast<uint64_t>(p.ldy);
+    int i0 = p.B, i1 = p.Hi, i2 = p.Wi, i3 = p.Ho, i4 = p.Wo, i5 = p.C, i6 = p.rate, i7 = p.y_h2;
+    float f0 = p.gain, f1 = p.bias0;
+    const unsigned bd = blockDim.x;               // an implicit argument behind the explicit ones
+    asm volatile("" : : "s"(bd));
+    asm volatile("" : : "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(a4), "s"(a5), "s"(l0), "s"(l1),
+                 "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5), "s"(i6), "s"(i7), "s"(f0),
+                 "s"(f1), "s"(c4n), "s"(nres), "s"(nchunk), "s"(nrows));
+    asm volatile("" : : "s"(part.mode), "s"(part.runs), "s"(part.rows), "s"(part.dwc[0].mul),
+                 "s"(part.dwc[0].sh1), "s"(part.dwc[0].sh2), "s"(part.dwc[0].d),
+                 "s"(part.dwc[1].mul), "s"(part.dwc[1].sh1), "s"(part.dwc[1].sh2),
+                 "s"(part.dc4n.mul), "s"(part.dc4n.sh1), "s"(part.dc4n.sh2), "s"(part.dchunk.mul),
+                 "s"(part.dchunk.sh1), "s"(part.dchunk.sh2), "s"(part.dres.mul), "s"(part.dres.sh1),
+                 "s"(part.dres.sh2), "s"(part.dho.mul), "s"(part.dho.sh1), "s"(part.dho.sh2),
+                 "s"(part.drate.mul), "s"(part.drate.sh1), "s"(part.drate.sh2));
+  }
   const bool h2 = p.y_h2 != 0;                 // uniform: fp16-pair output
-  float hs = 1.f, hinv;
-  if (h2) h2_scale(p.x_amax, p.x_amax2, p.gain, p.bias0, threadIdx.x & 63, hs, hinv);
+  // The scale of an fp16-pair output comes from the absmax slot of X: a global load + a wave
+  // reduction. Only the stores need it, so the slot word is REQUESTED here -- unconditionally
+  // (a load under a branch is waited for on the spot; without y_h2 the lane reads a word of the
+  // bias vector that nobody uses) -- and the reduction runs behind the input loads
+  // (dw_scale_finish below). Until round 5 the whole of h2_scale stood here: slot load, wait,
+  // six dependent permutes, and only then the weight and input loads -- two dependent memory
+  // round trips per launch instead of one (round 6; profiles/r06/dw_scale_round_trip.txt).
+  float hs = 1.f;
+  unsigned am_raw, am_raw2;
+  {
+    const unsigned* s1 = h2 ? p.x_amax : reinterpret_cast<const unsigned*>(p.bias);
+    const unsigned* s2 = (h2 && p.x_amax2) ? p.x_amax2 : s1;
+    const int li = h2 ? static_cast<int>(threadIdx.x & 63) : 0;
+    am_raw = s1[li];
+    am_raw2 = s2[li];
+  }
+  static_assert(EPOS_DW_REP == 1, "the scale reduction sits inside the (one) run of a thread");
+  auto dw_scale_finish = [&] {
+    if (h2) {
+      float hinv;
+      // opaque: otherwise the first max of the two words is hoisted above the input loads
+      // (common to both paths) and takes the wait for the slot with it
+      unsigned r1 = am_raw, r2 = am_raw2;
+      asm volatile("" : "+v"(r1), "+v"(r2));
+      h2_scale_finish(r1, r2, p.gain, p.bias0, hs, hinv);
+    }
+  };
   const int xcd = blockIdx.x & 7;
   const unsigned local = (blockIdx.x >> 3) * blockDim.x + threadIdx.x;
   int c, chunk, res, ys, b;
@@ -195,7 +259,14 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
     y = static_cast<int>(2 * r * g + (ys - g * r));
   }
   live = live && res + chunk * (EPOS_DW_REP * L) * r < p.Wo && y < p.Ho;
-  if (!live) return;
+  // A wave without any live lane leaves. In a wave that keeps some, the dead lanes stay (the
+  // scale reduction below is wave-wide): they walk the run at the image's origin -- valid
+  // addresses, never "interior" -- and store nothing.
+  if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+  if (!live) {
+    c = part.mode == 0 ? (xcd * c4n / 8) * 4 : 0;
+    chunk = 0; res = 0; y = 0; b = 0;
+  }
   const bool row1 = ROWS == 2 && y + r < p.Ho;   // the pair's second row exists
   float4 w[9];
 #pragma unroll
@@ -224,6 +295,9 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
     for (int i = 0; i < L + 2; ++i)
 #pragma unroll
       for (int ky = 0; ky < NR; ++ky) col[i][ky] = ld4(xb + (o00 + ky * rstep + i * cstep));
+    __builtin_amdgcn_sched_barrier(0);
+    dw_scale_finish();             // behind the input loads: waits for the slot word only
+    __builtin_amdgcn_sched_barrier(0);
     if (RELU_IN) {
 #pragma unroll
       for (int i = 0; i < L + 2; ++i)
@@ -264,6 +338,9 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
 #pragma unroll
     for (int ky = 0; ky < NR; ++ky) col[i][ky] = ld4(xb + (rowoff[ky] + off));
   }
+  __builtin_amdgcn_sched_barrier(0);
+  dw_scale_finish();
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 0; i < L + 2; ++i) {
     const int xi = x0 + (i - 1) * r;
@@ -289,7 +366,7 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
         acc = fma4(col[j + 2][ky + rr], w[ky * 3 + 2], acc);
       }
       if (RELU_OUT) acc = relu4_1op(acc);
-      if (x < p.Wo) st4_any(yb + (static_cast<unsigned>(x * ldy) + (rr ? yrow1 : 0u)), acc, h2, hs);
+      if (x < p.Wo && live) st4_any(yb + (static_cast<unsigned>(x * ldy) + (rr ? yrow1 : 0u)), acc, h2, hs);
     }
   }
   }   // rep

@@ -365,7 +365,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   // latency that the first LDS-DMA stages can hide -- so it is computed AFTER the prologue's
   // DMA issue (below).
   // (Only in the variants with registers to spare: the residual ones sit at 256 VGPRs.)
-  constexpr bool LATE_SCALE = !HAS_RES;
+  constexpr bool LATE_SCALE = true;
   constexpr bool EARLY_EPI = !HAS_RES;
   float sa_v = 0.f, inv_a = 0.f, sa = 0.f;
   unsigned am_raw = 0, am_raw2 = 0;

@@ -38,8 +38,15 @@ import pickle
 import sys
 import time
 
-import numpy as np
-import torch
+# One hardware queue per pipeline stream: with the runtime's default of 4 queues the null
+# stream and the four pipeline streams (--pipeline_depth 4) make five, two pipelines share a
+# queue and serialise against each other (bench.py sets the same; without it this entry point
+# ran at 0.81 of bench.py's rate, profiles/r06/infer_end_to_end.txt). Must be in the
+# environment before the HIP runtime initialises, i.e. before torch is imported.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import numpy as np     # noqa: E402
+import torch           # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

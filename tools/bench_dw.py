@@ -26,6 +26,10 @@ def timeit(fn, warm=200, it=100):
   for _ in range(it): fn()
   e1.record(); torch.cuda.synchronize()
   return e0.elapsed_time(e1) / it * 1e3
+if '--one' in sys.argv:             # the middle-flow tensor only, few launches (PMC passes)
+  shapes = shapes[:1]
+  _t = timeit
+  timeit = lambda fn, warm=3, it=5: _t(fn, warm, it)
 for (h, w, c, rate) in shapes:
   X = torch.randn(1, h, w, c, device='cuda'); Y = torch.empty_like(X)
   w9 = torch.randn(9, c, device='cuda'); b = torch.randn(c, device='cuda')

@@ -137,7 +137,10 @@ struct DwPartition {
   int mode;        // 0: channel slices, 1: row bands
   int runs;        // mode 0: runs of the whole launch = B*Ho*nres*nchunk
   int rows;        // mode 1: B*Ho
-  FastDiv dwc[2];  // mode 0: slice widths floor(c4n/8) and floor(c4n/8)+1
+  int unit;        // mode 0: slices start on multiples of `unit` float4 (8 = one 128-byte line
+                   // when rows and base addresses are line-aligned; else 1), nu = units per row
+  int nu;
+  FastDiv dwc[3];  // mode 0: the (at most three) distinct slice widths
   FastDiv dc4n, dchunk, dres, dho;   // dho: / row slots per image
   FastDiv drate;                     // ROWS = 2: / rate (slot -> row group)
 };
@@ -186,7 +189,8 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
                  "s"(f1), "s"(c4n), "s"(nres), "s"(nchunk), "s"(nrows));
     asm volatile("" : : "s"(part.mode), "s"(part.runs), "s"(part.rows), "s"(part.dwc[0].mul),
                  "s"(part.dwc[0].sh1), "s"(part.dwc[0].sh2), "s"(part.dwc[0].d),
-                 "s"(part.dwc[1].mul), "s"(part.dwc[1].sh1), "s"(part.dwc[1].sh2),
+                 "s"(part.dwc[1].mul), "s"(part.dwc[1].sh1), "s"(part.dwc[1].sh2), "s"(part.dwc[1].d),
+                 "s"(part.dwc[2].mul), "s"(part.dwc[2].sh1), "s"(part.dwc[2].sh2), "s"(part.unit), "s"(part.nu),
                  "s"(part.dc4n.mul), "s"(part.dc4n.sh1), "s"(part.dc4n.sh2), "s"(part.dchunk.mul),
                  "s"(part.dchunk.sh1), "s"(part.dchunk.sh2), "s"(part.dres.mul), "s"(part.dres.sh1),
                  "s"(part.dres.sh2), "s"(part.dho.mul), "s"(part.dho.sh1), "s"(part.dho.sh2),
@@ -225,9 +229,13 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
   int c, chunk, res, ys, b;
   bool live = true;
   if (part.mode == 0) {
-    const int c_lo = xcd * c4n / 8, wc = (xcd + 1) * c4n / 8 - c_lo;
-    live = wc != 0 && local < static_cast<unsigned>(part.runs) * wc;
-    const FastDiv& dw = wc == static_cast<int>(part.dwc[0].d) ? part.dwc[0] : part.dwc[1];
+    const int c_lo = (xcd * part.nu / 8) * part.unit;
+    int c_hi = ((xcd + 1) * part.nu / 8) * part.unit;
+    c_hi = c_hi < c4n ? c_hi : c4n;
+    const int wc = c_hi - c_lo;
+    live = wc > 0 && local < static_cast<unsigned>(part.runs) * wc;
+    const FastDiv& dw = wc == static_cast<int>(part.dwc[0].d) ? part.dwc[0]
+                      : wc == static_cast<int>(part.dwc[1].d) ? part.dwc[1] : part.dwc[2];
     unsigned rest = fdiv(local, dw);
     c = (c_lo + static_cast<int>(local - rest * wc)) * 4;
     unsigned q = fdiv(rest, part.dchunk);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(256, (ROWS == 2 ? EPOS_DW_MIN_BLOCKS2 : EPOS_DW_MIN
   // addresses, never "interior" -- and store nothing.
   if (__builtin_amdgcn_ballot_w64(live) == 0) return;
   if (!live) {
-    c = part.mode == 0 ? (xcd * c4n / 8) * 4 : 0;
+    c = part.mode == 0 ? (xcd * part.nu / 8) * part.unit * 4 : 0;
     chunk = 0; res = 0; y = 0; b = 0;
   }
   const bool row1 = ROWS == 2 && y + r < p.Ho;   // the pair's second row exists
@@ -739,15 +747,35 @@ extern "C" int epos_depthwise3x3_f32(const EposDepthwiseArgs* a, void* stream) {
     if (c4n < 8) part.mode = 1;
     part.runs = static_cast<int>(runs);
     part.rows = a->B * nrows;
-    part.dwc[0] = fast_div(c4n / 8 > 0 ? c4n / 8 : 1);
-    part.dwc[1] = fast_div(c4n / 8 + 1);
+    // Slices that start on 128-byte lines when every pixel's channel vector does (rows of a
+    // multiple of 32 floats from line-aligned bases; the plan pads 728 -> 736): no line is then
+    // fetched by two XCDs. Otherwise slices of float4 granularity, as balanced as they get (a
+    // 728-float row has 7 slice boundaries inside lines: ~30 % of the input read twice).
+    const bool lines = a->ldx % 32 == 0 && a->ldy % 32 == 0 &&
+                       (reinterpret_cast<uintptr_t>(a->X) & 127) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a->Y) & 127) == 0 && c4n >= 64;
+    part.unit = lines ? 8 : 1;
+    part.nu = static_cast<int>(ceil_div(c4n, part.unit));
+    int widths[3] = {0, 0, 0}, nwid = 0, wmax = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int lo = (x * part.nu / 8) * part.unit;
+      int hi = ((x + 1) * part.nu / 8) * part.unit;
+      hi = hi < c4n ? hi : c4n;
+      const int wdt = hi - lo;
+      if (wdt <= 0) continue;
+      wmax = wdt > wmax ? wdt : wmax;
+      bool seen = false;
+      for (int i = 0; i < nwid; ++i) seen = seen || widths[i] == wdt;
+      if (!seen && nwid < 3) widths[nwid++] = wdt;
+    }
+    for (int i = 0; i < 3; ++i) part.dwc[i] = fast_div(widths[i] > 0 ? widths[i] : 1);
     part.dc4n = fast_div(c4n);
     part.dchunk = fast_div(nchunk);
     part.dres = fast_div(nres);
     part.dho = fast_div(nrows);
     part.drate = fast_div(a->rate);
     int64_t per_xcd;                        // items of the busiest XCD
-    if (part.mode == 0) per_xcd = runs * ceil_div(c4n, 8);
+    if (part.mode == 0) per_xcd = runs * (wmax > 0 ? wmax : 1);
     else per_xcd = ceil_div(part.rows, 8) * nres * nchunk * c4n;
     const unsigned grid = 8 * blocks_for(per_xcd, threads);
     const int v = (a->relu_in ? 2 : 0) | (a->relu_out ? 1 : 0);

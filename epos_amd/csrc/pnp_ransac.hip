@@ -341,29 +341,13 @@ struct PointBatch {
 // MSAC scores + inlier counts of `ns` (<= 4) poses over idx[0..m) in ONE pass over
 // the correspondences (wave-wide; results uniform). Each pose's sum keeps the
 // canonical order: 64 strided per-lane partials, then the xor butterfly.
-//
-// Exact pruning (round 6; `bound` != null): the round's winner is the hypothesis of maximal
-// score (ties: lowest index) and nothing else of the table is read (ransac_select_lo, arg-max
-// mode), so a wave may stop as soon as NONE of its poses can reach the best score any wave of
-// the slot has shown so far. *bound holds that score -- the maximum over the PARTIAL sums the
-// waves publish (MSAC terms are >= 0: a partial sum is a lower bound of its final sum, also in
-// floating point, every addition being monotone) -- and a pose's final score is at most its
-// partial sum + one per remaining point. A wave that stops returns false and its hypotheses
-// count as absent; the winner's wave can never stop (its own bound is >= its final score >=
-// *bound), nor can one that ties it, so winner, score, count and pose are bit-identical with
-// and without pruning. Which LOSERS stop, and when, depends on timing.
-// Under EPOS-like inlier ratios (best score ~0.4 n) a hopeless hypothesis stops after ~70 % of
-// the points; with random heads (best score ~20) nothing ever stops and the checks are spaced
-// out (every 8th batch of 256 points while the bound is far away, else every 2nd).
-constexpr double PRUNE_SLACK = 1.0;     // one whole point of margin over any rounding
-__device__ bool score_poses(const double* poses, int ns, const double* K,
+__device__ void score_poses(const double* poses, int ns, const double* K,
                             const double* xy, const double* xyz, const int32_t* idx,
                             int64_t m, double thr2, int lane, double* score,
-                            int* count, unsigned long long* bound) {
+                            int* count) {
   const double inv_thr2 = 1.0 / thr2;
   double acc[MAX_SOL] = {0.0, 0.0, 0.0, 0.0};
   int cnt[MAX_SOL] = {0, 0, 0, 0};
-  int batches = 0, next_check = 2;
   // PF items of this lane's partial are fetched together (index -> point is a dependent
   // gather: without this the loop is one memory round trip per item) and then consumed
   // in the canonical order i, i + 64, ...
@@ -384,24 +368,6 @@ __device__ bool score_poses(const double* poses, int ns, const double* K,
         }
       }
     }
-    if (bound && ++batches == next_check) {                // wave-uniform
-      const int64_t done_pts = (i0 - lane) + 64 * PF;
-      const int64_t left = m - done_pts;
-      if (left > 0) {
-        double mine = 0.0;
-#pragma unroll
-        for (int q = 0; q < MAX_SOL; ++q)
-          if (q < ns) { const double v = butterfly_sum(acc[q]); mine = v > mine ? v : mine; }
-        // non-negative doubles order like their bit patterns
-        unsigned long long seen = 0;
-        if (lane == 0)
-          seen = atomicMax(bound, static_cast<unsigned long long>(__double_as_longlong(mine)));
-        seen = __shfl(seen, 0, 64);
-        const double best = __longlong_as_double(static_cast<long long>(seen));
-        if (mine + static_cast<double>(left) + PRUNE_SLACK < best) return false;
-        next_check = batches + (static_cast<double>(left) < 4.0 * best ? 2 : 8);
-      }
-    }
   }
 #pragma unroll
   for (int q = 0; q < MAX_SOL; ++q) {
@@ -410,7 +376,6 @@ __device__ bool score_poses(const double* poses, int ns, const double* K,
       score[q] = butterfly_sum(acc[q]);
     }
   }
-  return true;
 }
 
 __device__ void bearing(const double* K, const double* xy, double* f) {
@@ -454,8 +419,6 @@ struct Work {
   double* hyp_score;     // [S][iters][4]
   double* hyp_pose;      // [S][iters][4][12]
   int32_t* hyp_count;    // [S][iters][4]
-  unsigned long long* hyp_bound;   // [S][hyp_rounds] best partial score shown so far (bits of a
-  int hyp_rounds;                  //     double >= 0; zeroed by ransac_init), or null: no pruning
   int32_t* active;       // [N] local indices, pooled by slot_base
   int32_t* n_active;     // [S]
   int32_t* done;         // [S]
@@ -549,9 +512,6 @@ __global__ __launch_bounds__(256) void ransac_init(const double* __restrict__ xy
   if (first) {
     for (int i = threadIdx.x; i < n_lo; i += blockDim.x)
       w.lo_cnt[static_cast<int64_t>(s) * n_lo + i] = 0u;
-    if (w.hyp_bound)
-      for (int i = threadIdx.x; i < w.hyp_rounds; i += blockDim.x)
-        w.hyp_bound[static_cast<int64_t>(s) * w.hyp_rounds + i] = 0ull;
     if (threadIdx.x == 0) w.nb_ok[s] = build_nb;
     if (s == 0 && threadIdx.x == 0) *w.lo_timeout = 0;
   }
@@ -675,13 +635,8 @@ __global__ __launch_bounds__(256) void ransac_hypotheses(
       int cnt[MAX_SOL];
       // while nothing has been removed the active list is the identity (ransac_init): the
       // scoring passes then index the points directly -- one dependent load per item less
-      // arg-max selection only (the sequential termination bound of proposal_engine_conf < 1
-      // reads the whole table in order: no pruning there)
-      unsigned long long* bound = (w.hyp_bound && prm.proposal_engine_conf >= 1.0)
-          ? w.hyp_bound + static_cast<int64_t>(s) * w.hyp_rounds + round : nullptr;
-      if (!score_poses(sols, ns, K, xy, xyz, n_active == n ? nullptr : active, n_active, thr2,
-                       lane, sc, cnt, bound))
-        ns = 0;                                            // pruned: cannot win the round
+      score_poses(sols, ns, K, xy, xyz, n_active == n ? nullptr : active, n_active, thr2, lane,
+                  sc, cnt);
 #pragma unroll
       for (int q = 0; q < MAX_SOL; ++q) {
         if (q < ns) {
@@ -2367,7 +2322,7 @@ struct Layout {
   int64_t words_total;
   int64_t cur_pose, cur_score, cur_count, state, tries, last_new, gq, lab_a, lab_b;
   int64_t pearl_pose, pearl_acc, pearl_state, pearl_moved, lab_c, pearl_dt;
-  int64_t lo_cnt, lo_data, lo_timeout, hyp_bound;
+  int64_t lo_cnt, lo_data, lo_timeout;
   int64_t nb_cnt, nb_pool, nb_ok;
   int64_t geo, dyn_a, dyn_b, win, acc, flip_a, flip_b;
 };
@@ -2415,7 +2370,6 @@ Layout make_layout(int S, int64_t n_cap, int max_iters, int max_k) {
   L.pearl_moved = off; off = align_up(off + (S + 1) * 4);
   L.lab_c = off; off = align_up(off + n_cap + 1);
   L.pearl_dt = off; off = align_up(off + (n_cap + 1) * PEARL_DT * 4);
-  L.hyp_bound = off; off = align_up(off + static_cast<int64_t>(S + 1) * (max_k + 2) * 8);
   L.total = off;
   return L;
 }
@@ -2434,12 +2388,6 @@ int find6d_enqueue(const double* xy, const double* xyz, const int64_t* slot_base
   w.hyp_score = reinterpret_cast<double*>(wb + L.hyp_score);
   w.hyp_pose = reinterpret_cast<double*>(wb + L.hyp_pose);
   w.hyp_count = reinterpret_cast<int32_t*>(wb + L.hyp_count);
-  static const int use_prune = [] {         // EPOS_FIT_PRUNE=0: every hypothesis scores every point
-    const char* e = getenv("EPOS_FIT_PRUNE");
-    return e ? atoi(e) : 1;
-  }();
-  w.hyp_bound = use_prune ? reinterpret_cast<unsigned long long*>(wb + L.hyp_bound) : nullptr;
-  w.hyp_rounds = max_k + 2;
   w.active = reinterpret_cast<int32_t*>(wb + L.active);
   w.n_active = reinterpret_cast<int32_t*>(wb + L.n_active);
   w.done = reinterpret_cast<int32_t*>(wb + L.done);

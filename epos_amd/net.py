@@ -124,6 +124,8 @@ class EposNet(object):
     self.trace_layers, self.trace_outputs = [], {}
     self._exprs = {}
     self._last_bn = (None, None)
+    self.pad_rows = os.environ.get('EPOS_PAD_ROWS', '1') != '0'
+    self._lds = {}
     self._build_plan()
 
   # ------------------------------------------------------------ buffers ---
@@ -131,6 +133,23 @@ class EposNet(object):
     t = torch.empty(*shape, dtype=dtype, device=self.dev)
     self._keep.append(t)
     return t
+
+  def _act(self, b, h, w, c):
+    """Activation buffer [b, h, w, ld] for c channels: rows padded to a multiple of 32 floats
+    (128-byte lines) where c is not one already -- Xception's 728-channel tensors become 736
+    wide (+1.1 %) -- so that every pixel's channel vector starts on a line: the depthwise
+    kernel's per-XCD channel slices then share no line (csrc/layers.hip; a dense 728-float
+    row has 7 slice boundaries inside lines and ~30 % of the input is fetched by two XCDs),
+    and the GEMMs' A rows and C rows are line-aligned. The padding columns are never read or
+    written. EPOS_PAD_ROWS=0: dense rows (the A/B switch)."""
+    ld = (c + 31) // 32 * 32 if (self.pad_rows and c >= 256) else c
+    t = self._empty(b, h, w, ld)
+    self._lds[id(t)] = ld
+    return t
+
+  def _ld(self, buf):
+    """Row pitch (floats) of an activation buffer."""
+    return self._lds.get(id(buf), buf.shape[-1])
 
   def _dev(self, arr):
     t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.dev)
@@ -389,7 +408,8 @@ class EposNet(object):
     ho = hi if stride == 1 else (hi - 1) // 2 + 1
     wo = wi if stride == 1 else (wi - 1) // 2 + 1
     w9c, bias = self._dw_params(scope, eps)
-    y = self._empty(self.B, ho, wo, c)
+    y = self._act(self.B, ho, wo, c)
+    ldy = self._ld(y)
     ein = self._expr_of(x, 0, c)
     if relu_in:
       ein = self._relu_expr(ein)
@@ -397,14 +417,14 @@ class EposNet(object):
       ein = 'pad(%s,%d,%d)' % (ein, rate, rate)
     self._trace_layer(name, 'depthwise_conv2d', 3, stride, rate,
                       'SAME' if stride == 1 else 'VALID', c, c, eps, False, ein, (ho, wo))
-    self._set_expr(y, self._relu_expr('L:' + name) if relu_out else 'L:' + name)
+    self._set_expr(y, self._relu_expr('L:' + name) if relu_out else 'L:' + name, 0, c)
     xb = self._bound_of(x)
     if xb is not None:
       g, b0 = self._dw_gain, self._dw_bias0
       self._set_bound(y, xb[0], xb[1], g * (xb[2] if xb[2] else 1.0),
                       g * xb[3] + b0)
     args = _lib.DepthwiseArgs(
-        X=_ptr(x), ldx=ldx, w9c=_ptr(w9c), bias=_ptr(bias), Y=_ptr(y), ldy=c,
+        X=_ptr(x), ldx=ldx, w9c=_ptr(w9c), bias=_ptr(bias), Y=_ptr(y), ldy=ldy,
         B=self.B, Hi=hi, Wi=wi, Ho=ho, Wo=wo, C=c, stride=stride, rate=rate,
         relu_in=int(relu_in), relu_out=int(relu_out))
     yb = self._bound_of(y)
@@ -657,9 +677,9 @@ class EposNet(object):
     if skip == 'conv':
       # The shortcut GEMM shares a launch with the first pointwise conv.
       w_kn, sc, bi = self._conv_params(scope + '/shortcut', eps)
-      shortcut = self._empty(self.B, ho, wo, depths[2])
-      self._pointwise(scope + '/shortcut', x, 0, cin, self.B * ho * wo, cin,
-                      w_kn, sc, bi, shortcut, 0, depths[2], relu=False,
+      shortcut = self._act(self.B, ho, wo, depths[2])
+      self._pointwise(scope + '/shortcut', x, 0, self._ld(x), self.B * ho * wo, cin,
+                      w_kn, sc, bi, shortcut, 0, self._ld(shortcut), relu=False,
                       sub=stride, ho=ho, wo=wo, hi=hi, wi=wi, group=grp)
     r, rh, rw, rc = x, hi, wi, cin
     taps = {}
@@ -668,19 +688,19 @@ class EposNet(object):
       sc = '%s/separable_conv%d' % (scope, i + 1)
       s_i = stride if i == 2 else 1
       d, dh, dw_ = self._depthwise(
-          sc + '_depthwise', r, rc, rh, rw, rc, s_i, rate * unit_rates[i],
+          sc + '_depthwise', r, self._ld(r), rh, rw, rc, s_i, rate * unit_rates[i],
           sc + '_depthwise', eps, relu_in=(not act_in_sep) and not r_is_relu,
           relu_out=act_in_sep)
       w_kn, scl, bi = self._conv_params(sc + '_pointwise', eps)
-      y = self._empty(self.B, dh, dw_, depths[i])
+      y = self._act(self.B, dh, dw_, depths[i])
       res, ldr = None, 0
       if i == 2 and skip == 'conv':
-        res, ldr = shortcut, depths[2]
+        res, ldr = shortcut, self._ld(shortcut)
       elif i == 2 and skip == 'sum':
-        res, ldr = x, cin
+        res, ldr = x, self._ld(x)
       fold_next_relu = (not act_in_sep) and i < 2 and i not in linear_taps
-      self._pointwise(sc + '_pointwise', d, 0, rc, self.B * dh * dw_, rc, w_kn,
-                      scl, bi, y, 0, depths[i], relu=act_in_sep or fold_next_relu,
+      self._pointwise(sc + '_pointwise', d, 0, self._ld(d), self.B * dh * dw_, rc, w_kn,
+                      scl, bi, y, 0, self._ld(y), relu=act_in_sep or fold_next_relu,
                       res=res, ldr=ldr, group=grp if i == 0 else None)
       r_is_relu = fold_next_relu
       if i == 0:
@@ -763,7 +783,7 @@ class EposNet(object):
       d, _, _ = self._depthwise('aspp%d_depthwise' % i, x, ec, eh, ew, ec, 1, r,
                                 'aspp%d_depthwise' % i, HEAD_BN_EPS, False, True)
       w_kn, sc, bi = self._conv_params('aspp%d_pointwise' % i, HEAD_BN_EPS)
-      self._pointwise('aspp%d_pointwise' % i, d, 0, ec, m_enc, ec, w_kn, sc, bi,
+      self._pointwise('aspp%d_pointwise' % i, d, 0, self._ld(d), m_enc, ec, w_kn, sc, bi,
                       cat, 256 * (i + 1), ldcat, relu=True, group=grp)
     self._flush_group(grp)
     # the broadcast image-pooling branch is part of `cat` too: its absmax joins the slot
@@ -815,7 +835,7 @@ class EposNet(object):
                                 scope + '_depthwise', HEAD_BN_EPS, False, True)
       w_kn, sc, bi = self._conv_params(scope + '_pointwise', HEAD_BN_EPS)
       y = self._empty(B, dh, dw_, 256)
-      self._pointwise(scope + '_pointwise', d, 0, c, m_dec, c, w_kn, sc, bi, y,
+      self._pointwise(scope + '_pointwise', d, 0, self._ld(d), m_dec, c, w_kn, sc, bi, y,
                       0, 256, relu=True)
       x, c = y, 256
     self.decoder_out = x

@@ -619,6 +619,7 @@ def main(argv=None):
     real_ids = set((f.scene_id, f.im_id) for f in frames[i0:i0 + n_real])
     seen = set()
     for p in poses:
+      p.setdefault('time', rt.get('total', 0.0))
       key = (p['scene_id'], p['im_id'], p['obj_id'], float(p['score']))
       if (p['scene_id'], p['im_id']) in real_ids and key not in seen:
         seen.add(key)
@@ -651,6 +652,9 @@ def main(argv=None):
     feed.release(i0)                            # its staging buffer may be decoded into again
 
   inflight = []                                 # (pipeline, i0, chunk), oldest first
+  # HIP events around the stages (the per-image times the reference prints, infer.py:730-734);
+  # EPOS_INFER_TIMING=0 runs without them (diagnostics: tools/infer_diag.sh)
+  stage_timing = os.environ.get('EPOS_INFER_TIMING', '1') != '0'
   # where the host's time goes, per loop phase (printed with the throughput line): waiting for
   # decoded frames, waiting for the oldest step in flight, enqueueing a step, bookkeeping
   host_s = {'wait_frames': 0.0, 'wait_gpu': 0.0, 'launch': 0.0, 'finish': 0.0}
@@ -680,7 +684,7 @@ def main(argv=None):
     p = pipes[step % depth]
     p.launch(imgs, Ks, tg, task_type=args.task_type,
              image_ids=[f.im_id for f in chunk], scene_ids=[f.scene_id for f in chunk],
-             seed=args.seed, timing=True)
+             seed=args.seed, timing=stage_timing)
     inflight.append((p, i0, chunk))
     t_now = clock(); host_s['launch'] += t_now - t_mark; t_mark = t_now
   while inflight:

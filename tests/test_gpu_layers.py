@@ -359,6 +359,48 @@ def test_depthwise(lib, hi, wi, c, stride, rate, relu_in, relu_out):
   np.testing.assert_allclose(Y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('hi,wi,c,rate,h2', [(60, 80, 728, 2, 0), (60, 80, 728, 2, 1),
+                                             (17, 23, 728, 1, 1), (30, 40, 1024, 2, 1),
+                                             (24, 20, 264, 1, 0)])
+def test_depthwise_line_aligned_rows_equal_dense_rows(lib, hi, wi, c, rate, h2):
+  """Rows padded to a multiple of 32 floats (what the plan allocates since round 6: 728 -> 736)
+  take the line-aligned channel slices (an XCD's slice starts on a 128-byte line); the values
+  are those of the dense-row launch bit for bit, fp32 and fp16-pair output alike, and the
+  padding columns are never written."""
+  from epos_amd import _lib
+  rng = np.random.RandomState(c + hi)
+  b = 2
+  ld = (c + 31) // 32 * 32
+  assert ld != c or c % 32 == 0
+  x = rng.standard_normal((b, hi, wi, c)).astype(np.float32)
+  w9c = rng.standard_normal((9, c)).astype(np.float32)
+  bias = rng.standard_normal(c).astype(np.float32)
+  Wd, Bd = torch.from_numpy(w9c).cuda(), torch.from_numpy(bias).cuda()
+  slot = torch.zeros(64, dtype=torch.int32, device='cuda')
+  slot[5] = int(np.float32(np.abs(x).max()).view(np.int32))
+  gain = float(np.abs(w9c.astype(np.float64)).sum(0).max())
+  outs = []
+  for pad in (False, True):
+    l = ld if pad else c
+    X = torch.full((b, hi, wi, l), 7.0, device='cuda')
+    X[..., :c] = torch.from_numpy(x).cuda()
+    Y = torch.full((b, hi, wi, l), -3.0, device='cuda')
+    args = _lib.DepthwiseArgs(X=_p(X), ldx=l, w9c=_p(Wd), bias=_p(Bd), Y=_p(Y), ldy=l, B=b,
+                              Hi=hi, Wi=wi, Ho=hi, Wo=wi, C=c, stride=1, rate=rate, relu_in=1,
+                              relu_out=0)
+    if h2:
+      args.y_h2 = 1
+      args.x_amax = _p(slot)
+      args.gain, args.bias0 = gain, float(np.abs(bias).max())
+    _check(lib.epos_depthwise3x3_f32(ctypes.byref(args), None))
+    torch.cuda.synchronize()
+    out = Y.cpu().numpy()
+    if pad and l != c:
+      assert (out[..., c:] == -3.0).all()
+    outs.append(out[..., :c].copy())
+  assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
 @pytest.mark.parametrize('hi,wi,cin,cout,stride,pre', [(16, 20, 3, 32, 2, 1),
                                                        (15, 21, 3, 8, 2, 1),
                                                        (12, 16, 32, 64, 1, 0)])

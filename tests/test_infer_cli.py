@@ -397,3 +397,27 @@ def test_infer_eight_ranks_cover_32_frames_exactly_once(tmp_path):
     np.testing.assert_array_equal(x['t'], y['t'])
     seen[(x['im_id'], x['obj_id'], x['score'])] = seen.get((x['im_id'], x['obj_id'], x['score']), 0) + 1
   assert max(seen.values()) == 1                            # no frame fitted twice
+
+
+def test_entry_points_ask_for_one_hardware_queue_per_pipeline():
+  """infer.py and bench.py put GPU_MAX_HW_QUEUES into the environment BEFORE torch (and with
+  it the HIP runtime) is imported: with the runtime's default of four queues two of the four
+  pipelines share one and serialise against each other (profiles/r06/infer_diag_hw_queues.txt:
+  infer.py ran at 0.81 of bench.py until it did this too)."""
+  import ast
+  for name in ('infer.py', 'bench.py'):
+    tree = ast.parse(open(os.path.join(ROOT, name)).read())
+    set_at = torch_at = None
+    for node in tree.body:
+      src = ast.dump(node)
+      if set_at is None and 'GPU_MAX_HW_QUEUES' in src and 'setdefault' in src:
+        set_at = node.lineno
+      if torch_at is None and isinstance(node, (ast.Import, ast.ImportFrom)) and any(
+          a.name.split('.')[0] == 'torch' for a in node.names):
+        torch_at = node.lineno
+    assert set_at is not None and torch_at is not None and set_at < torch_at, (name, set_at, torch_at)
+  out = subprocess.run(
+      [sys.executable, '-c', 'import os, epos_amd; print(os.environ["GPU_MAX_HW_QUEUES"])'],
+      capture_output=True, text=True, cwd=ROOT, env={k: v for k, v in os.environ.items()
+                                                   if k != 'GPU_MAX_HW_QUEUES'})
+  assert out.stdout.strip() == '8', out.stdout + out.stderr

@@ -30,10 +30,12 @@ if '--one' in sys.argv:             # the middle-flow tensor only, few launches 
   shapes = shapes[:1]
   _t = timeit
   timeit = lambda fn, warm=3, it=5: _t(fn, warm, it)
+PAD = '--pad32' in sys.argv       # rows padded to a multiple of 32 floats (128-byte lines)
 for (h, w, c, rate) in shapes:
-  X = torch.randn(1, h, w, c, device='cuda'); Y = torch.empty_like(X)
+  ld = (c + 31) // 32 * 32 if PAD else c
+  X = torch.randn(1, h, w, ld, device='cuda'); Y = torch.empty_like(X)
   w9 = torch.randn(9, c, device='cuda'); b = torch.randn(c, device='cuda')
-  a = _lib.DepthwiseArgs(X=p(X), ldx=c, w9c=p(w9), bias=p(b), Y=p(Y), ldy=c, B=1, Hi=h, Wi=w,
+  a = _lib.DepthwiseArgs(X=p(X), ldx=ld, w9c=p(w9), bias=p(b), Y=p(Y), ldy=ld, B=1, Hi=h, Wi=w,
                          Ho=h, Wo=w, C=c, stride=1, rate=rate, relu_in=1, relu_out=0)
   if H2:
     import numpy as np

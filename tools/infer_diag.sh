@@ -19,8 +19,9 @@ run() {   # tag, env..., -- args
 {
 run base X=1 --
 run upload_copy EPOS_UPLOAD=copy --
-run threads EPOS_DECODE_PROCS=0 --
-run depth3 X=1 -- --pipeline_depth 3
+run no_events EPOS_INFER_TIMING=0 --
+run no_events_copy EPOS_INFER_TIMING=0 EPOS_UPLOAD=copy --
+run depth6 X=1 -- --pipeline_depth 6
 run depth5 X=1 -- --pipeline_depth 5
 run base_again X=1 --
 } | tee $OUT/infer_diag.txt

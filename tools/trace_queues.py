@@ -13,10 +13,19 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Queue_Id'], r['Kernel_Name'])
             for r in rows)
-t_lo = ev[0][0] + (ev[-1][1] - ev[0][0]) * skip
-ev = [e for e in ev if e[0] >= t_lo]
-t0, t1 = ev[0][0], max(e[1] for e in ev)
+# the window: from the step at `skip` of all steps (a step = one im2col3x3 launch, the
+# network's first kernel) to the step at 95 % -- set-up, warm-up and the drain stay outside
+steps = [e[0] for e in ev if 'im2col3x3' in e[3]]
+if len(steps) >= 20:
+  t_lo, t_hi = steps[int(len(steps) * skip)], steps[int(len(steps) * 0.95)]
+  n_steps = int(len(steps) * 0.95) - int(len(steps) * skip)
+else:
+  t_lo, t_hi, n_steps = ev[0][0] + (ev[-1][1] - ev[0][0]) * skip, ev[-1][1], 0
+ev = [e for e in ev if t_lo <= e[0] < t_hi]
+t0, t1 = t_lo, t_hi
 wall = t1 - t0
+if n_steps:
+  print('%d steps in the window: %.3f ms per step' % (n_steps, wall / n_steps / 1e6))
 
 
 def union(iv):
@@ -41,9 +50,9 @@ for q in sorted(set(e[2] for e in ev)):
   busy_sum += b
   gaps = [iv[i + 1][0] - max(x[1] for x in iv[:i + 1][-4:]) for i in range(len(iv) - 1)]
   gaps = [g for g in gaps if g > 0]
-  big = [g for g in gaps if g > 100000]                 # > 100 us: between steps
+  big = [g for g in gaps if g > 50000]                  # > 50 us: between steps
   nets = sum(1 for _, _, qq, n in ev if qq == q and 'im2col3x3' in n)
-  print('  queue %-3s %6d kernels, %4d steps (im2col launches); busy %5.1f %% of the window; gaps > 100 us: '
+  print('  queue %-3s %6d kernels, %4d steps (im2col launches); busy %5.1f %% of the window; gaps > 50 us: '
         '%4d, mean %.2f ms, sum %.1f %% of the window' % (
             q, len(iv), nets, 100.0 * b / wall, len(big),
             (sum(big) / len(big) / 1e6) if big else 0.0, 100.0 * sum(big) / wall))

@@ -141,6 +141,11 @@ def parse_args():
                   help='keep the raw random-init logits layers (every confidence '
                        'then stays below tau_a and corr/RANSAC get no work)')
   ap.add_argument('--no-graph', action='store_true')
+  ap.add_argument('--launch-queue', type=int, default=int(os.environ.get('EPOS_LAUNCH_QUEUE', '1')),
+                  help='batches enqueued per pipeline before the oldest is collected '
+                       '(EposPipeline(queue=)): with 2 a pipeline\'s next batch is already in its '
+                       'stream when the current one finishes, so the stream does not wait for the '
+                       'host between two batches')
   ap.add_argument('--pipeline-depth', type=int, default=0,
                   help='batches in flight per GPU: with >= 2, the fitting tail of '
                        'step i overlaps the network of step i+1 (two independent '
@@ -494,7 +499,7 @@ def main():
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
       capacity=1 << 20, max_instances=max(1, args.instances), device=dev,
       use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads,
-      model_options=mo, fitting_method=args.fitting_method)
+      model_options=mo, fitting_method=args.fitting_method, queue=max(1, args.launch_queue))
            for j in range(depth)]
   pipe = pipes[0]
   # Synthetic frames, resident in HBM before the timed region.
@@ -562,7 +567,7 @@ def main():
     local, inflight = [], []
     for i in range(first, first + count):
       p = ps[i % d]
-      if len(inflight) == d:
+      if len(inflight) == d * p.queue:      # the oldest batch in flight is this pipeline's
         local += inflight.pop(0).collect()[0]
       imgs, tg, idx = pool[i % n_pool]
       p.launch(imgs, Ks, tg, image_ids=idx, seed=i, after_net=planter(i % n_pool))
@@ -659,6 +664,7 @@ def main():
           'rccl_ranks_seen': (torch.distributed.get_world_size()
                               if torch.distributed.is_initialized() else 1),
           'hip_graph': not args.no_graph, 'pipeline_depth': depth,
+          'launch_queue': pipe.queue,
           'weights': args.weights,
           # which kernel every GEMM layer of the plan runs on: fp16-pair ("h2") layers and
           # layers whose weight matrix the fp16-pair packer refused (-> bf16 x 6 kernel)
@@ -719,6 +725,7 @@ def main():
   fitp = pipe.fit
   result['batch_per_gpu'] = B
   result['pipeline_depth'] = depth
+  result['launch_queue'] = pipe.queue
   result['fit'] = {'method': args.fitting_method, 'max_iters': int(fitp.max_iters),
                    'lo_iters': int(fitp.lo_iters), 'gc_sweeps': int(fitp.gc_sweeps),
                    'pearl_iters': int(fitp.pearl_iters), 'max_instances': args.instances,

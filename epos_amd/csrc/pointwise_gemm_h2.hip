@@ -62,6 +62,17 @@
 // K steps (commit 417060e: +-0). All of these are bit-identical and all deliver the same
 // ~380 TFLOP/s in steady state although their pipe utilisation in CYCLES differs (62-70 %):
 // the socket sits at its 1400 W cap there and the clock gives back what the schedule gains.
+// Round 6: (a) the scale of A is requested before and finished behind the prologue's LDS-DMA
+// issue in EVERY variant (the residual variants waited for it first); (b) built, bit-identical
+// (482 tests), measured and removed: workgroups that walk several tiles (grid = two per CU,
+// tile raw, raw + grid, ...; raw barriers without a fence, so that the stores of tile i are
+// still in flight while the pieces of tile i + 1 are issued) -- per launch 73.8 -> 74.6 us
+// (19200 x 728 x 728), 159.3 -> 161.7 (19200 x 4032 x 256, the heads' shape), 22.8 -> 23.3
+// (76800 x 128 x 128); end to end C2 +0.6 %, C3's shard -0.5 %, C5 -0.3 %; and the loop form cost
+// the group instantiations 26 VGPRs (224 -> 250-256) and the SINGLE ones, with their pinned
+// arguments carried around the loop, 380-816 bytes of scratch. The hardware already overlaps a
+// finishing workgroup's store drain with its CU's other workgroup. profiles/r06/ab_persist_*.txt,
+// persist_micro.txt; the code is commit 3f47a57.
 #include <string.h>
 
 #include <mutex>
@@ -319,30 +330,10 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
                  "s"(u1), "s"(u2), "s"(f0), "s"(f1));
     asm volatile("" : : "s"(i7), "s"(i8), "s"(i9), "s"(i10), "s"(i11), "s"(a9), "s"(l3));
   }
-  // A workgroup walks the tiles raw = blockIdx.x, + gridDim.x, ... (round 6). With one tile per
-  // workgroup (gridDim.x = number of tiles) this is the kernel of rounds 3-5. With fewer
-  // workgroups than tiles (launch_h2_tt: two per CU) the global stores of tile i are still in
-  // flight while the LDS-DMA pieces of tile i + 1 are issued: nothing between the last store
-  // and the next prologue waits for them -- raw barriers with an LDS-only wait, no fence --,
-  // they are simply older entries of the in-order vector-memory queue that the prologue's
-  // counted wait for its first stage drains anyway; and the successor tile pays neither a
-  // workgroup launch nor the kernel-argument round trip.
-  const int total_tiles = gp->tile_start[MAX_GROUP];
-  // (the SINGLE instantiations keep one tile per workgroup: their pinned kernel arguments
-  // live in ~60 SGPRs, and carried around a loop they spill -- 380-816 bytes of scratch; a
-  // single problem with more tiles than workgroup slots is launched in the group form)
-  int raw = blockIdx.x;                 // < total_tiles: the grid never exceeds the tile count
-  do {
-  if (!SINGLE && raw != static_cast<int>(blockIdx.x)) {
-    // every wave has read back its staged rows (and the absmax words) of the previous tile
-    // before any wave's LDS-DMA overwrites the ring
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
   int bid;
   {   // workgroups of one XCD (blockIdx % 8) take a contiguous range of tiles
-    const int total = total_tiles;
-    const int x = raw & 7, idx = raw >> 3;
+    const int total = gp->tile_start[MAX_GROUP];
+    const int raw = blockIdx.x, x = raw & 7, idx = raw >> 3;
     const int q = total >> 3, r = total & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
   }
@@ -810,7 +801,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
   H2_STAMP(3);
   // ---- epilogue --------------------------------------------------------------
 #ifdef EPOS_H2_ABL_NOEPI            // ablation (tools/power_components_h2.py): no epilogue
-  if (p.ldr != 0x7fffffff) continue;  // (always taken; the compiler cannot know)
+  if (p.ldr != 0x7fffffff) return;  // (always taken; the compiler cannot know)
 #endif
   if constexpr (!EARLY_EPI) {
     // (requesting these at the top of the last K step was tried: the residual variants sit
@@ -826,6 +817,9 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     float* ws = smem + wave * 32 * Geo::EP_ROW;
     float amax = vec_epilogue_h2<HAS_RES, NB>(ws, acc, corr, cn, EARLY_EPI ? bias4 : nullptr,
                                               inv_a, p, m0 + wrow * 32, n0w, lane);
+#ifdef EPOS_H2_AMAX_PER_WAVE      // A/B: the former one-atomic-per-wave publish
+    if (p.c_amax) { amax_publish(p.c_amax, amax, lane, blockIdx.x * NW + wave); return; }
+#endif
     if (p.c_amax) {
       // ONE atomic per workgroup: the workgroups of a launch finish together, and their
       // atomics all land on the slot's two cache lines -- one per wave (912 for a middle-flow
@@ -843,9 +837,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
       for (int o = 32; o > 0; o >>= 1) amax = xor_max(amax, o);
       float* red = smem + NW * 32 * Geo::EP_ROW;           // behind every wave's staged rows
       if (lane == 0) red[wave] = amax;
-      // LDS only: __syncthreads() would also wait for the tile's global stores (a fence)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      __syncthreads();
       if (wave == 0) {
         float v = lane < NW ? red[lane] : 0.f;
 #pragma unroll
@@ -859,7 +851,7 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores acknowledged
     H2_STAMP(4);
 #endif
-    continue;
+    return;
   }
   if constexpr (!EARLY_EPI) {
 #pragma unroll
@@ -893,31 +885,6 @@ void pointwise_gemm_h2_f32(GroupedArgs ga_) {
       if (m < M && n < N) p.C[static_cast<int64_t>(m) * p.ldc + n] = v;
     }
   }
-  } while (!SINGLE && (raw += gridDim.x) < total_tiles);   // tiles of this workgroup
-}
-
-// Workgroups of a launch: one per tile, or -- EPOS_H2_PERSIST=1 -- at most two per CU, each
-// walking tiles raw, raw + grid, ... (a multiple of 8, so a workgroup's tiles stay in its XCD's
-// range). Same bits either way.
-int h2_persist() {
-  static const int persist = [] {
-    const char* e = getenv("EPOS_H2_PERSIST");
-    return e ? atoi(e) : 0;
-  }();
-  return persist;
-}
-int h2_grid(int total, bool single) {
-  if (!h2_persist() || single) return total;
-  static const int slots = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      int v = 0;
-      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-        cus = v;
-    }
-    return (2 * cus) & ~7;
-  }();
-  return total < slots ? total : slots;
 }
 
 template <bool HAS_RES, bool SINGLE, bool CONV, bool PRESPLIT = false, int NB = 4>
@@ -932,7 +899,7 @@ int launch_h2_tt(const GroupedArgs& g, int total, hipStream_t s) {
     if (rc) return rc;
   }
   // 80 KB (60 KB) per workgroup: at most two per CU = two MFMA waves per SIMD
-  hipLaunchKernelGGL(kern, dim3(h2_grid(total, SINGLE)), dim3(256), lds, s, g);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(256), lds, s, g);
   return launch_status("pointwise_gemm_h2_f32");
 }
 
@@ -1179,9 +1146,7 @@ int launch_grouped_h2(const EposPointwiseArgs* args, int count, hipStream_t s,
     return EPOS_E_INVALID;
   }
   const bool res = args[0].R != nullptr;
-  // one problem with more tiles than the chip has workgroup slots: the group form, whose
-  // workgroups walk several tiles each (EPOS_H2_PERSIST=1)
-  const bool single = count == 1 && !(h2_persist() && total > h2_grid(total, false) && !args[0].R);
+  const bool single = count == 1;
   const bool ps = args[0].a_presplit != 0;
   // Kernel instantiations (11): 128 x 128 tiles -- single problem {residual} x {pre-split A},
   // group {pre-split A}, implicit 3x3 conv; 128 x 64 tiles (always the group form, which also

@@ -807,11 +807,14 @@ class EposNet(object):
     dh = scale_dimension(H, 1.0 / 4)
     dw_ = scale_dimension(Wd, 1.0 / 4)
     assert (lh, lw) == (dh, dw_), ((lh, lw), (dh, dw_))
+    # (padding the concat's rows 304 -> 320 and the stem's im2col rows 28 -> 32 as well:
+    # measured neutral, profiles/r06/ab_pad_level.txt -- left dense)
     dcat = self._empty(B, dh, dw_, 304)
+    ldd = self._ld(dcat)
 
-    def run_up(stream, proj=proj, dcat=dcat):
+    def run_up(stream, proj=proj, dcat=dcat, ldd=ldd):
       _lib.check(lib.epos_resize_bilinear_f32(
-          _ptr(proj), 256, _ptr(dcat), 304, B, eh, ew, dh, dw_, 256, stream),
+          _ptr(proj), 256, _ptr(dcat), ldd, B, eh, ew, dh, dw_, 256, stream),
                  'decoder/resize')
     self._add('decoder/resize', run_up)
     self._set_expr(dcat, self._expr_of(proj) if (eh, ew) == (dh, dw_) else
@@ -819,7 +822,7 @@ class EposNet(object):
     m_dec = B * dh * dw_
     w_kn, sc, bi = self._conv_params('decoder/feature_projection0', HEAD_BN_EPS)
     self._pointwise('decoder/feature_projection0', ll, 0, lc, m_dec, lc, w_kn,
-                    sc, bi, dcat, 256, 304, relu=True)
+                    sc, bi, dcat, 256, ldd, relu=True)
     # dcat = [bilinear resize of proj | feature projection]: an interpolation never
     # exceeds its input's absmax, so the concat is bounded by the two producers' slots
     pb, fb = self._bound_of(proj), self._bound_of(dcat)
@@ -827,11 +830,11 @@ class EposNet(object):
       self._set_bound(dcat, fb[0], pb[0])
     else:
       self._bounds.pop(id(dcat), None)
-    self.decoder_concat = dcat
+    self.decoder_concat = dcat[..., :304]
     x, c = dcat, 304
     for j in range(2):
       scope = 'decoder/decoder_conv%d' % j
-      d, _, _ = self._depthwise(scope + '_depthwise', x, c, dh, dw_, c, 1, 1,
+      d, _, _ = self._depthwise(scope + '_depthwise', x, self._ld(x), dh, dw_, c, 1, 1,
                                 scope + '_depthwise', HEAD_BN_EPS, False, True)
       w_kn, sc, bi = self._conv_params(scope + '_pointwise', HEAD_BN_EPS)
       y = self._empty(B, dh, dw_, 256)

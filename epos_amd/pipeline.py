@@ -39,13 +39,23 @@ class EposPipeline(object):
                corr_min_frag_rel_conf=0.5, max_slots=None, capacity=1 << 20,
                max_instances=4, model_options=None, device='cuda:0',
                use_graph=True, instance=0, sparse_heads=False,
-               fitting_method='progressive_x', on_excess='raise'):
+               fitting_method='progressive_x', on_excess='raise', queue=1):
     """on_excess: what launch() does with a frame that asks for more instances of an object
     than `max_instances` (localization): 'raise' (default: EposError BEFORE anything of that
     batch is enqueued -- batches already in flight on other pipelines are unaffected and can
     still be collected) or 'clamp' (fit `max_instances` of them and warn once)."""
     if on_excess not in ('raise', 'clamp'):
       raise ValueError("on_excess must be 'raise' or 'clamp'")
+    # queue: how many batches launch() accepts before a collect() (round 6). With 2 the
+    # caller enqueues a pipeline's NEXT batch while the current one still runs, so the
+    # pipeline's stream never waits for the host between two batches (collect -> bookkeeping
+    # -> next frames -> launch: 0.3-0.5 ms per step otherwise). Batches of one pipeline run in
+    # stream order on the same device buffers; only the host-side staging (metadata, results,
+    # events) exists `queue` times. Readers of the plan's device buffers after collect()
+    # (net.outputs(), --vis, --save_corresp) need queue=1.
+    if queue < 1:
+      raise ValueError('queue must be >= 1')
+    self.queue = int(queue)
     self.on_excess = on_excess
     self.lib = _lib.load()
     # 'progressive_x' (infer.py:446-503) or 'opencv_ransac' (infer.py:505-528: one
@@ -117,12 +127,12 @@ class EposPipeline(object):
                                      ('overflow', 'i4', 1)])
     self.meta_dev = torch.zeros(self._meta_layout['_size'], dtype=torch.uint8,
                                 device=d)
-    self.meta_host = torch.zeros(self._meta_layout['_size'],
-                                 dtype=torch.uint8).pin_memory()
+    self._meta_hosts = [torch.zeros(self._meta_layout['_size'], dtype=torch.uint8).pin_memory()
+                        for _ in range(self.queue)]
     self.res_dev = torch.zeros(self._res_layout['_size'], dtype=torch.uint8,
                                device=d)
-    self.res_host = torch.zeros(self._res_layout['_size'],
-                                dtype=torch.uint8).pin_memory()
+    self._res_hosts = [torch.zeros(self._res_layout['_size'], dtype=torch.uint8).pin_memory()
+                       for _ in range(self.queue)]
     mv = lambda buf, lay, k: self._view(buf, lay, k)     # noqa: E731
     self.Ks = mv(self.meta_dev, self._meta_layout, 'Ks')
     self.seeds = mv(self.meta_dev, self._meta_layout, 'seeds')
@@ -134,9 +144,11 @@ class EposPipeline(object):
     self.corr.totals = mv(self.res_dev, self._res_layout, 'totals').view(S, 2)
     self.corr.overflow = mv(self.res_dev, self._res_layout, 'overflow')
     self.stream = torch.cuda.Stream(self.dev)
-    self._done = torch.cuda.Event()
-    self._pending = None
-    self._ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    self._dones = [torch.cuda.Event() for _ in range(self.queue)]
+    self._pending = collections.deque()        # launched, not yet collected (oldest first)
+    self._launches = 0
+    self._evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                 for _ in range(self.queue)]
 
   _DT = {'f8': (torch.float64, 8), 'i8': (torch.int64, 8), 'i4': (torch.int32, 4)}
 
@@ -207,8 +219,11 @@ class EposPipeline(object):
     tail with the next batch's network. after_net: optional callable(pipeline), invoked on
     the pipeline's stream between the network and the correspondence stage (bench.py
     --planted-poses overwrites head values there)."""
-    if self._pending is not None:
-      raise _lib.EposError('launch() called twice without collect()')
+    if len(self._pending) >= self.queue:
+      raise _lib.EposError('launch() called %s without collect()' % (
+          'twice' if self.queue == 1 else '%d times' % (self.queue + 1)))
+    q = self._launches % self.queue            # host-side staging of this batch
+    ev, mh, res_host, done = self._evs[q], self._meta_hosts[q], self._res_hosts[q], self._dones[q]
     B = self.B
     slots, wants = self.make_slots(targets, task_type)
     S = len(slots)
@@ -219,18 +234,18 @@ class EposPipeline(object):
     self.stream.wait_stream(cur)            # inputs produced on the caller's stream
     with torch.cuda.stream(self.stream):
       if timing:
-        self._ev[0].record()
+        ev[0].record()
       pred = self.net.forward(images, use_graph=self.use_graph,
                               sparse=self.sparse_heads)
       if timing and not self.sparse_heads:
-        self._ev[1].record()
+        ev[1].record()
       if S:
         if S > self.max_slots:
           raise ValueError('too many slots (%d > %d)' % (S, self.max_slots))
         Ksl = np.asarray(Ks, np.float64).reshape(B, 9)[[s[0] for s in slots]]
         sd = [(seed * 1000003 + (image_ids[im] if image_ids is not None else im)
                * 1009 + obj) & 0x7fffffffffffffff for im, obj in slots]
-        mh, ml = self.meta_host, self._meta_layout
+        ml = self._meta_layout
         self._view(mh, ml, 'Ks')[:S * 9] = torch.from_numpy(Ksl.reshape(-1))
         self._view(mh, ml, 'seeds')[:S] = torch.tensor(sd, dtype=torch.int64)
         self._view(mh, ml, 'slots')[:S * 2] = torch.tensor(
@@ -242,7 +257,7 @@ class EposPipeline(object):
         if self.sparse_heads:
           self.head_flops = self.net.run_sparse_heads(slots, self.corr.slots)
           if timing:
-            self._ev[1].record()
+            ev[1].record()
         if after_net is not None:
           after_net(self)
         self.corr.count(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
@@ -250,7 +265,7 @@ class EposPipeline(object):
         self.corr.fill(pred[W.PRED_OBJ_CONF], pred[W.PRED_FRAG_CONF],
                        pred[W.PRED_FRAG_LOC], self.output_scale)
         if timing:
-          self._ev[2].record()
+          ev[2].record()
         if self.fitting_method == 'opencv_ransac':
           # one pose per slot: poses [S, 1, 12], num_models = success flag, scores 0.0; the
           # inlier mask (u8 per correspondence) lands in the bytes of the label buffer
@@ -271,24 +286,24 @@ class EposPipeline(object):
               ctypes.c_void_p(self.stream.cuda_stream)), 'epos_find6d_poses_device')
         # NB: poses / scores are laid out [S, max_k(call), ...] for this call.
         if timing:
-          self._ev[3].record()
-        self.res_host.copy_(self.res_dev, non_blocking=True)  # one D2H
-      self._done.record()
-    self._pending = (slots, wants, max_k, image_ids, scene_ids, timing)
+          ev[3].record()
+        res_host.copy_(self.res_dev, non_blocking=True)       # one D2H
+      done.record()
+    self._launches += 1
+    self._pending.append((slots, wants, max_k, image_ids, scene_ids, timing, q))
 
   def collect(self):
     """Waits for the batch enqueued by ``launch()``; returns (poses, run_times)
     like process_image (infer.py:348-554)."""
-    if self._pending is None:
+    if not self._pending:
       raise _lib.EposError('collect() without launch()')
-    slots, wants, max_k, image_ids, scene_ids, timing = self._pending
-    self._pending = None
-    self._done.synchronize()                  # the one synchronisation
+    slots, wants, max_k, image_ids, scene_ids, timing, q = self._pending.popleft()
+    self._dones[q].synchronize()              # the one synchronisation
     S = len(slots)
     self.last_cap_hits = []
     poses_out = []
     if S:
-      rh, rl = self.res_host, self._res_layout
+      rh, rl = self._res_hosts[q], self._res_layout
       if int(self._view(rh, rl, 'overflow')[0]):
         raise _lib.EposError(
             'correspondence capacity (%d rows) exceeded' % self.corr.capacity)
@@ -330,7 +345,7 @@ class EposPipeline(object):
           })
     run_times = {}
     if timing and S:
-      e = self._ev
+      e = self._evs[q]
       run_times = {'prediction': e[0].elapsed_time(e[1]) * 1e-3,
                    'establish_corr': e[1].elapsed_time(e[2]) * 1e-3,
                    'fitting': e[2].elapsed_time(e[3]) * 1e-3}

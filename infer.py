@@ -159,6 +159,11 @@ def build_parser():
          'reference\'s loop). --vis, --save_corresp and the operator path (--use_prosac, '
          '--max_correspondences, --project_to_surface) read the plan\'s buffers after every '
          'step and always run at depth 1. The poses do not depend on the depth.')
+  a('--launch_queue', type=int, default=int(os.environ.get('EPOS_LAUNCH_QUEUE', '1')),
+    help='batches enqueued per plan before the oldest is collected: with 2 a plan\'s next '
+         'batch is already in its stream when the current one finishes (the stream does not wait '
+         'for the host between two batches). 1 whenever --vis / --save_corresp / the operator '
+         'path read the plan\'s buffers after a step. The poses do not depend on it.')
   a('--sparse_heads', default='auto',
     help='evaluate the fragment heads only for the target objects of each image. '
          'corresp.establish_many_to_many never reads the other objects\' channels in '
@@ -564,8 +569,10 @@ def main(argv=None):
   needs_dense = bool(operator_path or args.save_corresp or args.vis)
   depth = args.pipeline_depth if args.pipeline_depth > 0 else (
       4 if B == 1 else 2 if B >= 4 else 3)         # bench.py's rule
+  lq = max(1, args.launch_queue)
   if needs_dense:
     depth = 1                      # those paths read the plan's buffers after the step
+    lq = 1
   sh = str(args.sparse_heads).lower()
   if sh == 'auto':
     sparse_heads = args.task_type == pipeline.LOCALIZATION and not needs_dense
@@ -578,19 +585,20 @@ def main(argv=None):
   # decoded before the loop below asks for it
   from epos_amd import frames as eframes
   feed = eframes.Prefetcher(frames, B, h, w, workers=args.decode_threads or None,
-                            ahead=max(1, args.prefetch), inflight=depth)
+                            ahead=max(1, args.prefetch), inflight=depth * lq)
   pipes = [pipeline.EposPipeline(
       ckpt, B, h, w, num_objs, args.num_frags, store, fit_params=fit,
       corr_min_obj_conf=args.corr_min_obj_conf,
       corr_min_frag_rel_conf=args.corr_min_frag_rel_conf,
       max_instances=max_inst, model_options=mo, device=dev, instance=j,
-      sparse_heads=sparse_heads, fitting_method=args.fitting_method)
+      sparse_heads=sparse_heads, fitting_method=args.fitting_method, queue=lq)
            for j in range(depth)]
   pipe = pipes[0]
   if rank == 0:
-    print('plan: {} image(s) per step, {} step(s) in flight, {} heads, {} GEMM layers on the '
+    print('plan: {} image(s) per step, {} step(s) in flight{}, {} heads, {} GEMM layers on the '
           'fp16-pair kernel ({} on the bf16 x 6 fallback)'.format(
-              B, depth, 'sparse' if sparse_heads else 'dense', len(pipe.net.h2_layers),
+              B, depth, ' x {} enqueued per plan'.format(lq) if lq > 1 else '',
+              'sparse' if sparse_heads else 'dense', len(pipe.net.h2_layers),
               len(pipe.net.h2_refused)))
 
   # Set-up, not inference: every plan captures its hipGraph and loads its kernels on first
@@ -675,7 +683,7 @@ def main(argv=None):
       finish(i0, chunk, poses, rt)
       t_mark = clock()
       continue
-    if len(inflight) == depth:
+    if len(inflight) == depth * lq:
       q, j0, ch = inflight.pop(0)
       res = q.collect()
       t_now = clock(); host_s['wait_gpu'] += t_now - t_mark; t_mark = t_now

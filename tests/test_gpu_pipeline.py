@@ -257,3 +257,43 @@ def test_object_ids_without_channels_are_rejected():
     corresp.establish_many_to_many(z((16, 16, O + 1), 'f'), z((16, 16, O, F), 'f'),
                                    z((16, 16, O, F, 3), 'f'), [3], store, 0.25, 0.1,
                                    0.5, False, True)
+
+
+def test_two_batches_enqueued_per_pipeline_give_the_poses_of_one():
+  """EposPipeline(queue=2): launch() accepts a second batch before the first is collected (the
+  stream then never waits for the host between two batches); the batches run in stream order on
+  the same device buffers and only the host-side staging exists twice. Poses, scores and stage
+  timers' keys are those of the queue=1 pipeline, batch by batch; a third launch raises."""
+  from epos_amd import _lib, pipeline, weights
+  O, F, B, H, W_ = 3, 64, 1, 96, 128
+  ckpt = weights.random_init(num_objs=O, seed=5, randomize_bn=True, logits_std=0.6)
+  store = Store(O, F)
+  Ks = np.tile(np.array([[300., 0, 64], [0, 300., 48], [0, 0, 1]]), (B, 1, 1))
+  frames = [torch.from_numpy(np.random.RandomState(10 + i).randint(0, 256, (B, H, W_, 3)).astype(
+      'f')).cuda() for i in range(5)]
+  targets = [[{1: 1, 3: 1}], [{2: 1}], [{1: 1, 2: 1, 3: 1}], [{3: 1}], [{1: 1}]]
+  one = pipeline.EposPipeline(ckpt, B, H, W_, O, F, store, capacity=1 << 18)
+  exp = [one.process_batch(frames[i], Ks, targets[i], image_ids=[i], seed=3, timing=True)
+         for i in range(5)]
+  two = pipeline.EposPipeline(ckpt, B, H, W_, O, F, store, capacity=1 << 18, queue=2)
+  got, n_in = [], 0
+  for i in range(5):
+    if n_in == 2:
+      got.append(two.collect()); n_in -= 1
+    two.launch(frames[i], Ks, targets[i], image_ids=[i], seed=3, timing=True)
+    n_in += 1
+    if i == 1:
+      with pytest.raises(_lib.EposError):
+        two.launch(frames[i], Ks, targets[i], image_ids=[i], seed=3)
+  while n_in:
+    got.append(two.collect()); n_in -= 1
+  with pytest.raises(_lib.EposError):
+    two.collect()
+  assert len(got) == 5 and sum(len(p) for p, _ in exp) >= 3
+  for (pe, te), (pg, tg) in zip(exp, got):
+    assert set(te) == set(tg)
+    assert len(pe) == len(pg)
+    for a, b in zip(pe, pg):
+      assert (a['im_id'], a['obj_id']) == (b['im_id'], b['obj_id'])
+      assert np.array_equal(a['R'], b['R']) and np.array_equal(a['t'], b['t'])
+      assert a['score'] == b['score']

@@ -25,3 +25,12 @@ a = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Wh), bias=p(b), R=None, ldr=n, C=p(C)
                        relu_in=0, sub=1, Wh=p(Wh), a_amax=p(slot), a_presplit=1 if ps else 0, c_amax=p(cs))
 for _ in range(it): _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
 torch.cuda.synchronize()
+if '--time' in sys.argv:          # warm launches back to back, HIP events (round 6: EPOS_H2_PERSIST A/B)
+  for _ in range(200): lib.epos_pointwise_conv_f32(ctypes.byref(a), None)
+  e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(200): lib.epos_pointwise_conv_f32(ctypes.byref(a), None)
+  e1.record(); torch.cuda.synchronize()
+  us = e0.elapsed_time(e1) / 200 * 1e3
+  print('%d x %d x %d%s: %.1f us per launch, %.0f TFLOP/s fp32-equivalent' % (
+      m, n, k, ' presplit' if ps else '', us, 2.0 * m * n * k / us / 1e6))

@@ -141,11 +141,12 @@ def parse_args():
                   help='keep the raw random-init logits layers (every confidence '
                        'then stays below tau_a and corr/RANSAC get no work)')
   ap.add_argument('--no-graph', action='store_true')
-  ap.add_argument('--launch-queue', type=int, default=int(os.environ.get('EPOS_LAUNCH_QUEUE', '1')),
+  ap.add_argument('--launch-queue', type=int, default=int(os.environ.get('EPOS_LAUNCH_QUEUE', '2')),
                   help='batches enqueued per pipeline before the oldest is collected '
                        '(EposPipeline(queue=)): with 2 a pipeline\'s next batch is already in its '
                        'stream when the current one finishes, so the stream does not wait for the '
-                       'host between two batches')
+                       'host between two batches (default 2: +0.3..+0.8 %, profiles/r06/ab_launch_queue_*.txt; '
+                       'the strictly serial figure serial_depth1 always launches and collects one at a time)')
   ap.add_argument('--pipeline-depth', type=int, default=0,
                   help='batches in flight per GPU: with >= 2, the fitting tail of '
                        'step i overlaps the network of step i+1 (two independent '
@@ -499,7 +500,7 @@ def main():
       ckpt, B, args.height, args.width, args.num_objs, args.num_frags, store,
       capacity=1 << 20, max_instances=max(1, args.instances), device=dev,
       use_graph=not args.no_graph, instance=j, sparse_heads=args.sparse_heads,
-      model_options=mo, fitting_method=args.fitting_method, queue=max(1, args.launch_queue))
+      model_options=mo, fitting_method=args.fitting_method, queue=max(1, args.launch_queue) if depth > 1 else 1)
            for j in range(depth)]
   pipe = pipes[0]
   # Synthetic frames, resident in HBM before the timed region.
@@ -556,7 +557,7 @@ def main():
   clk_stream = None      # created after the timed region (an extra stream changes
                          # the stream -> hardware-queue mapping of the pipelines)
 
-  def run(first, count, probe=False, use=None):
+  def run(first, count, probe=False, use=None, one_at_a_time=False):
     """`count` steps; step i is launched on pipes[i % depth] after the step that
     used that pipeline `depth` steps earlier has been collected. Every step is
     complete (its poses on this rank's host) on return; the ranks' records are then
@@ -567,7 +568,7 @@ def main():
     local, inflight = [], []
     for i in range(first, first + count):
       p = ps[i % d]
-      if len(inflight) == d * p.queue:      # the oldest batch in flight is this pipeline's
+      if len(inflight) == d * (1 if one_at_a_time else p.queue):   # the oldest in flight is this pipeline's
         local += inflight.pop(0).collect()[0]
       imgs, tg, idx = pool[i % n_pool]
       p.launch(imgs, Ks, tg, image_ids=idx, seed=i, after_net=planter(i % n_pool))
@@ -798,11 +799,11 @@ def main():
   serial = None
   if not args.no_stage_times:
     k = max(3, min(args.steps, 10))
-    run(0, 2, use=[pipes[0]])
+    run(0, 2, use=[pipes[0]], one_at_a_time=True)
     torch.cuda.synchronize()
     edist.barrier()
     t1 = time.perf_counter()
-    run(2, k, use=[pipes[0]])
+    run(2, k, use=[pipes[0]], one_at_a_time=True)
     torch.cuda.synchronize()
     dt = edist.max_over_ranks(time.perf_counter() - t1)
     stage = {}

@@ -159,7 +159,7 @@ def build_parser():
          'reference\'s loop). --vis, --save_corresp and the operator path (--use_prosac, '
          '--max_correspondences, --project_to_surface) read the plan\'s buffers after every '
          'step and always run at depth 1. The poses do not depend on the depth.')
-  a('--launch_queue', type=int, default=int(os.environ.get('EPOS_LAUNCH_QUEUE', '1')),
+  a('--launch_queue', type=int, default=int(os.environ.get('EPOS_LAUNCH_QUEUE', '2')),
     help='batches enqueued per plan before the oldest is collected: with 2 a plan\'s next '
          'batch is already in its stream when the current one finishes (the stream does not wait '
          'for the host between two batches). 1 whenever --vis / --save_corresp / the operator '
@@ -573,6 +573,8 @@ def main(argv=None):
   if needs_dense:
     depth = 1                      # those paths read the plan's buffers after the step
     lq = 1
+  if depth == 1:
+    lq = 1                         # strictly one batch at a time means launch -> collect
   sh = str(args.sparse_heads).lower()
   if sh == 'auto':
     sparse_heads = args.task_type == pipeline.LOCALIZATION and not needs_dense

@@ -19,7 +19,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 2>$OUT/bench_driver_cmd.err | tai
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_driver_cmd_again.json
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_100steps.json
 python bench.py --steps 100 --warmup 10 --sparse-heads --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_sparse_heads.json
-EPOS_GEMM_SPLIT=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_fp32_mfma.json
+EPOS_HIP_LIB=$PWD/epos_amd/lib/libepos_hip_ref.so EPOS_GEMM_SPLIT=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_fp32_mfma.json
 EPOS_GEMM_H2=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_bf16x6.json
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_100steps_b.json
 # the other BASELINE configurations
@@ -46,5 +46,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/pmc_traffic.py --merge $OUT/pmc_FETCH_SIZE.json $OUT/pmc_WRITE_SIZE.json > $OUT/gemm_hbm_traffic_pmc.json
 python tools/bench_ransac.py > $OUT/ransac_microbench.txt 2>&1
+# round 6: the planted workload (fitting stage with EPOS-like inlier ratios) next to the default
+for f in 0.3 0.5 0.7; do
+  python bench.py --planted-poses --planted-outliers $f --steps 60 --warmup 8 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_planted_c2_$f.json
+done
+python bench.py --planted-poses --planted-outliers 0.5 --height 540 --width 720 --num-objs 30 --objs-per-image 8 --instances 2 --pipeline-depth 3 --steps 40 --warmup 5 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_planted_c4_0.5.json
+python bench.py --weights heavy-tailed --steps 60 --warmup 8 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_weights_heavy_tailed.json
 rm -rf $OUT/kt1 $OUT/kt4 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT

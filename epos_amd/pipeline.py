@@ -32,6 +32,23 @@ def _ptr(t):
   return ctypes.c_void_p(t.data_ptr())
 
 
+_STREAMS = {}
+
+
+def _pipeline_stream(dev, instance):
+  """The HIP stream of pipeline number `instance` on a device: created once per process and
+  handed out again when a pipeline with that number is built anew. Streams land on the
+  runtime's hardware queues in creation order: the first four a process creates get queues of
+  their own (GPU_MAX_HW_QUEUES=8), a second set of four ran 0.29 ms per step slower (2.06 ->
+  2.36 ms; some of them share a queue), a third set as fast as the first
+  (profiles/r06/stream_sets_and_hw_queues.txt). A process that rebuilds its pipelines therefore
+  keeps the streams it had."""
+  key = (str(dev), int(instance))
+  if key not in _STREAMS:
+    _STREAMS[key] = torch.cuda.Stream(dev)
+  return _STREAMS[key]
+
+
 class EposPipeline(object):
 
   def __init__(self, checkpoint, batch, height, width, num_objs, num_frags,
@@ -143,7 +160,7 @@ class EposPipeline(object):
     self.num_models = mv(self.res_dev, self._res_layout, 'num_models')
     self.corr.totals = mv(self.res_dev, self._res_layout, 'totals').view(S, 2)
     self.corr.overflow = mv(self.res_dev, self._res_layout, 'overflow')
-    self.stream = torch.cuda.Stream(self.dev)
+    self.stream = _pipeline_stream(self.dev, instance)
     self._dones = [torch.cuda.Event() for _ in range(self.queue)]
     self._pending = collections.deque()        # launched, not yet collected (oldest first)
     self._launches = 0

@@ -24,7 +24,7 @@ EPOS_GEMM_H2=0 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traff
 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_100steps_b.json
 # the other BASELINE configurations
 python bench.py --steps 60 --warmup 5 --num-objs 1 --objs-per-image 1 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c1.json
-python bench.py --steps 40 --warmup 5 --height 540 --width 720 --num-objs 30 --objs-per-image 8 --instances 2 --pipeline-depth 3 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c4.json
+python bench.py --steps 40 --warmup 5 --height 540 --width 720 --num-objs 30 --objs-per-image 8 --instances 2 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c4.json
 python bench.py --steps 20 --warmup 3 --model-variant resnet_v1_101_beta --num-objs 15 --batch-per-gpu 8 --pipeline-depth 2 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c5.json
 python bench.py --steps 40 --warmup 5 --batch-per-gpu 4 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_c3_shard_batch4.json
 for d in 4 1; do
@@ -50,7 +50,7 @@ python tools/bench_ransac.py > $OUT/ransac_microbench.txt 2>&1
 for f in 0.3 0.5 0.7; do
   python bench.py --planted-poses --planted-outliers $f --steps 60 --warmup 8 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_planted_c2_$f.json
 done
-python bench.py --planted-poses --planted-outliers 0.5 --height 540 --width 720 --num-objs 30 --objs-per-image 8 --instances 2 --pipeline-depth 3 --steps 40 --warmup 5 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_planted_c4_0.5.json
+python bench.py --planted-poses --planted-outliers 0.5 --height 540 --width 720 --num-objs 30 --objs-per-image 8 --instances 2 --steps 40 --warmup 5 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_planted_c4_0.5.json
 python bench.py --weights heavy-tailed --steps 60 --warmup 8 --no-cpu-baseline --traffic static 2>/dev/null | tail -1 > $OUT/bench_weights_heavy_tailed.json
 rm -rf $OUT/kt1 $OUT/kt4 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT

@@ -25,6 +25,10 @@ a = _lib.PointwiseArgs(A=p(A), lda=k, Wp=p(Wh), bias=p(b), R=None, ldr=n, C=p(C)
                        relu_in=0, sub=1, Wh=p(Wh), a_amax=p(slot), a_presplit=1 if ps else 0, c_amax=p(cs))
 for _ in range(it): _lib.check(lib.epos_pointwise_conv_f32(ctypes.byref(a), None))
 torch.cuda.synchronize()
+if '--copy' in sys.argv:          # a plain copy of A beside the GEMM (PMC calibration)
+  B2 = torch.empty_like(A)
+  for _ in range(it): B2.copy_(A)
+  torch.cuda.synchronize()
 if '--time' in sys.argv:          # warm launches back to back, HIP events (round 6: EPOS_H2_PERSIST A/B)
   for _ in range(200): lib.epos_pointwise_conv_f32(ctypes.byref(a), None)
   e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

@@ -253,7 +253,7 @@ def test_infer_streaming_default_matches_the_serial_dense_run(tmp_path):
     plan = [l for l in out.stdout.split('\n') if l.startswith('plan:')][0]
     assert ('1 step(s) in flight, dense' in plan) == (name == 'serial'), plan
     if name == 'default':
-      assert '4 step(s) in flight, sparse' in plan, plan
+      assert '4 step(s) in flight x 2 enqueued per plan, sparse' in plan, plan
     assert 'Throughput:' in out.stdout
     txt = (models / 'toy' / 'infer' / 'estimated-poses.csv').read_text().strip().split('\n')
     rows[name] = [','.join(r.split(',')[:-1]) for r in txt]
